@@ -1,0 +1,63 @@
+"""Build libcelebbasis_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU).
+
+The library links only the HIP runtime; it has no torch/ATen dependency (the boundary is a plain C ABI,
+include/celebbasis_hip.h). Object files are cached under celebbasis_amd/_build and rebuilt when a source
+or header is newer.
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+BUILD = os.path.join(HERE, "_build")
+LIB = os.path.join(HERE, "libcelebbasis_hip.so")
+SOURCES = ["cb_gemm.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip", "cb_abi.hip"]
+HEADERS = ["cb_common.h", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
+         "-Wno-unused-lambda-capture", "-Wno-unused-result"]
+
+
+def _hipcc():
+    for c in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if c and (os.path.isabs(c) and os.path.exists(c) or not os.path.isabs(c)):
+            return c
+    return "hipcc"
+
+
+def _newer(src_paths, target):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in src_paths)
+
+
+def build(verbose=True, force=False):
+    os.makedirs(BUILD, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS]
+    hipcc = _hipcc()
+
+    def compile_one(src):
+        s = os.path.join(CSRC, src)
+        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        if force or _newer([s] + hdrs, o):
+            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            if verbose:
+                print("[celebbasis_amd.build]", " ".join(cmd), flush=True)
+            subprocess.check_call(cmd)
+        return o
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
+        objs = list(ex.map(compile_one, SOURCES))
+    if force or _newer(objs, LIB):
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
+        if verbose:
+            print("[celebbasis_amd.build]", " ".join(cmd), flush=True)
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)
+    print(LIB)

@@ -1,0 +1,609 @@
+// cb_abi.hip — extern "C" surface of libcelebbasis_hip.so (declared in include/celebbasis_hip.h).
+#include "../../include/celebbasis_hip.h"
+#include "cb_models.h"
+
+using namespace cb;
+
+static thread_local std::string g_err;
+
+#define CB_TRY try {
+#define CB_END                                                                     \
+    }                                                                              \
+    catch (const cb::Error& e) { g_err = e.what(); return e.code; }                \
+    catch (const std::exception& e) { g_err = e.what(); return CB_STATUS_INTERNAL; } \
+    catch (...) { g_err = "unknown error"; return CB_STATUS_INTERNAL; }            \
+    return CB_STATUS_OK;
+
+struct cb_ctx { Ctx c; };
+struct cb_wtab { WTab t; };
+struct cb_unet { Ctx* ctx; UNet U; std::unique_ptr<Graph> G; Ten* out = nullptr; Ten* context = nullptr; int B = 0, H = 0, W = 0, L = 0; };
+struct cb_vae { Ctx* ctx; VaeEnc V; };
+struct cb_clip { Ctx* ctx; Clip C; std::unique_ptr<Graph> G; Ten* out = nullptr; Ten* in = nullptr; };
+struct cb_frnet { Ctx* ctx; FrNet F; };
+struct cb_trainer { Ctx* ctx; Trainer T; };
+
+static void require(const void* p, const char* what) { CB_CHECK(p != nullptr, CB_ERR_ARG, "%s must not be NULL", what); }
+
+extern "C" {
+
+const char* cb_last_error(void) { return g_err.c_str(); }
+int cb_version(void) { return 100; }
+
+// ------------------------------------------------------------------ context
+int cb_ctx_create(int device, void* hip_stream, cb_ctx** out) {
+    CB_TRY
+    require(out, "out");
+    std::unique_ptr<cb_ctx> h(new cb_ctx());
+    Ctx& c = h->c;
+    c.device = device;
+    c.dry = device < 0;
+    c.arena.dry = c.dry; c.pool.dry = c.dry;
+    if (!c.dry) {
+        int n = 0;
+        CB_HIP(hipGetDeviceCount(&n));
+        CB_CHECK(device < n, CB_ERR_ARG, "device %d out of range (%d visible)", device, n);
+        CB_HIP(hipSetDevice(device));
+        hipDeviceProp_t prop;
+        CB_HIP(hipGetDeviceProperties(&prop, device));
+        CB_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, CB_ERR_HIP,
+                 "libcelebbasis_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
+        c.stream = static_cast<hipStream_t>(hip_stream);
+    }
+    *out = h.release();
+    CB_END
+}
+int cb_ctx_destroy(cb_ctx* ctx) {
+    CB_TRY
+    delete ctx;
+    CB_END
+}
+int cb_ctx_sync(cb_ctx* ctx) {
+    CB_TRY
+    require(ctx, "ctx");
+    if (!ctx->c.dry) CB_HIP(hipStreamSynchronize(ctx->c.stream));
+    CB_END
+}
+int cb_ctx_stats(cb_ctx* ctx, double* gemm_flops, int64_t* launches, int64_t* arena_peak_bytes, int64_t* pool_bytes) {
+    CB_TRY
+    require(ctx, "ctx");
+    if (gemm_flops) *gemm_flops = ctx->c.stats.gemm_flops;
+    if (launches) *launches = ctx->c.stats.launches;
+    if (arena_peak_bytes) *arena_peak_bytes = (int64_t)ctx->c.arena.peak;
+    if (pool_bytes) *pool_bytes = (int64_t)ctx->c.pool.total;
+    CB_END
+}
+int cb_ctx_reset_stats(cb_ctx* ctx) {
+    CB_TRY
+    require(ctx, "ctx");
+    ctx->c.stats = Stats();
+    ctx->c.arena.peak = 0;
+    CB_END
+}
+int cb_ctx_set_debug_taps(cb_ctx* ctx, int enable) {
+    CB_TRY
+    require(ctx, "ctx");
+    ctx->c.debug_taps = enable != 0;
+    if (!enable) ctx->c.taps.clear();
+    CB_END
+}
+int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems, int64_t* numel) {
+    CB_TRY
+    require(ctx, "ctx"); require(name, "name");
+    auto it = ctx->c.taps.find(name);
+    CB_CHECK(it != ctx->c.taps.end(), CB_ERR_MISSING, "no tap named '%s'", name);
+    if (numel) *numel = it->second.second;
+    if (host_dst && !ctx->c.dry) {
+        int64_t n = std::min<int64_t>(max_elems, it->second.second);
+        CB_HIP(hipStreamSynchronize(ctx->c.stream));
+        CB_HIP(hipMemcpy(host_dst, it->second.first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    CB_END
+}
+
+// ------------------------------------------------------------------ weight table
+int cb_wtab_create(cb_wtab** out) {
+    CB_TRY
+    require(out, "out");
+    *out = new cb_wtab();
+    CB_END
+}
+int cb_wtab_add(cb_wtab* wt, const char* name, const float* data, int on_device, int ndim, const int64_t* dims) {
+    CB_TRY
+    require(wt, "wt"); require(name, "name");
+    CB_CHECK(ndim >= 0 && ndim <= 8 && (ndim == 0 || dims), CB_ERR_ARG, "bad dims for '%s'", name);
+    WEntry e; e.data = data; e.on_device = on_device;
+    for (int i = 0; i < ndim; ++i) e.dims.push_back(dims[i]);
+    wt->t.m[name] = e;
+    CB_END
+}
+int cb_wtab_destroy(cb_wtab* wt) {
+    CB_TRY
+    delete wt;
+    CB_END
+}
+
+// ------------------------------------------------------------------ op level
+int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d) {
+    CB_TRY
+    require(ctx, "ctx"); require(d, "desc");
+    GemmArgs a;
+    a.A = d->A; a.B = d->B; a.C = d->C; a.M = d->M; a.N = d->N; a.K = d->K;
+    a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
+    a.a_kind = d->a_layout == CB_LD_COL ? LD_COL : LD_ROW;
+    a.b_kind = d->b_layout == CB_LD_COL ? LD_COL : LD_ROW;
+    a.batch = d->batch > 0 ? d->batch : 1; a.nh = 1;
+    a.sAb = d->strideA; a.sBb = d->strideB; a.sCb = d->strideC;
+    a.bias = d->bias; a.R = d->R; a.ldr = d->ldr; a.sRb = d->strideR;
+    a.alpha = d->alpha; a.beta = d->beta;
+    Ctx* c = &ctx->c;
+    plan_and_run(c, [&]() {
+        Launch L = c->launch();
+        size_t wsb = gemm_ws_bytes(a);
+        float* ws = wsb ? static_cast<float*>(c->arena.alloc(wsb)) : nullptr;
+        gemm(L, a, ws, wsb);
+    });
+    CB_END
+}
+int cb_pack_conv_weight(cb_ctx* ctx, const float* w, float* out, int O, int I, int ks, int dgrad) {
+    CB_TRY
+    require(ctx, "ctx");
+    Launch L = ctx->c.launch();
+    if (dgrad) k_pack_conv_dgrad(L, out, w, O, I, ks); else k_pack_conv(L, out, w, O, I, ks);
+    CB_END
+}
+int cb_conv2d_fwd(cb_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* rowbias,
+                  const float* residual, float* y, int N, int H, int W, int Cin, int Cout, int ks, int mode) {
+    CB_TRY
+    require(ctx, "ctx");
+    Ctx* c = &ctx->c;
+    Conv cv; cv.w = const_cast<float*>(w_packed); cv.b = const_cast<float*>(bias); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        Ten* xt = G.wrap(const_cast<float*>(x), N, H, W, Cin);
+        int Ho, Wo; ConvGeom g;
+        conv_out_dims(cv, (ConvMode)mode, H, W, &Ho, &Wo, &g);
+        Ten* rb = rowbias ? G.wrap(const_cast<float*>(rowbias), N, 1, 1, Cout) : nullptr;
+        Ten* rs = residual ? G.wrap(const_cast<float*>(residual), N, Ho, Wo, Cout) : nullptr;
+        Ten* o = G.conv(xt, cv, (ConvMode)mode, rb, rs);
+        k_axpby(G.L, y, o->p, o->numel(), 1.f, 0.f);
+    });
+    CB_END
+}
+int cb_conv2d_dgrad(cb_ctx* ctx, const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout, int ks,
+                    int mode, float beta) {
+    CB_TRY
+    require(ctx, "ctx");
+    Ctx* c = &ctx->c;
+    Conv cv; cv.wd = const_cast<float*>(wd); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        conv_dgrad(&G, dy, cv, (ConvMode)mode, N, H, W, dx, beta);
+    });
+    CB_END
+}
+int cb_groupnorm_silu_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats, int N,
+                          int HW, int C, float eps, int silu) {
+    CB_TRY
+    require(ctx, "ctx");
+    Ctx* c = &ctx->c;
+    plan_and_run(c, [&]() {
+        float* ws = c->arena.allocf(gn_ws_floats(N, HW, C, 32) + (size_t)N * 64);
+        k_groupnorm_fwd(c->launch(), y, x, gamma, beta, stats, ws, N, HW, C, 32, eps, silu);
+    });
+    CB_END
+}
+int cb_groupnorm_silu_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* beta,
+                          const float* stats, float* dx, int N, int HW, int C, int silu, float acc_beta) {
+    CB_TRY
+    require(ctx, "ctx");
+    Ctx* c = &ctx->c;
+    plan_and_run(c, [&]() {
+        float* ws = c->arena.allocf(gn_ws_floats(N, HW, C, 32) + (size_t)N * 64);
+        k_groupnorm_bwd(c->launch(), dx, x, dy, gamma, beta, stats, ws, N, HW, C, 32, silu, acc_beta);
+    });
+    CB_END
+}
+int cb_layernorm_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats, int64_t rows,
+                     int C, float eps) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_layernorm_fwd(ctx->c.launch(), y, x, gamma, beta, stats, rows, C, eps);
+    CB_END
+}
+int cb_layernorm_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* stats, float* dx,
+                     int64_t rows, int C, float acc_beta) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_layernorm_bwd(ctx->c.launch(), dx, x, dy, gamma, stats, rows, C, acc_beta);
+    CB_END
+}
+int cb_geglu_fwd(cb_ctx* ctx, const float* x, float* y, int64_t M, int D) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_geglu_fwd(ctx->c.launch(), y, x, M, D);
+    CB_END
+}
+int cb_geglu_bwd(cb_ctx* ctx, const float* x, const float* dy, float* dx, int64_t M, int D) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_geglu_bwd(ctx->c.launch(), dx, x, dy, M, D);
+    CB_END
+}
+int cb_attention(cb_ctx* ctx, const cb_attention_desc* d) {
+    CB_TRY
+    require(ctx, "ctx"); require(d, "desc");
+    Ctx* c = &ctx->c;
+    const bool bwd = d->dout != nullptr;
+    if (bwd) CB_CHECK(d->dqbuf && d->dkvbuf, CB_ERR_ARG, "attention: backward needs dqbuf and dkvbuf");
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        Ten* qt = G.wrap(const_cast<float*>(d->qbuf), d->B, d->Nq, 1, (int)d->ldq, bwd);
+        Ten* kt = (d->kvbuf == d->qbuf) ? qt : G.wrap(const_cast<float*>(d->kvbuf), d->B, d->Nk, 1, (int)d->ldkv, bwd);
+        Ten* o = G.attention(qt, d->q_off, kt, d->k_off, d->v_off, d->C, d->heads, d->scale, d->causal != 0);
+        k_axpby(G.L, d->out, o->p, o->numel(), 1.f, 0.f);
+        if (bwd) {
+            float beta; float* go = G.grad(o, &beta);
+            k_axpby(G.L, go, d->dout, o->numel(), 1.f, 0.f);
+            qt->g = d->dqbuf;
+            if (kt != qt) kt->g = d->dkvbuf;
+            G.backward();
+        }
+    });
+    CB_END
+}
+int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, float* out, int B, int dim) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_timestep_embedding(ctx->c.launch(), out, t, B, dim);
+    CB_END
+}
+int cb_q_sample(cb_ctx* ctx, const float* x0, const float* eps, const int64_t* t, const float* sa, const float* sb, float* xt, int B,
+                int C, int HW) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_qsample(ctx->c.launch(), xt, x0, eps, t, sa, sb, B, C, HW);
+    CB_END
+}
+int cb_mse_loss(cb_ctx* ctx, const float* pred, const float* target, float* loss, float* dpred, int B, int C, int HW) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_mse_loss(ctx->c.launch(), loss, dpred, pred, target, B, C, HW);
+    CB_END
+}
+int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size) {
+    CB_TRY
+    require(ctx, "ctx");
+    static const float th[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f, 0.03625215f, 1.07695457f, -5.32134629f / 512.f};
+    Launch L = ctx->c.launch();
+    k_affine_warp(L, warped, faces, B, S, nface, th);
+    k_resize_bilinear_ac(L, out, warped, nface * B, S, S, out_size, out_size, 3);
+    CB_END
+}
+int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map, int B,
+                   int T, int C, int reps, int64_t placeholder) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_row_surgery_fwd(ctx->c.launch(), out, embedded, z, tokens, map, B, T, C, reps, placeholder);
+    CB_END
+}
+int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int64_t n, int* step_dev, float lr, float b1,
+                  float b2, float eps, float wd) {
+    CB_TRY
+    require(ctx, "ctx");
+    Launch L = ctx->c.launch();
+    k_step_inc(L, step_dev);
+    k_adamw(L, p, m, v, g, n, step_dev, lr, b1, b2, eps, wd);
+    CB_END
+}
+int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_nchw_to_nhwc(ctx->c.launch(), dst, src, N, C, H, W);
+    CB_END
+}
+int cb_nhwc_to_nchw(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W) {
+    CB_TRY
+    require(ctx, "ctx");
+    k_nhwc_to_nchw(ctx->c.launch(), dst, src, N, C, H, W);
+    CB_END
+}
+
+// ------------------------------------------------------------------ graph level: UNet
+static UNetCfg to_cfg(const cb_unet_cfg* c) {
+    UNetCfg u;
+    u.in_channels = c->in_channels; u.out_channels = c->out_channels; u.model_channels = c->model_channels;
+    u.num_res_blocks = c->num_res_blocks; u.n_mult = c->n_mult; u.n_attn = c->n_attn;
+    CB_CHECK(c->n_mult >= 1 && c->n_mult <= 8 && c->n_attn >= 0 && c->n_attn <= 8, CB_ERR_ARG, "unet cfg: bad list sizes");
+    for (int i = 0; i < 8; ++i) { u.channel_mult[i] = c->channel_mult[i]; u.attention_resolutions[i] = c->attention_resolutions[i]; }
+    u.num_heads = c->num_heads; u.context_dim = c->context_dim;
+    CB_CHECK(u.model_channels % 32 == 0 && u.num_heads > 0, CB_ERR_ARG, "unet cfg: model_channels must be a multiple of 32");
+    return u;
+}
+static VaeCfg to_cfg(const cb_vae_cfg* c) {
+    VaeCfg v;
+    v.ch = c->ch; v.n_mult = c->n_mult; v.num_res_blocks = c->num_res_blocks; v.in_channels = c->in_channels; v.z_channels = c->z_channels;
+    CB_CHECK(c->n_mult >= 1 && c->n_mult <= 8, CB_ERR_ARG, "vae cfg: bad n_mult");
+    for (int i = 0; i < 8; ++i) v.ch_mult[i] = c->ch_mult[i];
+    return v;
+}
+static ClipCfg to_cfg(const cb_clip_cfg* c) {
+    ClipCfg k; k.vocab = c->vocab; k.width = c->width; k.layers = c->layers; k.heads = c->heads; k.ctx_len = c->ctx_len; k.mlp = c->mlp;
+    return k;
+}
+
+int cb_unet_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_unet_cfg* cfg, cb_unet** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    std::unique_ptr<cb_unet> u(new cb_unet());
+    u->ctx = &ctx->c;
+    unet_load(&ctx->c, wt->t, prefix ? prefix : "", to_cfg(cfg), &u->U);
+    *out = u.release();
+    CB_END
+}
+int cb_unet_destroy(cb_unet* u) {
+    CB_TRY
+    delete u;
+    CB_END
+}
+int cb_unet_forward(cb_unet* u, const float* x_nchw, const int64_t* t, const float* context, int B, int H, int W, int L,
+                    float* eps_nchw, int need_grad) {
+    CB_TRY
+    require(u, "unet");
+    Ctx* c = u->ctx;
+    u->B = B; u->H = H; u->W = W; u->L = L;
+    plan_and_run(c, [&]() {
+        u->G.reset(new Graph(c));
+        Graph& G = *u->G;
+        Ten* x = G.make(B, H, W, u->U.cfg.in_channels);
+        k_nchw_to_nhwc(G.L, x->p, x_nchw, B, u->U.cfg.in_channels, H, W);
+        Ten* cx = G.wrap(const_cast<float*>(context), B, L, 1, u->U.cfg.context_dim, need_grad != 0);
+        Ten* o = unet_forward(G, u->U, x, t, cx);
+        k_nhwc_to_nchw(G.L, eps_nchw, o->p, B, u->U.cfg.out_channels, H, W);
+        u->out = o; u->context = cx;
+        if (c->dry && need_grad) { float beta; G.grad(o, &beta); G.backward(); }   // size the arena for the backward as well
+    });
+    CB_END
+}
+int cb_unet_backward_context(cb_unet* u, const float* deps_nchw, float* dcontext) {
+    CB_TRY
+    require(u, "unet");
+    CB_CHECK(u->G && u->out && u->context && u->context->rg, CB_ERR_STATE, "unet backward: call cb_unet_forward(need_grad=1) first");
+    Graph& G = *u->G;
+    float beta; float* go = G.grad(u->out, &beta);
+    k_nchw_to_nhwc(G.L, go, deps_nchw, u->B, u->U.cfg.out_channels, u->H, u->W);
+    G.backward();
+    if (!u->ctx->dry) CB_CHECK(u->context->ginit, CB_ERR_STATE, "unet backward: no gradient reached the context");
+    if (u->context->g) k_axpby(G.L, dcontext, u->context->g, u->context->numel(), 1.f, 0.f);
+    CB_END
+}
+
+// ------------------------------------------------------------------ VAE
+int cb_vae_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_vae_cfg* cfg, cb_vae** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    std::unique_ptr<cb_vae> v(new cb_vae());
+    v->ctx = &ctx->c;
+    vae_load(&ctx->c, wt->t, prefix ? prefix : "", to_cfg(cfg), &v->V);
+    *out = v.release();
+    CB_END
+}
+int cb_vae_destroy(cb_vae* v) {
+    CB_TRY
+    delete v;
+    CB_END
+}
+int cb_vae_encode(cb_vae* v, const float* image, const float* post_noise, int B, int H, int W, float scale, float* moments,
+                  float* z_nchw) {
+    CB_TRY
+    require(v, "vae");
+    Ctx* c = v->ctx;
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        Ten* img = G.wrap(const_cast<float*>(image), B, H, W, v->V.cfg.in_channels);
+        Ten* mom = vae_encode_moments(G, v->V, img);
+        const int zc = v->V.cfg.z_channels;
+        if (moments) k_axpby(G.L, moments, mom->p, mom->numel(), 1.f, 0.f);
+        if (z_nchw) {
+            Ten* z = G.make(B, mom->h, mom->w, zc);
+            k_vae_sample(G.L, z->p, mom->p, post_noise, B, mom->h * mom->w, zc, scale);
+            k_nhwc_to_nchw(G.L, z_nchw, z->p, B, zc, mom->h, mom->w);
+        }
+    });
+    CB_END
+}
+
+// ------------------------------------------------------------------ CLIP
+int cb_clip_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_clip_cfg* cfg, cb_clip** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    std::unique_ptr<cb_clip> k(new cb_clip());
+    k->ctx = &ctx->c;
+    clip_load(&ctx->c, wt->t, prefix ? prefix : "", to_cfg(cfg), &k->C);
+    *out = k.release();
+    CB_END
+}
+int cb_clip_destroy(cb_clip* c) {
+    CB_TRY
+    delete c;
+    CB_END
+}
+int cb_clip_embed_tokens(cb_clip* c, const int64_t* tokens, int B, int L, float* embedded) {
+    CB_TRY
+    require(c, "clip");
+    k_gather_rows(c->ctx->launch(), embedded, c->C.tok_emb, tokens, (long)B * L, c->C.cfg.width, c->C.cfg.vocab);
+    CB_END
+}
+int cb_clip_forward(cb_clip* k, const float* embedded, int B, int L, float* hidden, int need_grad) {
+    CB_TRY
+    require(k, "clip");
+    Ctx* c = k->ctx;
+    plan_and_run(c, [&]() {
+        k->G.reset(new Graph(c));
+        Graph& G = *k->G;
+        Ten* e = G.wrap(const_cast<float*>(embedded), B, L, 1, k->C.cfg.width, need_grad != 0);
+        Ten* o = clip_encode(G, k->C, e);
+        k_axpby(G.L, hidden, o->p, o->numel(), 1.f, 0.f);
+        k->out = o; k->in = e;
+        if (c->dry && need_grad) { float beta; G.grad(o, &beta); G.backward(); }
+    });
+    CB_END
+}
+int cb_clip_backward_embeds(cb_clip* k, const float* dhidden, float* dembedded) {
+    CB_TRY
+    require(k, "clip");
+    CB_CHECK(k->G && k->out && k->in && k->in->rg, CB_ERR_STATE, "clip backward: call cb_clip_forward(need_grad=1) first");
+    Graph& G = *k->G;
+    float beta; float* go = G.grad(k->out, &beta);
+    k_axpby(G.L, go, dhidden, k->out->numel(), 1.f, 0.f);
+    G.backward();
+    if (k->in->g) k_axpby(G.L, dembedded, k->in->g, k->in->numel(), 1.f, 0.f);
+    CB_END
+}
+
+// ------------------------------------------------------------------ FR-net
+int cb_frnet_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const int* layers4, int width, int in_size, cb_frnet** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(layers4, "layers"); require(out, "out");
+    CB_CHECK(in_size % 16 == 0 && width > 0, CB_ERR_ARG, "frnet: in_size must be a multiple of 16");
+    std::unique_ptr<cb_frnet> f(new cb_frnet());
+    f->ctx = &ctx->c;
+    frnet_load(&ctx->c, wt->t, prefix ? prefix : "", &f->F, layers4, width, in_size);
+    *out = f.release();
+    CB_END
+}
+int cb_frnet_destroy(cb_frnet* f) {
+    CB_TRY
+    delete f;
+    CB_END
+}
+int cb_frnet_forward(cb_frnet* f, const float* img, int N, float* features) {
+    CB_TRY
+    require(f, "frnet");
+    Ctx* c = f->ctx;
+    CB_CHECK(N >= 1 && N <= 8, CB_ERR_ARG, "frnet: N=%d must be in 1..8", N);
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        Ten* x = G.wrap(const_cast<float*>(img), N, f->F.in_size, f->F.in_size, 3);
+        Ten* o = frnet_forward(G, f->F, x);
+        k_axpby(G.L, features, o->p, o->numel(), 1.f, 0.f);
+    });
+    CB_END
+}
+
+// ------------------------------------------------------------------ trainer
+int cb_trainer_cfg_default(cb_trainer_cfg* cfg) {
+    CB_TRY
+    require(cfg, "cfg");
+    memset(cfg, 0, sizeof(*cfg));
+    cb_unet_cfg& u = cfg->unet;     // aigc_id.yaml:39-54
+    u.in_channels = 4; u.out_channels = 4; u.model_channels = 320; u.num_res_blocks = 2;
+    u.channel_mult[0] = 1; u.channel_mult[1] = 2; u.channel_mult[2] = 4; u.channel_mult[3] = 4; u.n_mult = 4;
+    u.attention_resolutions[0] = 4; u.attention_resolutions[1] = 2; u.attention_resolutions[2] = 1; u.n_attn = 3;
+    u.num_heads = 8; u.context_dim = 768;
+    cb_vae_cfg& v = cfg->vae;       // aigc_id.yaml:56-77
+    v.ch = 128; v.ch_mult[0] = 1; v.ch_mult[1] = 2; v.ch_mult[2] = 4; v.ch_mult[3] = 4; v.n_mult = 4; v.num_res_blocks = 2;
+    v.in_channels = 3; v.z_channels = 4;
+    cb_clip_cfg& k = cfg->clip;     // openai/clip-vit-large-patch14 text tower
+    k.vocab = 49408; k.width = 768; k.layers = 12; k.heads = 12; k.ctx_len = 77; k.mlp = 3072;
+    cfg->fr_layers[0] = 3; cfg->fr_layers[1] = 13; cfg->fr_layers[2] = 30; cfg->fr_layers[3] = 3; cfg->fr_width = 64; cfg->fr_in = 112;
+    cfg->image_size = 512; cfg->es = 2; cfg->inner_dim = 512; cfg->max_ids = 10;
+    cfg->momentum = 0.99f; cfg->scale_factor = 0.18215f; cfg->linear_start = 0.00085f; cfg->linear_end = 0.012f; cfg->timesteps = 1000;
+    cfg->placeholder_token = 48136;
+    cfg->adam_b1 = 0.9f; cfg->adam_b2 = 0.999f; cfg->adam_eps = 1e-8f; cfg->weight_decay = 1e-2f;
+    CB_END
+}
+int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg, cb_trainer** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    TrainerCfg tc;
+    tc.unet = to_cfg(&cfg->unet); tc.vae = to_cfg(&cfg->vae); tc.clip = to_cfg(&cfg->clip);
+    for (int i = 0; i < 4; ++i) tc.fr_layers[i] = cfg->fr_layers[i];
+    tc.fr_width = cfg->fr_width; tc.fr_in = cfg->fr_in;
+    tc.image_size = cfg->image_size; tc.es = cfg->es; tc.inner_dim = cfg->inner_dim; tc.max_ids = cfg->max_ids;
+    tc.momentum = cfg->momentum; tc.scale_factor = cfg->scale_factor; tc.linear_start = cfg->linear_start;
+    tc.linear_end = cfg->linear_end; tc.timesteps = cfg->timesteps; tc.placeholder_token = cfg->placeholder_token;
+    tc.adam_b1 = cfg->adam_b1; tc.adam_b2 = cfg->adam_b2; tc.adam_eps = cfg->adam_eps; tc.weight_decay = cfg->weight_decay;
+    CB_CHECK(tc.image_size % 8 == 0 && tc.es >= 1 && tc.inner_dim >= 1 && tc.max_ids >= 1 && tc.timesteps >= 1, CB_ERR_ARG,
+             "trainer cfg: bad sizes");
+    std::unique_ptr<cb_trainer> t(new cb_trainer());
+    t->ctx = &ctx->c;
+    trainer_load(&ctx->c, wt->t, tc, &t->T);
+    *out = t.release();
+    CB_END
+}
+int cb_trainer_destroy(cb_trainer* t) {
+    CB_TRY
+    delete t;
+    CB_END
+}
+int cb_trainer_step(cb_trainer* t, const cb_batch* b, float lr) {
+    CB_TRY
+    require(t, "trainer"); require(b, "batch");
+    if (!t->ctx->dry) {
+        require(b->image, "batch.image"); require(b->faces, "batch.faces"); require(b->ids, "batch.ids");
+        require(b->tokens, "batch.tokens"); require(b->t, "batch.t"); require(b->noise, "batch.noise");
+        require(b->post_noise, "batch.post_noise");
+    }
+    Batch bt;
+    bt.image = b->image; bt.faces = b->faces; bt.ids = b->ids; bt.tokens = b->tokens; bt.t = b->t; bt.noise = b->noise;
+    bt.post_noise = b->post_noise; bt.B = b->B;
+    trainer_step(&t->T, bt, lr, false);
+    CB_END
+}
+
+struct StateRef { void* p; long n; bool is_int; };
+static StateRef find_state(cb_trainer* t, const char* name) {
+    Trainer& T = t->T;
+    const TrainerCfg& c = T.cfg;
+    const long O = (long)c.es * c.inner_dim, I = T.fr.feat, w = c.clip.width;
+    std::string s(name);
+    if (s == "loss") return {T.loss, 1, false};
+    if (s == "mlp.weight") return {T.W, O * I, false};
+    if (s == "mlp.bias") return {T.b, O, false};
+    if (s == "mlp.grad_weight") return {T.gW, O * I, false};
+    if (s == "mlp.grad_bias") return {T.gb, O, false};
+    if (s == "adam.m_weight") return {T.mW, O * I, false};
+    if (s == "adam.v_weight") return {T.vW, O * I, false};
+    if (s == "adam.m_bias") return {T.mb, O, false};
+    if (s == "adam.v_bias") return {T.vb, O, false};
+    if (s == "id_embeddings") return {T.id_emb, (long)c.max_ids * c.es * w, false};
+    if (s == "id_coefficients") return {T.id_coef, (long)c.max_ids * O, false};
+    if (s == "step") return {T.step, 1, true};
+    fail(CB_ERR_MISSING, "unknown trainer state '%s'", name);
+}
+int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64_t max_elems, int64_t* numel) {
+    CB_TRY
+    require(t, "trainer"); require(name, "name");
+    StateRef r = find_state(t, name);
+    if (numel) *numel = r.n;
+    if (host_dst && !t->ctx->dry) {
+        CB_CHECK(max_elems >= r.n, CB_ERR_ARG, "get_state '%s': buffer too small (%ld < %ld)", name, (long)max_elems, r.n);
+        CB_HIP(hipStreamSynchronize(t->ctx->stream));
+        if (r.is_int) {
+            int v = 0;
+            CB_HIP(hipMemcpy(&v, r.p, sizeof(int), hipMemcpyDeviceToHost));
+            host_dst[0] = (float)v;
+        } else {
+            CB_HIP(hipMemcpy(host_dst, r.p, (size_t)r.n * sizeof(float), hipMemcpyDeviceToHost));
+        }
+    }
+    CB_END
+}
+int cb_trainer_set_state(cb_trainer* t, const char* name, const float* host_src, int64_t numel) {
+    CB_TRY
+    require(t, "trainer"); require(name, "name"); require(host_src, "host_src");
+    StateRef r = find_state(t, name);
+    CB_CHECK(numel == r.n, CB_ERR_SHAPE, "set_state '%s': %ld elements given, %ld expected", name, (long)numel, r.n);
+    if (!t->ctx->dry) {
+        CB_HIP(hipStreamSynchronize(t->ctx->stream));
+        if (r.is_int) {
+            int v = (int)host_src[0];
+            CB_HIP(hipMemcpy(r.p, &v, sizeof(int), hipMemcpyHostToDevice));
+        } else {
+            CB_HIP(hipMemcpy(r.p, host_src, (size_t)r.n * sizeof(float), hipMemcpyHostToDevice));
+        }
+    }
+    CB_END
+}
+
+}  // extern "C"

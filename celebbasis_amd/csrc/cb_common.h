@@ -1,0 +1,154 @@
+// cb_common.h — shared declarations for the CelebBasis MI355X engine (gfx950 only).
+// Internal header: the public C ABI lives in include/celebbasis_hip.h.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <stdexcept>
+#include <cstdarg>
+
+namespace cb {
+
+// ---------------------------------------------------------------- errors
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+enum { CB_OK = 0, CB_ERR_ARG = -1, CB_ERR_HIP = -2, CB_ERR_SHAPE = -3, CB_ERR_MISSING = -4, CB_ERR_OOM = -5,
+       CB_ERR_STATE = -6 };
+
+[[noreturn]] inline void fail(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+inline void fail(int code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof buf, fmt, ap); va_end(ap);
+    throw Error(code, buf);
+}
+#define CB_CHECK(cond, code, ...) do { if (!(cond)) ::cb::fail(code, __VA_ARGS__); } while (0)
+#define CB_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
+    ::cb::fail(::cb::CB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+// ---------------------------------------------------------------- launch context
+// Every kernel launcher takes a Launch. In dry mode (no device) launchers only do shape checks and
+// accounting: this is how the host-side graph logic is tested on a box without a GPU.
+struct Stats {
+    double gemm_flops = 0;      // 2*M*N*K summed over GEMM-class launches
+    long   launches = 0;
+    long   gemm_launches = 0;
+};
+struct Launch {
+    hipStream_t stream = nullptr;
+    bool dry = false;
+    Stats* stats = nullptr;
+    void count(long n = 1) const { if (stats) stats->launches += n; }
+};
+
+inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
+inline long rup(long a, long b) { return (a + b - 1) / b * b; }
+
+// ---------------------------------------------------------------- conv geometry
+// Implicit-GEMM gather description (NHWC input). Virtual input = source upsampled 2x when `up`.
+struct ConvGeom {
+    int H = 0, W = 0, C = 0;    // source dims (NHWC), C = channels of the gathered tensor
+    int Ho = 0, Wo = 0;         // output spatial dims
+    int ks = 3;                 // kernel size 1 or 3
+    int stride = 1;             // step of the virtual coordinate per output pixel
+    int pad = 1;                // top/left padding in virtual coordinates
+    int up = 0;                 // 1: nearest-2x upsample fused: source pixel = virtual >> 1
+    int tr = 0;                 // 1: transposed stride-2 (dgrad of a stride-2 conv): virtual must be even, source = virtual >> 1
+};
+
+// ---------------------------------------------------------------- GEMM arguments
+enum { LD_ROW = 0, LD_COL = 1, LD_CONV = 2 };
+struct GemmArgs {
+    const float* A = nullptr; const float* B = nullptr; float* C = nullptr;
+    int M = 0, N = 0, K = 0;
+    long lda = 0, ldb = 0, ldc = 0;
+    int a_kind = LD_ROW, b_kind = LD_ROW;
+    // batch: z = b*nh + h ; offset = b*s?b + h*s?h
+    int batch = 1, nh = 1;
+    long sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0;
+    // epilogue: C = alpha*acc + bias[n] + rowbias[m / rows_per_img][n] + R[m][n] + beta*C
+    const float* bias = nullptr;
+    const float* rowbias = nullptr; int rows_per_img = 1;
+    const float* R = nullptr; long ldr = 0; long sRb = 0, sRh = 0;
+    float alpha = 1.f, beta = 0.f;
+    ConvGeom g;
+};
+
+void gemm(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
+size_t gemm_ws_bytes(const GemmArgs& a);
+
+// ---------------------------------------------------------------- other kernels (cb_kernels.hip)
+void k_fill(const Launch& L, float* p, long n, float v);
+void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b);          // dst = a*src + b*dst
+void k_add(const Launch& L, float* dst, const float* x, const float* y, long n);
+void k_copy2d(const Launch& L, float* dst, long ldd, const float* src, long lds, long rows, int cols, float beta);
+void k_silu(const Launch& L, float* dst, const float* src, long n);
+void k_geglu_fwd(const Launch& L, float* y, const float* x, long M, int D);
+void k_geglu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long M, int D);
+void k_quickgelu_fwd(const Launch& L, float* y, const float* x, long n);
+void k_quickgelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float beta);
+void k_leakyrelu_fwd(const Launch& L, float* y, const float* x, long n, float slope);
+void k_leakyrelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float slope);
+void k_nchw_to_nhwc(const Launch& L, float* dst, const float* src, int N, int C, int H, int W);
+void k_nhwc_to_nchw(const Launch& L, float* dst, const float* src, int N, int C, int H, int W);
+void k_channel_affine(const Launch& L, float* y, const float* x, const float* scale, const float* shift,
+                      const float* prelu, long rows, int C);
+void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H, int W, int C, float beta);
+
+// GroupNorm (NHWC, G groups). stats = [N][G][2] (mean, rstd). partial ws sized gn_ws_floats().
+size_t gn_ws_floats(int N, int HW, int C, int G);
+void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
+                     float* stats, float* ws, int N, int HW, int C, int G, float eps, int silu);
+void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
+                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta);
+// LayerNorm over last dim C; stats = [rows][2]
+void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
+                     float* stats, long rows, int C, float eps);
+void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma,
+                     const float* stats, long rows, int C, float acc_beta);
+// softmax over rows of length n (leading dim ld), in place. causal: row i (mod rows_per_mat) sees cols <= i.
+void k_softmax_fwd(const Launch& L, float* S, long rows, int n, int ld, int causal, int rows_per_mat);
+// dS = scale * P * (dP - sum(dP*P)), in place in dP
+void k_softmax_bwd(const Launch& L, float* dP, const float* P, long rows, int n, int ld, float scale);
+
+// diffusion-specific
+void k_timestep_embedding(const Launch& L, float* out, const int64_t* t, int B, int dim);
+void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nchw, const int64_t* t,
+               const float* sqrt_ac, const float* sqrt_1mac, int B, int C, int HW);
+void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw,
+                int B, int C, int HW);
+void k_vae_sample(const Launch& L, float* z, const float* moments, const float* noise_nchw, int B, int HW, int Cz, float scale);
+void k_gather_rows(const Launch& L, float* out, const float* table, const int64_t* idx, long rows, int C, long table_rows);
+void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* pos, long rows, int period, int C);
+// face pre-processing (meta_net.py:250-260)
+void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* theta);
+void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C);
+// manager
+void k_l2norm_fwd(const Launch& L, float* y, float* norms, const float* x, long rows, int D);
+void k_l2norm_bwd(const Launch& L, float* dx, const float* y, const float* norms, const float* dy, long rows, int D);
+void k_basis_fwd(const Launch& L, float* z, const float* coef, const float* basis, int R, int E, int Kc, int Cz);
+void k_basis_bwd(const Launch& L, float* dcoef, const float* dz, const float* basis, int R, int E, int Kc, int Cz);
+void k_row_surgery_fwd(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens,
+                       int32_t* map, int B, int T, int C, int reps, int64_t placeholder);
+void k_row_surgery_bwd(const Launch& L, float* dz, const float* dout, const int32_t* map, int B, int T, int C, int reps);
+void k_ema_update(const Launch& L, float* id_emb, float* id_coef, const float* z, const float* coef,
+                  const int64_t* ids, int ids_stride, int B, int embN, int coefN, int max_ids, float m);
+void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, const float* v, int R, int O, int I);
+void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step,
+             float lr, float b1, float b2, float eps, float wd);
+void k_step_inc(const Launch& L, int* step);
+void k_gemv(const Launch& L, float* y, const float* x, const float* W, const float* bias, int M, int N, int K);
+// weight packing
+void k_pack_conv(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);          // -> [O][ky][kx][I]
+void k_pack_conv_dgrad(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);    // -> [I][ky'][kx'][O], flipped
+void k_pack_fc_nhwc(const Launch& L, float* out, const float* w, int O, int C, int HW);            // [O][C*HW] -> [O][HW*C]
+void k_fold_bn(const Launch& L, float* w_packed, float* bias_out, const float* bn_w, const float* bn_b,
+               const float* bn_m, const float* bn_v, float eps, int O, long per_o);
+void k_bn_to_affine(const Launch& L, float* scale, float* shift, const float* w, const float* b, const float* m,
+                    const float* v, float eps, int C);
+
+}  // namespace cb

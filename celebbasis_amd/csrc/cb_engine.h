@@ -1,0 +1,134 @@
+// cb_engine.h — native runtime of the CelebBasis MI355X training step: device memory pools, a weight table
+// keyed by the reference's state-dict names, and a tiny input-gradient-only autograd tape (every pretrained
+// weight is frozen, ddpm.py:491-500, so backward needs dgrad only; pruning of branches that do not depend
+// on the conditioning falls out of requires-grad propagation exactly as in torch autograd).
+#pragma once
+#include "cb_common.h"
+#include <deque>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace cb {
+
+// ---------------------------------------------------------------- memory
+// Bump allocator. The step arena is reset at the start of every step and never reuses memory inside a
+// step (288 GB of HBM3E: ~10 GB of live activations is nothing), which makes every intermediate a valid
+// debug tap until the next step and makes addresses replay-stable for hipGraph capture.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, off = 0, peak = 0;
+    bool dry = false;
+    void* alloc(size_t bytes) {
+        off = (size_t)rup((long)off, 256);
+        if (!dry) CB_CHECK(off + bytes <= cap, CB_ERR_OOM, "step arena exhausted: need %zu, cap %zu", off + bytes, cap);
+        void* p = (dry ? reinterpret_cast<char*>(0x100000) : base) + off;
+        off += bytes;
+        if (off > peak) peak = off;
+        return p;
+    }
+    float* allocf(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
+    void reset() { off = 0; }
+};
+
+// Persistent pool (weights, packed weights, optimiser state): grows in hipMalloc'ed slabs.
+struct Pool {
+    bool dry = false;
+    std::vector<void*> slabs;
+    char* cur = nullptr; size_t left = 0; size_t total = 0;
+    size_t slab_bytes = (size_t)1 << 30;
+    void* alloc(size_t bytes);
+    float* allocf(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
+    void release();
+};
+
+// ---------------------------------------------------------------- weight table (mirrors a torch state_dict)
+struct WEntry { const void* data = nullptr; int on_device = 0; std::vector<int64_t> dims; int dtype = 0; /*0 f32, 1 i64*/ };
+struct WTab {
+    std::map<std::string, WEntry> m;
+    const WEntry& get(const std::string& name) const {
+        auto it = m.find(name);
+        CB_CHECK(it != m.end(), CB_ERR_MISSING, "weight '%s' missing from the table", name.c_str());
+        return it->second;
+    }
+    bool has(const std::string& name) const { return m.count(name) != 0; }
+};
+
+struct Ctx {
+    int device = -1;             // -1: dry (no GPU): shape checks and accounting only
+    hipStream_t stream = nullptr;
+    bool dry = true;
+    Arena arena;                 // per-step activations
+    Pool pool;                   // persistent
+    Stats stats;
+    bool debug_taps = false;
+    std::map<std::string, std::pair<const float*, long>> taps;
+    Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; return L; }
+    void ensure_arena(size_t bytes);
+    // upload a table entry to the device (raw copy); dims are checked against `expect` (-1 = any)
+    float* upload(const WTab& wt, const std::string& name, std::initializer_list<int64_t> expect);
+    ~Ctx();
+};
+
+// ---------------------------------------------------------------- tensors and tape
+struct Ten {
+    float* p = nullptr;
+    float* g = nullptr;
+    int n = 1, h = 1, w = 1, c = 1;   // NHWC; sequences are (n=B, h=L, w=1, c)
+    bool rg = false;                  // requires grad
+    bool ginit = false;               // g holds a value (first writer uses beta=0)
+    long rows() const { return (long)n * h * w; }
+    long numel() const { return rows() * c; }
+};
+
+struct Conv { float* w = nullptr; float* wd = nullptr; float* b = nullptr; int cin = 0, cout = 0, ks = 3; };
+struct Lin { float* w = nullptr; float* b = nullptr; int in = 0, out = 0; };
+struct Norm { float* g = nullptr; float* b = nullptr; int c = 0; float eps = 1e-5f; };
+
+enum ConvMode { CONV_SAME = 0, CONV_DOWN = 1, CONV_DOWN_ASYM = 2, CONV_UP = 3, CONV_S2_1x1 = 4 };
+
+struct Graph {
+    Ctx* ctx;
+    Launch L;
+    std::deque<Ten> tens;
+    std::vector<std::function<void()>> tape;
+    explicit Graph(Ctx* c) : ctx(c), L(c->launch()) {}
+
+    Ten* make(int n, int h, int w, int c, bool rg = false);
+    Ten* wrap(float* p, int n, int h, int w, int c, bool rg = false);   // external buffer
+    float* grad(Ten* t, float* beta);      // grad buffer for a writer; *beta = 0 on first write, 1 afterwards
+    void tap(const std::string& name, const Ten* t);
+    void backward();
+
+    // ops (forward now, backward pushed on the tape when an input requires grad)
+    Ten* conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias = nullptr, Ten* residual = nullptr);
+    Ten* linear(Ten* x, const Lin& l, Ten* residual = nullptr);
+    Ten* groupnorm(Ten* x, const Norm& nm, bool silu);
+    Ten* layernorm(Ten* x, const Norm& nm);
+    // q: columns [qoff, qoff+C) of qt ; k/v: columns of kt at koff/voff. Output [B, Nq, C].
+    Ten* attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal);
+    Ten* geglu(Ten* x);
+    Ten* quickgelu(Ten* x);
+    Ten* silu(Ten* x);                      // no grad path only
+    Ten* concat(Ten* a, Ten* b);            // channel concat
+    Ten* channel_affine(Ten* x, const float* scale, const float* shift, const float* prelu);   // no grad
+};
+
+// conv geometry / dgrad shared by the tape ops and the op-level C ABI
+void conv_out_dims(const Conv& cv, ConvMode mode, int H, int W, int* Ho, int* Wo, ConvGeom* g);
+void conv_dgrad(Graph* G, const float* dy, const Conv& cv, ConvMode mode, int N, int H, int W, float* dx, float beta);
+
+// run fn once in dry mode to size the step arena, then for real (no-op split on a dry context)
+void plan_and_run(Ctx* ctx, const std::function<void()>& fn);
+
+// weight loading helpers (cb_engine.hip)
+Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias = true);
+Lin load_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out, bool bias = true);
+Lin load_conv1x1_as_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out);
+Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, int out_each, bool bias,
+                    bool conv1x1 = false);
+Norm load_norm(Ctx* ctx, const WTab& wt, const std::string& prefix, int c, float eps);
+
+}  // namespace cb

@@ -1,0 +1,457 @@
+// cb_engine.hip — memory pools, weight loading/packing and the autograd-tape ops of the native runtime.
+#include "cb_engine.h"
+
+namespace cb {
+
+// ---------------------------------------------------------------- pools
+void* Pool::alloc(size_t bytes) {
+    bytes = (size_t)rup((long)bytes, 256);
+    total += bytes;
+    if (dry) return reinterpret_cast<void*>(0x200000 + (total - bytes));
+    if (bytes > left) {
+        size_t sz = bytes > slab_bytes ? bytes : slab_bytes;
+        void* p = nullptr;
+        CB_HIP(hipMalloc(&p, sz));
+        slabs.push_back(p);
+        cur = static_cast<char*>(p);
+        left = sz;
+    }
+    void* r = cur;
+    cur += bytes;
+    left -= bytes;
+    return r;
+}
+void Pool::release() {
+    for (void* p : slabs) (void)hipFree(p);
+    slabs.clear(); cur = nullptr; left = 0; total = 0;
+}
+
+void Ctx::ensure_arena(size_t bytes) {
+    if (dry) { arena.dry = true; return; }
+    if (arena.cap >= bytes) return;
+    CB_HIP(hipStreamSynchronize(stream));
+    if (arena.base) CB_HIP(hipFree(arena.base));
+    arena.base = nullptr; arena.cap = 0;
+    size_t want = bytes + bytes / 16 + ((size_t)64 << 20);
+    void* p = nullptr;
+    CB_HIP(hipMalloc(&p, want));
+    arena.base = static_cast<char*>(p);
+    arena.cap = want;
+    arena.off = 0;
+}
+Ctx::~Ctx() {
+    if (!dry) {
+        (void)hipStreamSynchronize(stream);
+        if (arena.base) (void)hipFree(arena.base);
+        pool.release();
+    }
+}
+
+void plan_and_run(Ctx* ctx, const std::function<void()>& fn) {
+    if (!ctx->dry) {
+        Stats saved = ctx->stats;
+        ctx->dry = true; ctx->arena.dry = true; ctx->arena.reset(); ctx->arena.peak = 0;
+        try { fn(); } catch (...) { ctx->dry = false; ctx->arena.dry = false; ctx->stats = saved; throw; }
+        size_t need = ctx->arena.peak;
+        ctx->dry = false; ctx->arena.dry = false; ctx->stats = saved;
+        ctx->ensure_arena(need);
+    }
+    ctx->arena.reset();
+    fn();
+}
+
+static long numel_of(const std::vector<int64_t>& d) { long n = 1; for (auto v : d) n *= v; return n; }
+
+float* Ctx::upload(const WTab& wt, const std::string& name, std::initializer_list<int64_t> expect) {
+    const WEntry& e = wt.get(name);
+    CB_CHECK(e.dtype == 0, CB_ERR_ARG, "weight '%s' must be float32", name.c_str());
+    std::vector<int64_t> ex(expect);
+    if (!ex.empty()) {
+        bool ok = ex.size() == e.dims.size();
+        for (size_t i = 0; ok && i < ex.size(); ++i) ok = (ex[i] < 0) || (ex[i] == e.dims[i]);
+        if (!ok) {
+            std::string got, want;
+            for (auto v : e.dims) got += std::to_string(v) + ",";
+            for (auto v : ex) want += std::to_string(v) + ",";
+            fail(CB_ERR_SHAPE, "weight '%s' has shape [%s] but [%s] was expected", name.c_str(), got.c_str(), want.c_str());
+        }
+    }
+    long n = numel_of(e.dims);
+    float* d = pool.allocf((size_t)n);
+    if (!dry) {
+        CB_CHECK(e.data != nullptr, CB_ERR_ARG, "weight '%s' has no data", name.c_str());
+        CB_HIP(hipMemcpyAsync(d, e.data, (size_t)n * sizeof(float), e.on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice,
+                              stream));
+        if (!e.on_device) CB_HIP(hipStreamSynchronize(stream));  // the caller may free host memory afterwards
+    }
+    return d;
+}
+
+Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias) {
+    Conv c; c.cin = cin; c.cout = cout; c.ks = ks;
+    Launch L = ctx->launch();
+    float* raw = ctx->upload(wt, prefix + ".weight", {cout, cin, ks, ks});
+    size_t n = (size_t)cout * cin * ks * ks;
+    c.w = ctx->pool.allocf(n);
+    k_pack_conv(L, c.w, raw, cout, cin, ks);
+    if (need_dgrad) {
+        c.wd = ctx->pool.allocf(n);
+        k_pack_conv_dgrad(L, c.wd, raw, cout, cin, ks);
+    }
+    if (bias) c.b = ctx->upload(wt, prefix + ".bias", {cout});
+    return c;
+}
+Lin load_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out, bool bias) {
+    Lin l; l.in = in; l.out = out;
+    l.w = ctx->upload(wt, prefix + ".weight", {out, in});
+    if (bias) l.b = ctx->upload(wt, prefix + ".bias", {out});
+    return l;
+}
+Lin load_conv1x1_as_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out) {
+    Lin l; l.in = in; l.out = out;
+    l.w = ctx->upload(wt, prefix + ".weight", {out, in, 1, 1});
+    l.b = ctx->upload(wt, prefix + ".bias", {out});
+    return l;
+}
+// concatenate several [out_each, in] projections into one [n*out_each, in] weight (fused QKV / KV)
+Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, int out_each, bool bias,
+                    bool conv1x1) {
+    Lin l; l.in = in; l.out = out_each * (int)prefixes.size();
+    l.w = ctx->pool.allocf((size_t)l.out * in);
+    if (bias) l.b = ctx->pool.allocf((size_t)l.out);
+    Launch L = ctx->launch();
+    for (size_t i = 0; i < prefixes.size(); ++i) {
+        float* w = conv1x1 ? ctx->upload(wt, prefixes[i] + ".weight", {out_each, in, 1, 1})
+                           : ctx->upload(wt, prefixes[i] + ".weight", {out_each, in});
+        k_axpby(L, l.w + i * (size_t)out_each * in, w, (long)out_each * in, 1.f, 0.f);
+        if (bias) {
+            float* b = ctx->upload(wt, prefixes[i] + ".bias", {out_each});
+            k_axpby(L, l.b + i * (size_t)out_each, b, out_each, 1.f, 0.f);
+        }
+    }
+    return l;
+}
+Norm load_norm(Ctx* ctx, const WTab& wt, const std::string& prefix, int c, float eps) {
+    Norm n; n.c = c; n.eps = eps;
+    n.g = ctx->upload(wt, prefix + ".weight", {c});
+    n.b = ctx->upload(wt, prefix + ".bias", {c});
+    return n;
+}
+
+// ---------------------------------------------------------------- graph basics
+Ten* Graph::make(int n, int h, int w, int c, bool rg) {
+    tens.emplace_back();
+    Ten* t = &tens.back();
+    t->n = n; t->h = h; t->w = w; t->c = c; t->rg = rg;
+    t->p = ctx->arena.allocf((size_t)t->numel());
+    return t;
+}
+Ten* Graph::wrap(float* p, int n, int h, int w, int c, bool rg) {
+    tens.emplace_back();
+    Ten* t = &tens.back();
+    t->n = n; t->h = h; t->w = w; t->c = c; t->rg = rg; t->p = p;
+    return t;
+}
+float* Graph::grad(Ten* t, float* beta) {
+    if (!t->g) t->g = ctx->arena.allocf((size_t)t->numel());
+    *beta = t->ginit ? 1.f : 0.f;
+    t->ginit = true;
+    return t->g;
+}
+void Graph::tap(const std::string& name, const Ten* t) {
+    if (ctx->debug_taps) ctx->taps[name] = {t->p, t->numel()};
+}
+void Graph::backward() {
+    for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
+    tape.clear();
+}
+
+static void run_gemm(Graph* G, const GemmArgs& a) {
+    size_t wsb = gemm_ws_bytes(a);
+    float* ws = wsb ? static_cast<float*>(G->ctx->arena.alloc(wsb)) : nullptr;
+    gemm(G->L, a, ws, wsb);
+}
+
+static void accumulate(Graph* G, Ten* t, const float* src) {
+    float beta;
+    float* g = G->grad(t, &beta);
+    k_axpby(G->L, g, src, t->numel(), 1.f, beta);
+}
+
+// ---------------------------------------------------------------- conv
+void conv_out_dims(const Conv& cv, ConvMode mode, int H, int W, int* Ho, int* Wo, ConvGeom* g) {
+    g->H = H; g->W = W; g->C = cv.cin; g->ks = cv.ks; g->up = 0; g->tr = 0;
+    *Ho = H; *Wo = W;
+    switch (mode) {
+        case CONV_SAME: g->stride = 1; g->pad = cv.ks / 2; break;
+        case CONV_DOWN: CB_CHECK(cv.ks == 3, CB_ERR_ARG, "conv down: ks"); g->stride = 2; g->pad = 1;
+            *Ho = (H + 2 - 3) / 2 + 1; *Wo = (W + 2 - 3) / 2 + 1; break;
+        case CONV_DOWN_ASYM: CB_CHECK(cv.ks == 3, CB_ERR_ARG, "conv down: ks"); g->stride = 2; g->pad = 0;
+            *Ho = (H + 1 - 3) / 2 + 1; *Wo = (W + 1 - 3) / 2 + 1; break;
+        case CONV_UP: CB_CHECK(cv.ks == 3, CB_ERR_ARG, "conv up: ks"); g->stride = 1; g->pad = 1; g->up = 1; *Ho = 2 * H; *Wo = 2 * W; break;
+        case CONV_S2_1x1: CB_CHECK(cv.ks == 1, CB_ERR_ARG, "conv s2 1x1: ks"); g->stride = 2; g->pad = 0;
+            *Ho = (H - 1) / 2 + 1; *Wo = (W - 1) / 2 + 1; break;
+        default: fail(CB_ERR_ARG, "conv: unknown mode %d", (int)mode);
+    }
+    g->Ho = *Ho; g->Wo = *Wo;
+}
+// dx[N,H,W,cin] (beta-accumulated) from dy[N,Ho,Wo,cout] using the flipped/transposed pack cv.wd
+void conv_dgrad(Graph* G, const float* dy, const Conv& cv, ConvMode mode, int N, int H, int W, float* dx, float beta) {
+    CB_CHECK(cv.wd, CB_ERR_STATE, "conv: dgrad weights were not packed");
+    CB_CHECK(mode == CONV_SAME || mode == CONV_DOWN || mode == CONV_UP, CB_ERR_ARG, "conv: mode %d has no dgrad", (int)mode);
+    int Ho, Wo; ConvGeom fg;
+    conv_out_dims(cv, mode, H, W, &Ho, &Wo, &fg);
+    GemmArgs d;
+    d.A = dy; d.B = cv.wd;
+    d.N = cv.cin; d.K = cv.ks * cv.ks * cv.cout;
+    d.a_kind = LD_CONV; d.b_kind = LD_ROW; d.ldb = d.K; d.ldc = cv.cin;
+    ConvGeom dg; dg.H = Ho; dg.W = Wo; dg.C = cv.cout; dg.ks = cv.ks; dg.stride = 1; dg.pad = cv.ks - 1 - cv.ks / 2;
+    if (mode == CONV_SAME) {
+        dg.Ho = H; dg.Wo = W;
+        d.C = dx; d.beta = beta; d.M = N * H * W; d.g = dg;
+        run_gemm(G, d);
+    } else if (mode == CONV_DOWN) {      // transposed stride-2 gather
+        dg.Ho = H; dg.Wo = W; dg.tr = 1; dg.pad = 1;
+        d.C = dx; d.beta = beta; d.M = N * H * W; d.g = dg;
+        run_gemm(G, d);
+    } else {                              // CONV_UP: dgrad at the upsampled resolution, then 2x2 sum-pool
+        dg.Ho = Ho; dg.Wo = Wo;
+        float* tmp = G->ctx->arena.allocf((size_t)N * Ho * Wo * cv.cin);
+        d.C = tmp; d.beta = 0.f; d.M = N * Ho * Wo; d.g = dg;
+        run_gemm(G, d);
+        k_upsample2x_bwd(G->L, dx, tmp, N, H, W, cv.cin, beta);
+    }
+}
+
+Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* residual) {
+    CB_CHECK(x->c == cv.cin, CB_ERR_SHAPE, "conv: input has %d channels, weight expects %d", x->c, cv.cin);
+    const int H = x->h, W = x->w;
+    ConvGeom g; int Ho, Wo;
+    conv_out_dims(cv, mode, H, W, &Ho, &Wo, &g);
+    bool rg = x->rg || (residual && residual->rg);
+    Ten* y = make(x->n, Ho, Wo, cv.cout, rg);
+    if (residual) CB_CHECK(residual->numel() == y->numel() && residual->c == y->c, CB_ERR_SHAPE, "conv: residual shape");
+    if (rowbias) CB_CHECK(rowbias->rows() == x->n && rowbias->c == cv.cout, CB_ERR_SHAPE, "conv: rowbias shape");
+    GemmArgs a;
+    a.A = x->p; a.B = cv.w; a.C = y->p;
+    a.M = (int)y->rows(); a.N = cv.cout; a.K = cv.ks * cv.ks * cv.cin;
+    a.a_kind = LD_CONV; a.b_kind = LD_ROW; a.ldb = a.K; a.ldc = cv.cout;
+    a.bias = cv.b;
+    if (rowbias) { a.rowbias = rowbias->p; a.rows_per_img = Ho * Wo; }
+    if (residual) { a.R = residual->p; a.ldr = cv.cout; }
+    a.g = g;
+    run_gemm(this, a);
+    if (rg) {
+        CB_CHECK(!x->rg || cv.wd, CB_ERR_STATE, "conv: dgrad weights were not packed for a layer on the gradient path");
+        CB_CHECK(!x->rg || mode == CONV_SAME || mode == CONV_DOWN || mode == CONV_UP, CB_ERR_ARG, "conv: mode has no dgrad");
+        Conv cvc = cv;
+        tape.push_back([this, x, y, residual, cvc, mode]() {
+            if (!y->ginit) return;
+            if (residual && residual->rg) accumulate(this, residual, y->g);
+            if (!x->rg) return;
+            float beta; float* gx = grad(x, &beta);
+            conv_dgrad(this, y->g, cvc, mode, x->n, x->h, x->w, gx, beta);
+        });
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------- linear
+Ten* Graph::linear(Ten* x, const Lin& l, Ten* residual) {
+    CB_CHECK(x->c == l.in, CB_ERR_SHAPE, "linear: input has %d features, weight expects %d", x->c, l.in);
+    bool rg = x->rg || (residual && residual->rg);
+    Ten* y = make(x->n, x->h, x->w, l.out, rg);
+    long rows = x->rows();
+    if (residual) CB_CHECK(residual->numel() == y->numel(), CB_ERR_SHAPE, "linear: residual shape");
+    if (rows <= 8 && !residual) {
+        k_gemv(L, y->p, x->p, l.w, l.b, (int)rows, l.out, l.in);
+    } else {
+        GemmArgs a;
+        a.A = x->p; a.B = l.w; a.C = y->p; a.M = (int)rows; a.N = l.out; a.K = l.in;
+        a.lda = l.in; a.ldb = l.in; a.ldc = l.out; a.bias = l.b;
+        if (residual) { a.R = residual->p; a.ldr = l.out; }
+        run_gemm(this, a);
+    }
+    if (rg) {
+        Lin lc = l;
+        tape.push_back([this, x, y, residual, lc, rows]() {
+            if (!y->ginit) return;
+            if (residual && residual->rg) accumulate(this, residual, y->g);
+            if (!x->rg) return;
+            GemmArgs d;   // dx[rows,in] = dy[rows,out] . W[out,in]
+            d.A = y->g; d.lda = lc.out; d.a_kind = LD_ROW;
+            d.B = lc.w; d.ldb = lc.in; d.b_kind = LD_COL;
+            d.M = (int)rows; d.N = lc.in; d.K = lc.out; d.ldc = lc.in;
+            float beta; d.C = grad(x, &beta); d.beta = beta;
+            run_gemm(this, d);
+        });
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------- norms
+Ten* Graph::groupnorm(Ten* x, const Norm& nm, bool silu) {
+    CB_CHECK(x->c == nm.c, CB_ERR_SHAPE, "groupnorm: channels %d vs %d", x->c, nm.c);
+    const int G = 32, N = x->n, HW = x->h * x->w, C = x->c;
+    Ten* y = make(x->n, x->h, x->w, x->c, x->rg);
+    float* stats = ctx->arena.allocf((size_t)N * G * 2);
+    float* ws = ctx->arena.allocf(gn_ws_floats(N, HW, C, G) + (size_t)N * G * 2);
+    k_groupnorm_fwd(L, y->p, x->p, nm.g, nm.b, stats, ws, N, HW, C, G, nm.eps, silu ? 1 : 0);
+    if (x->rg) {
+        Norm nc = nm;
+        tape.push_back([this, x, y, nc, stats, ws, N, HW, C, silu]() {
+            if (!y->ginit) return;
+            float beta; float* gx = grad(x, &beta);
+            k_groupnorm_bwd(L, gx, x->p, y->g, nc.g, nc.b, stats, ws, N, HW, C, 32, silu ? 1 : 0, beta);
+        });
+    }
+    return y;
+}
+Ten* Graph::layernorm(Ten* x, const Norm& nm) {
+    CB_CHECK(x->c == nm.c, CB_ERR_SHAPE, "layernorm: channels %d vs %d", x->c, nm.c);
+    Ten* y = make(x->n, x->h, x->w, x->c, x->rg);
+    long rows = x->rows();
+    float* stats = ctx->arena.allocf((size_t)rows * 2);
+    k_layernorm_fwd(L, y->p, x->p, nm.g, nm.b, stats, rows, x->c, nm.eps);
+    if (x->rg) {
+        Norm nc = nm;
+        tape.push_back([this, x, y, nc, stats, rows]() {
+            if (!y->ginit) return;
+            float beta; float* gx = grad(x, &beta);
+            k_layernorm_bwd(L, gx, x->p, y->g, nc.g, stats, rows, x->c, beta);
+        });
+    }
+    return y;
+}
+
+// ---------------------------------------------------------------- attention (materialised scores, round 1)
+// attention.py:170-193 CrossAttention (scale after QK^T, softmax over context), model.py:186-198 AttnBlock,
+// transformers-4.18 CLIPAttention (causal additive mask).
+Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal) {
+    const int B = qt->n, Nq = qt->h * qt->w, Nk = kt->h * kt->w, d = C / heads;
+    CB_CHECK(kt->n == B && C % heads == 0, CB_ERR_SHAPE, "attention: batch/head mismatch");
+    CB_CHECK(qoff + C <= qt->c && koff + C <= kt->c && voff + C <= kt->c, CB_ERR_SHAPE, "attention: column views out of range");
+    const long ldq = qt->c, ldk = kt->c;
+    const int ldS = (int)rup(Nk, 4);
+    const int BH = B * heads;
+    bool rg = qt->rg || kt->rg;
+    float* P = ctx->arena.allocf((size_t)BH * Nq * ldS);
+    Ten* o = make(B, qt->h, qt->w, C, rg);
+
+    GemmArgs s;   // S = scale * Q K^T
+    s.A = qt->p + qoff; s.lda = ldq; s.sAb = (long)Nq * ldq; s.sAh = d;
+    s.B = kt->p + koff; s.ldb = ldk; s.sBb = (long)Nk * ldk; s.sBh = d;
+    s.C = P; s.ldc = ldS; s.sCb = (long)heads * Nq * ldS; s.sCh = (long)Nq * ldS;
+    s.M = Nq; s.N = Nk; s.K = d; s.alpha = scale; s.batch = BH; s.nh = heads;
+    run_gemm(this, s);
+    k_softmax_fwd(L, P, (long)BH * Nq, Nk, ldS, causal ? 1 : 0, Nq);
+    GemmArgs pv;  // O = P V
+    pv.A = P; pv.lda = ldS; pv.sAb = s.sCb; pv.sAh = s.sCh;
+    pv.B = kt->p + voff; pv.ldb = ldk; pv.b_kind = LD_COL; pv.sBb = (long)Nk * ldk; pv.sBh = d;
+    pv.C = o->p; pv.ldc = C; pv.sCb = (long)Nq * C; pv.sCh = d;
+    pv.M = Nq; pv.N = d; pv.K = Nk; pv.batch = BH; pv.nh = heads;
+    run_gemm(this, pv);
+
+    if (rg) {
+        tape.push_back([=]() {
+            if (!o->ginit) return;
+            float* dP = ctx->arena.allocf((size_t)BH * Nq * ldS);
+            GemmArgs a;   // dP = dO V^T
+            a.A = o->g; a.lda = C; a.sAb = (long)Nq * C; a.sAh = d;
+            a.B = kt->p + voff; a.ldb = ldk; a.sBb = (long)Nk * ldk; a.sBh = d;
+            a.C = dP; a.ldc = ldS; a.sCb = (long)heads * Nq * ldS; a.sCh = (long)Nq * ldS;
+            a.M = Nq; a.N = Nk; a.K = d; a.batch = BH; a.nh = heads;
+            run_gemm(this, a);
+            k_softmax_bwd(L, dP, P, (long)BH * Nq, Nk, ldS, scale);   // dP now holds d(QK^T)
+            float bq = 0.f, bk = 0.f; float* gq = nullptr; float* gk = nullptr;
+            if (qt->rg) gq = grad(qt, &bq);
+            if (kt->rg) { if (kt == qt) { gk = gq; bk = bq; } else gk = grad(kt, &bk); }
+            if (gq) {     // dQ = dS K
+                GemmArgs q;
+                q.A = dP; q.lda = ldS; q.sAb = a.sCb; q.sAh = a.sCh;
+                q.B = kt->p + koff; q.ldb = ldk; q.b_kind = LD_COL; q.sBb = (long)Nk * ldk; q.sBh = d;
+                q.C = gq + qoff; q.ldc = ldq; q.sCb = (long)Nq * ldq; q.sCh = d; q.beta = bq;
+                q.M = Nq; q.N = d; q.K = Nk; q.batch = BH; q.nh = heads;
+                run_gemm(this, q);
+            }
+            if (gk) {     // dK = dS^T Q ; dV = P^T dO
+                GemmArgs k;
+                k.A = dP; k.lda = ldS; k.a_kind = LD_COL; k.sAb = a.sCb; k.sAh = a.sCh;
+                k.B = qt->p + qoff; k.ldb = ldq; k.b_kind = LD_COL; k.sBb = (long)Nq * ldq; k.sBh = d;
+                k.C = gk + koff; k.ldc = ldk; k.sCb = (long)Nk * ldk; k.sCh = d; k.beta = bk;
+                k.M = Nk; k.N = d; k.K = Nq; k.batch = BH; k.nh = heads;
+                run_gemm(this, k);
+                GemmArgs v;
+                v.A = P; v.lda = ldS; v.a_kind = LD_COL; v.sAb = a.sCb; v.sAh = a.sCh;
+                v.B = o->g; v.ldb = C; v.b_kind = LD_COL; v.sBb = (long)Nq * C; v.sBh = d;
+                v.C = gk + voff; v.ldc = ldk; v.sCb = (long)Nk * ldk; v.sCh = d; v.beta = bk;
+                v.M = Nk; v.N = d; v.K = Nq; v.batch = BH; v.nh = heads;
+                run_gemm(this, v);
+            }
+        });
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------- activations / glue
+Ten* Graph::geglu(Ten* x) {
+    CB_CHECK(x->c % 2 == 0, CB_ERR_SHAPE, "geglu: odd width");
+    const int D = x->c / 2;
+    Ten* y = make(x->n, x->h, x->w, D, x->rg);
+    k_geglu_fwd(L, y->p, x->p, x->rows(), D);
+    if (x->rg) {
+        tape.push_back([this, x, y, D]() {
+            if (!y->ginit) return;
+            float beta; float* gx = grad(x, &beta);
+            if (beta == 0.f) k_geglu_bwd(L, gx, x->p, y->g, x->rows(), D);
+            else {
+                float* tmp = ctx->arena.allocf((size_t)x->numel());
+                k_geglu_bwd(L, tmp, x->p, y->g, x->rows(), D);
+                k_axpby(L, gx, tmp, x->numel(), 1.f, 1.f);
+            }
+        });
+    }
+    return y;
+}
+Ten* Graph::quickgelu(Ten* x) {
+    Ten* y = make(x->n, x->h, x->w, x->c, x->rg);
+    k_quickgelu_fwd(L, y->p, x->p, x->numel());
+    if (x->rg) {
+        tape.push_back([this, x, y]() {
+            if (!y->ginit) return;
+            float beta; float* gx = grad(x, &beta);
+            k_quickgelu_bwd(L, gx, x->p, y->g, x->numel(), beta);
+        });
+    }
+    return y;
+}
+Ten* Graph::silu(Ten* x) {
+    CB_CHECK(!x->rg, CB_ERR_STATE, "silu: only used on the no-grad timestep path");
+    Ten* y = make(x->n, x->h, x->w, x->c, false);
+    k_silu(L, y->p, x->p, x->numel());
+    return y;
+}
+Ten* Graph::concat(Ten* a, Ten* b) {
+    CB_CHECK(a->rows() == b->rows() && a->h == b->h && a->w == b->w, CB_ERR_SHAPE, "concat: spatial mismatch");
+    const int ca = a->c, cb_ = b->c;
+    Ten* y = make(a->n, a->h, a->w, ca + cb_, a->rg || b->rg);
+    long rows = a->rows();
+    k_copy2d(L, y->p, ca + cb_, a->p, ca, rows, ca, 0.f);
+    k_copy2d(L, y->p + ca, ca + cb_, b->p, cb_, rows, cb_, 0.f);
+    if (y->rg) {
+        tape.push_back([this, a, b, y, ca, cb_, rows]() {
+            if (!y->ginit) return;
+            if (a->rg) { float beta; float* g = grad(a, &beta); k_copy2d(L, g, ca, y->g, ca + cb_, rows, ca, beta); }
+            if (b->rg) { float beta; float* g = grad(b, &beta); k_copy2d(L, g, cb_, y->g + ca, ca + cb_, rows, cb_, beta); }
+        });
+    }
+    return y;
+}
+Ten* Graph::channel_affine(Ten* x, const float* scale, const float* shift, const float* prelu) {
+    CB_CHECK(!x->rg, CB_ERR_STATE, "channel_affine: no-grad path only (frozen FR-net)");
+    Ten* y = make(x->n, x->h, x->w, x->c, false);
+    k_channel_affine(L, y->p, x->p, scale, shift, prelu, x->rows(), x->c);
+    return y;
+}
+
+}  // namespace cb

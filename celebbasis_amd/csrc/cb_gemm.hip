@@ -1,0 +1,416 @@
+// cb_gemm.hip — fp32 MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X).
+//
+// One kernel family covers every dense contraction on the CelebBasis training step
+// (SURVEY.md Appendix A.1, A.4, A.5, A.6): Linear fwd/dgrad, 1x1 and 3x3 conv fwd/dgrad
+// (NHWC implicit GEMM, optional fused nearest-2x upsample or transposed stride-2 gather),
+// and the batched attention contractions (QK^T, PV, and their backward forms).
+//
+//   C[M,N] = alpha * A[M,K] . B[K,N] + bias[n] + rowbias[img(m)][n] + R[m][n] + beta * C[m][n]
+//
+// Design (CDNA4): 256 threads = 4 wave64 in a 2x2 arrangement; each wave owns a (BM/2)x(BN/2)
+// sub-tile made of 32x32 fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF chip peak).
+// Operand tiles are staged through LDS *k-major* ([BK][BM+4]) so that the MFMA fragment read
+// (lane l -> A[m=l&31][k=l>>5]) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave,
+// and so that a transposed operand (M-contiguous in memory) needs no shuffle at all.
+// Global->register prefetch of tile t+1 is issued before the MFMA block of tile t (one barrier per
+// k-tile, double-buffered LDS). Split-K (partials in a workspace + a fused reduce/epilogue kernel)
+// fills the 256 CUs for the small-M / deep-K layers (8x8 and 16x16 UNet levels, CLIP, attention bwd).
+// blockIdx -> tile mapping is XCD-aware (bijective remap) so that tiles sharing an A row-panel
+// land on the same XCD L2.
+#include "cb_common.h"
+#include <cstdarg>
+
+namespace cb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 16;
+
+struct KArgs {
+    GemmArgs a;
+    int tiles_m, tiles_n;
+    int splitk, k_per_split;
+    float* ws;          // split-K partials [split][batch][M][N] (null when splitk == 1)
+    int a_vec, b_vec;   // 1 when the operand may use 16-byte global loads
+};
+
+// ---- tile loaders: global -> registers -------------------------------------------------
+// ROW: element (r, k) at p[r*ld + k]  (k contiguous)   -> NV = ROWS/64 float4 per thread (4 k's of one row)
+// COL: element (r, k) at p[k*ld + r]  (r contiguous)   -> NV = ROWS/64 float4 per thread (4 r's of one k)
+// CONV: row r = output pixel, k = (ky*ks + kx)*C + ci gathered from NHWC input.
+
+template <int ROWS>
+__device__ __forceinline__ void load_row(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R,
+                                         int k0, int Kend, int vec, int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int r = r0 + (idx >> 2);
+        int k = k0 + ((idx & 3) << 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R) {
+            const float* q = p + (long)r * ld + k;
+            if (vec && k + 3 < Kend) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                if (k + 0 < Kend) v.x = q[0];
+                if (k + 1 < Kend) v.y = q[1];
+                if (k + 2 < Kend) v.z = q[2];
+                if (k + 3 < Kend) v.w = q[3];
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+template <int ROWS>
+__device__ __forceinline__ void load_col(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R,
+                                         int k0, int Kend, int vec, int tid) {
+    constexpr int QPR = ROWS / 4;  // float4 per k-row
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int k = k0 + idx / QPR;
+        int r = r0 + (idx % QPR) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (k < Kend) {
+            const float* q = p + (long)k * ld + r;
+            if (vec && r + 3 < R) {
+                v = *reinterpret_cast<const float4*>(q);
+            } else {
+                if (r + 0 < R) v.x = q[0];
+                if (r + 1 < R) v.y = q[1];
+                if (r + 2 < R) v.z = q[2];
+                if (r + 3 < R) v.w = q[3];
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+__device__ __forceinline__ float conv_fetch(const float* __restrict__ p, const ConvGeom& g, int n, int oy, int ox, int k) {
+    int tap = k / g.C;
+    int ci = k - tap * g.C;
+    int ky = tap / g.ks, kx = tap - ky * g.ks;
+    int vy = oy * g.stride + ky - g.pad;
+    int vx = ox * g.stride + kx - g.pad;
+    int sh = (g.up | g.tr);
+    int Hv = g.H << sh, Wv = g.W << sh;
+    if (vy < 0 || vx < 0 || vy >= Hv || vx >= Wv) return 0.f;
+    if (g.tr && ((vy | vx) & 1)) return 0.f;
+    int iy = vy >> sh, ix = vx >> sh;
+    return p[(((long)n * g.H + iy) * g.W + ix) * g.C + ci];
+}
+
+template <int ROWS>
+__device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float* __restrict__ p, const ConvGeom& g,
+                                          int r0, int R, int k0, int Kend, int vec, int tid) {
+    const int HWo = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int r = r0 + (idx >> 2);
+        int k = k0 + ((idx & 3) << 2);
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < R && k < Kend) {
+            int n = r / HWo;
+            int rem = r - n * HWo;
+            int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+            if (vec && k + 3 < Kend) {
+                // C % 4 == 0: the 4 k's share one tap
+                int tap = k / g.C;
+                int ci = k - tap * g.C;
+                int ky = tap / g.ks, kx = tap - ky * g.ks;
+                int vy = oy * g.stride + ky - g.pad;
+                int vx = ox * g.stride + kx - g.pad;
+                int sh = (g.up | g.tr);
+                int Hv = g.H << sh, Wv = g.W << sh;
+                bool ok = (vy >= 0) && (vx >= 0) && (vy < Hv) && (vx < Wv);
+                if (g.tr && ((vy | vx) & 1)) ok = false;
+                if (ok) {
+                    int iy = vy >> sh, ix = vx >> sh;
+                    v = *reinterpret_cast<const float4*>(p + (((long)n * g.H + iy) * g.W + ix) * g.C + ci);
+                }
+            } else {
+                v.x = conv_fetch(p, g, n, oy, ox, k);
+                if (k + 1 < Kend) v.y = conv_fetch(p, g, n, oy, ox, k + 1);
+                if (k + 2 < Kend) v.z = conv_fetch(p, g, n, oy, ox, k + 2);
+                if (k + 3 < Kend) v.w = conv_fetch(p, g, n, oy, ox, k + 3);
+            }
+        }
+        reg[i] = v;
+    }
+}
+
+// ---- registers -> LDS (k-major tile [BK][ROWS+4]) -----------------------------------------
+template <int ROWS>
+__device__ __forceinline__ void store_kcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int r = idx >> 2;
+        int k = (idx & 3) << 2;
+        T[k + 0][r] = reg[i].x;
+        T[k + 1][r] = reg[i].y;
+        T[k + 2][r] = reg[i].z;
+        T[k + 3][r] = reg[i].w;
+    }
+}
+template <int ROWS>
+__device__ __forceinline__ void store_rcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid) {
+    constexpr int QPR = ROWS / 4;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int k = idx / QPR;
+        int r = (idx % QPR) * 4;
+        *reinterpret_cast<float4*>(&T[k][r]) = reg[i];
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    // bijective "XCD x gets a contiguous chunk" remap (guide §5: XCD swizzle must be bijective)
+    int q = n >> 3, r = n & 7;
+    int xcd = b & 7, j = b >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}
+
+template <int BM, int BN, int AK, int BKIND>
+__global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
+
+    const GemmArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int z = blockIdx.z;
+    const int zb = z / a.nh, zh = z - zb * a.nh;
+
+    const float* __restrict__ Ap = a.A + zb * a.sAb + zh * a.sAh;
+    const float* __restrict__ Bp = a.B + zb * a.sBb + zh * a.sBh;
+
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(a.K, kbeg + p.k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 64], rb[BN / 64];
+
+    auto loadA = [&](int k0) {
+        if constexpr (AK == LD_ROW) load_row<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
+        else if constexpr (AK == LD_COL) load_col<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
+        else load_conv<BM>(ra, Ap, a.g, m0, a.M, k0, kend, p.a_vec, tid);
+    };
+    auto loadB = [&](int k0) {
+        if constexpr (BKIND == LD_ROW) load_row<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
+        else load_col<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
+    };
+    auto storeA = [&](int buf) {
+        if constexpr (AK == LD_COL) store_rcontig<BM>(As[buf], ra, tid);
+        else store_kcontig<BM>(As[buf], ra, tid);
+    };
+    auto storeB = [&](int buf) {
+        if constexpr (BKIND == LD_COL) store_rcontig<BN>(Bs[buf], rb, tid);
+        else store_kcontig<BN>(Bs[buf], rb, tid);
+    };
+
+    if (kbeg < kend) {
+        loadA(kbeg); loadB(kbeg);
+        storeA(0); storeB(0);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    const int kl = lane >> 5, ml = lane & 31;
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        const bool more = (k0 + BK) < kend;
+        if (more) { loadA(k0 + BK); loadB(k0 + BK); }
+
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = As[cur][kk + kl][wm * (BM / 2) + i * 32 + ml];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = Bs[cur][kk + kl][wn * (BN / 2) + j * 32 + ml];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+
+        if (more) { storeA(cur ^ 1); storeB(cur ^ 1); }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---- epilogue. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if (p.splitk > 1) {
+        float* W = p.ws + ((long)split * a.batch + z) * (long)a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + wn * (BN / 2) + j * 32 + ml;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    if (row < a.M && col < a.N) W[(long)row * a.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    float* __restrict__ Cp = a.C + zb * a.sCb + zh * a.sCh;
+    const float* __restrict__ Rp = a.R ? a.R + zb * a.sRb + zh * a.sRh : nullptr;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int col = n0 + wn * (BN / 2) + j * 32 + ml;
+            if (col >= a.N) continue;
+            float bcol = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (row < a.M) {
+                    float v = a.alpha * acc[i][j][r] + bcol;
+                    if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * a.N + col];
+                    if (Rp) v += Rp[(long)row * a.ldr + col];
+                    float* c = Cp + (long)row * a.ldc + col;
+                    if (a.beta != 0.f) v += a.beta * (*c);
+                    *c = v;
+                }
+            }
+        }
+}
+
+// split-K reduce + epilogue: one thread per output element
+__global__ void splitk_reduce_kernel(const KArgs p) {
+    const GemmArgs& a = p.a;
+    long MN = (long)a.M * a.N;
+    long total = MN * a.batch;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int z = (int)(i / MN);
+        long rem = i - (long)z * MN;
+        int row = (int)(rem / a.N), col = (int)(rem - (long)row * a.N);
+        float s = 0.f;
+        for (int sp = 0; sp < p.splitk; ++sp) s += p.ws[((long)sp * a.batch + z) * MN + rem];
+        int zb = z / a.nh, zh = z - zb * a.nh;
+        float v = a.alpha * s;
+        if (a.bias) v += a.bias[col];
+        if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * a.N + col];
+        if (a.R) v += a.R[zb * a.sRb + zh * a.sRh + (long)row * a.ldr + col];
+        float* c = a.C + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col;
+        if (a.beta != 0.f) v += a.beta * (*c);
+        *c = v;
+    }
+}
+
+// ---------------------------------------------------------------- host side
+struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
+
+static Plan make_plan(const GemmArgs& a) {
+    Plan pl;
+    // tile choice: big tiles only when they still give >= ~2 waves of blocks over 256 CUs
+    auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * a.batch; };
+    int BM = 128, BN = 128;
+    if (a.N <= 64) BN = 64;
+    if (a.M <= 64) BM = 64;
+    if (tiles(BM, BN) < 512 && BM == 128 && a.M > 64) { BM = 64; }
+    if (tiles(BM, BN) < 512 && BN == 128 && a.N > 64) { BN = 64; }
+    pl.BM = BM; pl.BN = BN;
+    pl.tiles_m = cdiv(a.M, BM); pl.tiles_n = cdiv(a.N, BN);
+    long nb = (long)pl.tiles_m * pl.tiles_n * a.batch;
+    int ksteps = cdiv(a.K, BK);
+    int split = 1;
+    if (nb < 256 && ksteps >= 8) {
+        split = (int)((512 + nb - 1) / nb);
+        int maxsplit = ksteps / 4;           // keep >= 4 k-tiles (64 k) per split
+        if (split > maxsplit) split = maxsplit;
+        if (split > 64) split = 64;
+        if (split < 1) split = 1;
+    }
+    int kps = cdiv(ksteps, split) * BK;
+    split = cdiv(a.K, kps);
+    pl.splitk = split; pl.k_per_split = kps;
+    return pl;
+}
+
+size_t gemm_ws_bytes(const GemmArgs& a) {
+    Plan pl = make_plan(a);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+}
+
+template <int AK, int BKIND>
+static void launch_tiles(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<64, 128, AK, BKIND>), grid, dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKIND>), grid, dim3(256), 0, s, ka);
+}
+
+void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
+    CB_CHECK(a.M > 0 && a.N > 0 && a.K > 0, CB_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    CB_CHECK(a.batch >= 1 && a.nh >= 1 && a.batch % a.nh == 0, CB_ERR_SHAPE, "gemm: bad batch %d/%d", a.batch, a.nh);
+    CB_CHECK(a.beta == 0.f || a.beta == 1.f, CB_ERR_ARG, "gemm: beta must be 0 or 1");
+    if (a.a_kind == LD_CONV) {
+        const ConvGeom& g = a.g;
+        CB_CHECK(g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
+        CB_CHECK(a.K == g.ks * g.ks * g.C, CB_ERR_SHAPE, "conv: K=%d != %d*%d*%d", a.K, g.ks, g.ks, g.C);
+        CB_CHECK(a.M % (g.Ho * g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, g.Ho * g.Wo);
+        CB_CHECK(!(g.up && g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
+        CB_CHECK(a.b_kind == LD_ROW, CB_ERR_ARG, "conv: packed weights must be ROW");
+    }
+    Plan pl = make_plan(a);
+    if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
+    L.count(pl.splitk > 1 ? 2 : 1);
+    if (pl.splitk > 1) {
+        size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+        CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
+    }
+    if (L.dry) return;
+
+    KArgs ka;
+    ka.a = a;
+    ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
+    ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
+    ka.ws = ws;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    auto strides_ok = [](long a, long b) { return (a % 4 == 0) && (b % 4 == 0); };
+    if (a.a_kind == LD_CONV) ka.a_vec = aligned16(a.A) && (a.g.C % 4 == 0);
+    else ka.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && strides_ok(a.sAb, a.sAh);
+    ka.b_vec = aligned16(a.B) && (a.ldb % 4 == 0) && strides_ok(a.sBb, a.sBh);
+
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka);
+    else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka);
+    else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka);
+    else if (a.a_kind == LD_COL && a.b_kind == LD_ROW) launch_tiles<LD_COL, LD_ROW>(pl, grid, L.stream, ka);
+    else if (a.a_kind == LD_CONV) launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka);
+    else fail(CB_ERR_ARG, "gemm: unsupported operand kinds %d/%d", a.a_kind, a.b_kind);
+    CB_HIP(hipGetLastError());
+    if (pl.splitk > 1) {
+        long total = (long)a.M * a.N * a.batch;
+        unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, L.stream, ka);
+        CB_HIP(hipGetLastError());
+    }
+}
+
+}  // namespace cb

@@ -1,0 +1,1059 @@
+// cb_kernels.hip — HBM-bound kernels of the CelebBasis training step for gfx950 (MI355X):
+// GroupNorm(+SiLU), LayerNorm, softmax, GEGLU, activations, layout changes, DDPM glue (q_sample, loss),
+// face warp/resize, the CelebBasis coefficient head (L2-norm, basis contraction, row surgery, EMA),
+// AdamW, and one-time weight packing. All tensors are fp32, activations are NHWC ([tokens][channels]).
+// wave = 64 lanes everywhere; reductions use 64-wide shuffles.
+#include "cb_common.h"
+#include <cstdarg>
+
+namespace cb {
+
+#define LAUNCH(kernel, grid, block, L, ...)                                                   \
+    do {                                                                                      \
+        (L).count();                                                                          \
+        if (!(L).dry) {                                                                       \
+            hipLaunchKernelGGL(kernel, grid, block, 0, (L).stream, __VA_ARGS__);              \
+            CB_HIP(hipGetLastError());                                                        \
+        }                                                                                     \
+    } while (0)
+
+static inline dim3 grid1d(long n, int per_block = 256, int cap = 8192) {
+    long b = (n + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > cap) b = cap;
+    return dim3((unsigned)b);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + __expf(-x)); }
+
+// block-wide sum for 256-thread blocks (4 waves); result valid in all threads
+__device__ __forceinline__ float block_sum256(float v, float* sh /*>=4 floats*/) {
+    v = wave_sum(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+__device__ __forceinline__ float block_max256(float v, float* sh) {
+    v = wave_max(v);
+    int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[w] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// ------------------------------------------------------------------ simple elementwise
+__global__ void fill_kernel(float* p, long n, float v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+void k_fill(const Launch& L, float* p, long n, float v) { LAUNCH(fill_kernel, grid1d(n), dim3(256), L, p, n, v); }
+
+__global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, float a, float b) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = a * src[i];
+        if (b != 0.f) v += b * dst[i];
+        dst[i] = v;
+    }
+}
+void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b) {
+    LAUNCH(axpby_kernel, grid1d(n), dim3(256), L, dst, src, n, a, b);
+}
+
+__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ x, const float* __restrict__ y, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = x[i] + y[i];
+}
+void k_add(const Launch& L, float* dst, const float* x, const float* y, long n) {
+    LAUNCH(add_kernel, grid1d(n), dim3(256), L, dst, x, y, n);
+}
+
+__global__ void copy2d_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds, long rows, int cols,
+                              float beta) {
+    long total = rows * cols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / cols;
+        int c = (int)(i - r * cols);
+        float v = src[r * lds + c];
+        float* d = dst + r * ldd + c;
+        if (beta != 0.f) v += beta * (*d);
+        *d = v;
+    }
+}
+void k_copy2d(const Launch& L, float* dst, long ldd, const float* src, long lds, long rows, int cols, float beta) {
+    LAUNCH(copy2d_kernel, grid1d(rows * cols), dim3(256), L, dst, ldd, src, lds, rows, cols, beta);
+}
+
+__global__ void silu_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float x = src[i];
+        dst[i] = x * sigmoidf_(x);
+    }
+}
+void k_silu(const Launch& L, float* dst, const float* src, long n) { LAUNCH(silu_kernel, grid1d(n), dim3(256), L, dst, src, n); }
+
+// GEGLU (attention.py:37-44): x[M][2D] -> y[M][D] = x[:, :D] * gelu(x[:, D:]), exact erf GELU
+__global__ void geglu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long M, int D) {
+    long total = M * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / D;
+        int c = (int)(i - r * D);
+        float a = x[r * 2 * D + c];
+        float g = x[r * 2 * D + D + c];
+        float ge = 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
+        y[i] = a * ge;
+    }
+}
+void k_geglu_fwd(const Launch& L, float* y, const float* x, long M, int D) {
+    LAUNCH(geglu_fwd_kernel, grid1d(M * D), dim3(256), L, y, x, M, D);
+}
+__global__ void geglu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy, long M, int D) {
+    long total = M * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / D;
+        int c = (int)(i - r * D);
+        float a = x[r * 2 * D + c];
+        float g = x[r * 2 * D + D + c];
+        float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
+        float pdf = 0.39894228040143268f * __expf(-0.5f * g * g);
+        float d = dy[i];
+        dx[r * 2 * D + c] = d * g * cdf;
+        dx[r * 2 * D + D + c] = d * a * (cdf + g * pdf);
+    }
+}
+void k_geglu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long M, int D) {
+    LAUNCH(geglu_bwd_kernel, grid1d(M * D), dim3(256), L, dx, x, dy, M, D);
+}
+
+// quick-GELU x*sigmoid(1.702x) (transformers 4.18 activations.QuickGELUActivation)
+__global__ void quickgelu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        y[i] = v * sigmoidf_(1.702f * v);
+    }
+}
+void k_quickgelu_fwd(const Launch& L, float* y, const float* x, long n) {
+    LAUNCH(quickgelu_fwd_kernel, grid1d(n), dim3(256), L, y, x, n);
+}
+__global__ void quickgelu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy, long n,
+                                     float beta) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        float s = sigmoidf_(1.702f * v);
+        float g = dy[i] * s * (1.f + 1.702f * v * (1.f - s));
+        if (beta != 0.f) g += beta * dx[i];
+        dx[i] = g;
+    }
+}
+void k_quickgelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float beta) {
+    LAUNCH(quickgelu_bwd_kernel, grid1d(n), dim3(256), L, dx, x, dy, n, beta);
+}
+
+__global__ void leakyrelu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float s) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float v = x[i];
+        y[i] = v > 0.f ? v : s * v;
+    }
+}
+void k_leakyrelu_fwd(const Launch& L, float* y, const float* x, long n, float s) {
+    LAUNCH(leakyrelu_fwd_kernel, grid1d(n), dim3(256), L, y, x, n, s);
+}
+__global__ void leakyrelu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy, long n,
+                                     float s) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        dx[i] = x[i] > 0.f ? dy[i] : s * dy[i];
+}
+void k_leakyrelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float s) {
+    LAUNCH(leakyrelu_bwd_kernel, grid1d(n), dim3(256), L, dx, x, dy, n, s);
+}
+
+__global__ void nchw_to_nhwc_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int H, int W) {
+    long total = (long)N * C * H * W;
+    long HW = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes dst (n, hw, c)
+        int c = (int)(i % C);
+        long t = i / C;
+        long hw = t % HW;
+        long n = t / HW;
+        dst[i] = src[(n * C + c) * HW + hw];
+    }
+}
+void k_nchw_to_nhwc(const Launch& L, float* dst, const float* src, int N, int C, int H, int W) {
+    LAUNCH(nchw_to_nhwc_kernel, grid1d((long)N * C * H * W), dim3(256), L, dst, src, N, C, H, W);
+}
+__global__ void nhwc_to_nchw_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int H, int W) {
+    long total = (long)N * C * H * W;
+    long HW = (long)H * W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        // i indexes dst (n, c, hw)
+        long hw = i % HW;
+        long t = i / HW;
+        int c = (int)(t % C);
+        long n = t / C;
+        dst[i] = src[(n * HW + hw) * C + c];
+    }
+}
+void k_nhwc_to_nchw(const Launch& L, float* dst, const float* src, int N, int C, int H, int W) {
+    LAUNCH(nhwc_to_nchw_kernel, grid1d((long)N * C * H * W), dim3(256), L, dst, src, N, C, H, W);
+}
+
+// y = x*scale[c] + shift[c], then optional PReLU(slope[c]) (iresnet.py:44-63: eval BatchNorm + PReLU)
+__global__ void channel_affine_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ scale,
+                                      const float* __restrict__ shift, const float* __restrict__ prelu, long rows, int C) {
+    long total = rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        float v = x[i];
+        if (scale) v = v * scale[c] + shift[c];
+        if (prelu) v = v > 0.f ? v : prelu[c] * v;
+        y[i] = v;
+    }
+}
+void k_channel_affine(const Launch& L, float* y, const float* x, const float* scale, const float* shift, const float* prelu,
+                      long rows, int C) {
+    LAUNCH(channel_affine_kernel, grid1d(rows * C), dim3(256), L, y, x, scale, shift, prelu, rows, C);
+}
+
+// backward of nearest-2x upsample: dx[n,y,x,c] (+)= sum of the 2x2 block of dy (dy is [N,2H,2W,C])
+__global__ void upsample2x_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, int N, int H, int W, int C,
+                                      float beta) {
+    long total = (long)N * H * W * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long t = i / C;
+        int x = (int)(t % W);
+        t /= W;
+        int y = (int)(t % H);
+        long n = t / H;
+        const float* p = dy + (((n * 2 * H + 2 * y) * 2 * W) + 2 * x) * (long)C + c;
+        float v = p[0] + p[C] + p[(long)2 * W * C] + p[(long)2 * W * C + C];
+        if (beta != 0.f) v += beta * dx[i];
+        dx[i] = v;
+    }
+}
+void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H, int W, int C, float beta) {
+    LAUNCH(upsample2x_bwd_kernel, grid1d((long)N * H * W * C), dim3(256), L, dx, dy, N, H, W, C, beta);
+}
+
+// ------------------------------------------------------------------ GroupNorm (NHWC)
+// util.py:214-216 GroupNorm32 (eps 1e-5), attention.py:76-77 / model.py:38-39 Normalize (eps 1e-6).
+// Stage 1: per (image, row-chunk) block computes shifted per-group partial sums (shift = first element of
+// the group in the image, which keeps E[x^2]-E[x]^2 well conditioned); stage 2 combines in double.
+constexpr int GN_ROWS = 64;  // rows of HW per partial block
+constexpr int GN_MAXC_PER_T = 10;  // C <= 2560 with 256 threads
+
+size_t gn_ws_floats(int N, int HW, int C, int G) {
+    (void)C;
+    return (size_t)N * cdiv(HW, GN_ROWS) * G * 2;
+}
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const float* __restrict__ x, int HW, int C,
+                                                          int G, int nchunk) {
+    __shared__ float chs[2560 * 2];
+    int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+    int cpg = C / G;
+    const float* xn = x + (long)n * HW * C;
+    float s[GN_MAXC_PER_T], q[GN_MAXC_PER_T];
+#pragma unroll
+    for (int j = 0; j < GN_MAXC_PER_T; ++j) { s[j] = 0.f; q[j] = 0.f; }
+#pragma unroll
+    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        if (c < C) {
+            float sh = xn[(c / cpg) * cpg];  // shift: row 0, first channel of the group
+            float a = 0.f, b = 0.f;
+            for (int r = r0; r < r1; ++r) {
+                float v = xn[(long)r * C + c] - sh;
+                a += v;
+                b += v * v;
+            }
+            s[j] = a; q[j] = b;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        if (c < C) { chs[c] = s[j]; chs[C + c] = q[j]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        int g = threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; b += chs[C + c]; }
+        float* o = part + (((long)n * nchunk + chunk) * G + g) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+__global__ void gn_final_kernel(float* __restrict__ stats, const float* __restrict__ part, const float* __restrict__ x, int N,
+                                int HW, int C, int G, int nchunk, float eps) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * G) return;
+    int n = i / G, g = i % G;
+    int cpg = C / G;
+    double a = 0, b = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
+        a += o[0]; b += o[1];
+    }
+    double cnt = (double)HW * cpg;
+    double sh = x[(long)n * HW * C + g * cpg];
+    double m = a / cnt;
+    double var = b / cnt - m * m;
+    if (var < 0) var = 0;
+    stats[i * 2 + 0] = (float)(m + sh);
+    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+}
+__global__ void gn_apply_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, const float* __restrict__ stats, long total, int HW, int C, int G,
+                                int silu) {
+    int cpg = C / G;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long n = i / ((long)HW * C);
+        const float* st = stats + (n * G + c / cpg) * 2;
+        float v = (x[i] - st[0]) * st[1] * gamma[c] + beta[c];
+        if (silu) v = v * sigmoidf_(v);
+        y[i] = v;
+    }
+}
+void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, float* ws,
+                     int N, int HW, int C, int G, float eps, int silu) {
+    CB_CHECK(C % G == 0 && C <= 2560 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
+    int nchunk = cdiv(HW, GN_ROWS);
+    LAUNCH(gn_partial_kernel, dim3(N * nchunk), dim3(256), L, ws, x, HW, C, G, nchunk);
+    LAUNCH(gn_final_kernel, dim3(cdiv(N * G, 64)), dim3(64), L, stats, ws, x, N, HW, C, G, nchunk, eps);
+    long total = (long)N * HW * C;
+    LAUNCH(gn_apply_kernel, grid1d(total), dim3(256), L, y, x, gamma, beta, stats, total, HW, C, G, silu);
+}
+
+// backward: t = x_hat*gamma+beta ; dt = dy * silu'(t) (or dy) ; s1 = sum dt*gamma ; s2 = sum dt*gamma*x_hat (per n,g)
+// dx = rstd * (dt*gamma - s1/m - x_hat*s2/m)
+__device__ __forceinline__ float gn_dt(float xh, float gam, float bet, float dy, int silu) {
+    if (!silu) return dy;
+    float t = xh * gam + bet;
+    float s = sigmoidf_(t);
+    return dy * s * (1.f + t * (1.f - s));
+}
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const float* __restrict__ x,
+                                                              const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta, const float* __restrict__ stats,
+                                                              int HW, int C, int G, int nchunk, int silu) {
+    __shared__ float chs[2560 * 2];
+    int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
+    int cpg = C / G;
+    const float* xn = x + (long)n * HW * C;
+    const float* dn = dy + (long)n * HW * C;
+#pragma unroll
+    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        if (c < C) {
+            const float* st = stats + ((long)n * G + c / cpg) * 2;
+            float mean = st[0], rstd = st[1], gam = gamma[c], bet = beta[c];
+            float a = 0.f, b = 0.f;
+            for (int r = r0; r < r1; ++r) {
+                float xh = (xn[(long)r * C + c] - mean) * rstd;
+                float dt = gn_dt(xh, gam, bet, dn[(long)r * C + c], silu) * gam;
+                a += dt;
+                b += dt * xh;
+            }
+            chs[c] = a; chs[C + c] = b;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        int g = threadIdx.x;
+        float a = 0.f, b = 0.f;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; b += chs[C + c]; }
+        float* o = part + (((long)n * nchunk + chunk) * G + g) * 2;
+        o[0] = a; o[1] = b;
+    }
+}
+__global__ void gn_bwd_final_kernel(float* __restrict__ sums, const float* __restrict__ part, int N, int HW, int C, int G,
+                                    int nchunk) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * G) return;
+    int n = i / G, g = i % G;
+    double a = 0, b = 0;
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
+        a += o[0]; b += o[1];
+    }
+    double cnt = (double)HW * (C / G);
+    sums[i * 2 + 0] = (float)(a / cnt);
+    sums[i * 2 + 1] = (float)(b / cnt);
+}
+__global__ void gn_bwd_apply_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy,
+                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                    const float* __restrict__ stats, const float* __restrict__ sums, long total, int HW, int C,
+                                    int G, int silu, float acc_beta) {
+    int cpg = C / G;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long n = i / ((long)HW * C);
+        long sg = n * G + c / cpg;
+        float mean = stats[sg * 2], rstd = stats[sg * 2 + 1];
+        float gam = gamma[c];
+        float xh = (x[i] - mean) * rstd;
+        float dt = gn_dt(xh, gam, beta[c], dy[i], silu) * gam;
+        float v = rstd * (dt - sums[sg * 2] - xh * sums[sg * 2 + 1]);
+        if (acc_beta != 0.f) v += acc_beta * dx[i];
+        dx[i] = v;
+    }
+}
+void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
+                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta) {
+    CB_CHECK(C % G == 0 && C <= 2560 && G <= 256, CB_ERR_SHAPE, "groupnorm bwd: C=%d G=%d unsupported", C, G);
+    int nchunk = cdiv(HW, GN_ROWS);
+    float* part = ws;
+    float* sums = ws + (size_t)N * nchunk * G * 2;  // caller provides gn_ws_floats + N*G*2
+    LAUNCH(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), L, part, x, dy, gamma, beta, stats, HW, C, G, nchunk, silu);
+    LAUNCH(gn_bwd_final_kernel, dim3(cdiv(N * G, 64)), dim3(64), L, sums, part, N, HW, C, G, nchunk);
+    long total = (long)N * HW * C;
+    LAUNCH(gn_bwd_apply_kernel, grid1d(total), dim3(256), L, dx, x, dy, gamma, beta, stats, sums, total, HW, C, G, silu, acc_beta);
+}
+
+// ------------------------------------------------------------------ LayerNorm: one wave per row, C <= 64*24
+constexpr int LN_MAX_PER_LANE = 24;
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                             const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                             float* __restrict__ stats, long rows, int C, float eps) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const float* xr = x + row * C;
+    float v[LN_MAX_PER_LANE];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        int c = lane + j * 64;
+        v[j] = (c < C) ? xr[c] : 0.f;
+        s += v[j];
+    }
+    float mean = wave_sum(s) / C;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        int c = lane + j * 64;
+        float d = (c < C) ? v[j] - mean : 0.f;
+        q += d * d;
+    }
+    float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
+    if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
+    float* yr = y + row * C;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        int c = lane + j * 64;
+        if (c < C) yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+    }
+}
+void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, long rows,
+                     int C, float eps) {
+    CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm: C=%d too large", C);
+    LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, y, x, gamma, beta, stats, rows, C, eps);
+}
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x,
+                                                             const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                             const float* __restrict__ stats, long rows, int C, float acc_beta) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    const float* xr = x + row * C;
+    const float* dr = dy + row * C;
+    float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float xh[LN_MAX_PER_LANE], dg[LN_MAX_PER_LANE];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        int c = lane + j * 64;
+        if (c < C) {
+            xh[j] = (xr[c] - mean) * rstd;
+            dg[j] = dr[c] * gamma[c];
+        } else { xh[j] = 0.f; dg[j] = 0.f; }
+        s1 += dg[j];
+        s2 += dg[j] * xh[j];
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    float* o = dx + row * C;
+#pragma unroll
+    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
+        int c = lane + j * 64;
+        if (c < C) {
+            float v = rstd * (dg[j] - s1 - xh[j] * s2);
+            if (acc_beta != 0.f) v += acc_beta * o[c];
+            o[c] = v;
+        }
+    }
+}
+void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* stats,
+                     long rows, int C, float acc_beta) {
+    CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm bwd: C=%d too large", C);
+    LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, x, dy, gamma, stats, rows, C, acc_beta);
+}
+
+// ------------------------------------------------------------------ row softmax (materialised attention path)
+// one 256-thread block per row; n <= 256*16
+constexpr int SM_PER_T = 16;
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, int n, int ld, int causal, int rows_per_mat) {
+    __shared__ float sh[4];
+    long row = blockIdx.x;
+    float* r = S + row * ld;
+    int lim = causal ? (int)(row % rows_per_mat) + 1 : n;  // columns [0, lim) are visible
+    if (lim > n) lim = n;
+    float v[SM_PER_T];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SM_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        v[j] = (c < lim) ? r[c] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = block_max256(mx, sh);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        v[j] = (c < lim) ? __expf(v[j] - mx) : 0.f;
+        s += v[j];
+    }
+    s = block_sum256(s, sh);
+    float inv = 1.f / s;
+#pragma unroll
+    for (int j = 0; j < SM_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        if (c < n) r[c] = v[j] * inv;
+    }
+}
+void k_softmax_fwd(const Launch& L, float* S, long rows, int n, int ld, int causal, int rows_per_mat) {
+    CB_CHECK(n <= 256 * SM_PER_T, CB_ERR_SHAPE, "softmax: n=%d too large", n);
+    LAUNCH(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), L, S, n, ld, causal, rows_per_mat);
+}
+__global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dP, const float* __restrict__ P, int n, int ld,
+                                                           float scale) {
+    __shared__ float sh[4];
+    long row = blockIdx.x;
+    float* d = dP + row * ld;
+    const float* p = P + row * ld;
+    float pv[SM_PER_T], dv[SM_PER_T];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SM_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        pv[j] = (c < n) ? p[c] : 0.f;
+        dv[j] = (c < n) ? d[c] : 0.f;
+        s += pv[j] * dv[j];
+    }
+    s = block_sum256(s, sh);
+#pragma unroll
+    for (int j = 0; j < SM_PER_T; ++j) {
+        int c = threadIdx.x + j * 256;
+        if (c < n) d[c] = scale * pv[j] * (dv[j] - s);
+    }
+}
+void k_softmax_bwd(const Launch& L, float* dP, const float* P, long rows, int n, int ld, float scale) {
+    CB_CHECK(n <= 256 * SM_PER_T, CB_ERR_SHAPE, "softmax bwd: n=%d too large", n);
+    LAUNCH(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), L, dP, P, n, ld, scale);
+}
+
+// ------------------------------------------------------------------ diffusion glue
+// util.py:151-171 timestep_embedding: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(10000) * i / half)
+__global__ void timestep_embedding_kernel(float* __restrict__ out, const int64_t* __restrict__ t, int B, int dim) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    int half = dim / 2;
+    if (i >= B * half) return;
+    int b = i / half, j = i % half;
+    float freq = expf(-logf(10000.f) * (float)j / (float)half);
+    float arg = (float)t[b] * freq;
+    out[(long)b * dim + j] = cosf(arg);
+    out[(long)b * dim + half + j] = sinf(arg);
+    if ((dim & 1) && j == 0) out[(long)b * dim + dim - 1] = 0.f;
+}
+void k_timestep_embedding(const Launch& L, float* out, const int64_t* t, int B, int dim) {
+    LAUNCH(timestep_embedding_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), L, out, t, B, dim);
+}
+
+// ddpm.py:289-292 q_sample. x0/xt NHWC [B,HW,C]; eps is the caller's NCHW noise.
+__global__ void qsample_kernel(float* __restrict__ xt, const float* __restrict__ x0, const float* __restrict__ eps,
+                               const int64_t* __restrict__ t, const float* __restrict__ sa, const float* __restrict__ sb, int B,
+                               int C, int HW) {
+    long total = (long)B * C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        long hw = r % HW;
+        long b = r / HW;
+        float e = eps[(b * C + c) * HW + hw];
+        int64_t tt = t[b];
+        xt[i] = sa[tt] * x0[i] + sb[tt] * e;
+    }
+}
+void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
+               const float* sqrt_1mac, int B, int C, int HW) {
+    LAUNCH(qsample_kernel, grid1d((long)B * C * HW), dim3(256), L, xt, x0, eps_nchw, t, sqrt_ac, sqrt_1mac, B, C, HW);
+}
+
+// ddpm.py:1069-1116 with l2 / eps-parameterisation / logvar==0: loss = mean((pred - eps)^2); dpred = 2 (pred-eps)/numel
+__global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss, float* __restrict__ dpred,
+                                                        const float* __restrict__ pred, const float* __restrict__ target, int B,
+                                                        int C, int HW) {
+    __shared__ float sh[4];
+    long total = (long)B * C * HW;
+    float inv = 1.f / (float)total;
+    float acc = 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        long hw = r % HW;
+        long b = r / HW;
+        float d = pred[i] - target[(b * C + c) * HW + hw];
+        acc += d * d;
+        if (dpred) dpred[i] = 2.f * d * inv;
+    }
+    acc = block_sum256(acc, sh);
+    if (threadIdx.x == 0) atomicAdd(loss, acc * inv);
+}
+void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw, int B, int C, int HW) {
+    LAUNCH(fill_kernel, dim3(1), dim3(64), L, loss, 1L, 0.f);
+    LAUNCH(mse_loss_kernel, grid1d((long)B * C * HW, 256, 64), dim3(256), L, loss, dpred, pred, target_nchw, B, C, HW);
+}
+
+// distributions.py:24-37 + ddpm.py:597: z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale
+// moments NHWC [B,HW,2*Cz]; noise NCHW [B,Cz,HW]; z NHWC [B,HW,Cz]
+__global__ void vae_sample_kernel(float* __restrict__ z, const float* __restrict__ mom, const float* __restrict__ noise, int B,
+                                  int HW, int Cz, float scale) {
+    long total = (long)B * HW * Cz;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cz);
+        long r = i / Cz;
+        long hw = r % HW;
+        long b = r / HW;
+        float mean = mom[r * 2 * Cz + c];
+        float lv = fminf(fmaxf(mom[r * 2 * Cz + Cz + c], -30.f), 20.f);
+        float nz = noise ? noise[(b * Cz + c) * HW + hw] : 0.f;
+        z[i] = (mean + expf(0.5f * lv) * nz) * scale;
+    }
+}
+void k_vae_sample(const Launch& L, float* z, const float* moments, const float* noise_nchw, int B, int HW, int Cz, float scale) {
+    LAUNCH(vae_sample_kernel, grid1d((long)B * HW * Cz), dim3(256), L, z, moments, noise_nchw, B, HW, Cz, scale);
+}
+
+__global__ void gather_rows_kernel(float* __restrict__ out, const float* __restrict__ table, const int64_t* __restrict__ idx,
+                                   long rows, int C, long table_rows) {
+    long total = rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C;
+        int c = (int)(i - r * C);
+        int64_t id = idx[r];
+        out[i] = (id >= 0 && id < table_rows) ? table[id * C + c] : 0.f;
+    }
+}
+void k_gather_rows(const Launch& L, float* out, const float* table, const int64_t* idx, long rows, int C, long table_rows) {
+    LAUNCH(gather_rows_kernel, grid1d(rows * C), dim3(256), L, out, table, idx, rows, C, table_rows);
+}
+// dst[r][c] = x[r][c] + pos[r % period][c]
+__global__ void add_rowbcast_kernel(float* __restrict__ dst, const float* __restrict__ x, const float* __restrict__ pos,
+                                    long rows, int period, int C) {
+    long total = rows * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / C;
+        int c = (int)(i - r * C);
+        dst[i] = x[i] + pos[(r % period) * C + c];
+    }
+}
+void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* pos, long rows, int period, int C) {
+    LAUNCH(add_rowbcast_kernel, grid1d(rows * C), dim3(256), L, dst, x, pos, rows, period, C);
+}
+
+// ------------------------------------------------------------------ face pre-processing (meta_net.py:250-260)
+// faces: [B, S, S, 3*nface] HWC; out: [nface*B, S, S, 3] with face f of sample b at index f*B + b
+// (forward_multi_faces chunks along channels then cats along batch, meta_net.py:336-337).
+// affine_grid(theta, align_corners=True) + grid_sample(bilinear, zeros, align_corners=True).
+__global__ void affine_warp_kernel(float* __restrict__ out, const float* __restrict__ faces, int B, int S, int nface, float t00,
+                                   float t01, float t02, float t10, float t11, float t12) {
+    long total = (long)nface * B * S * S;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int x = (int)(i % S);
+        long r = i / S;
+        int y = (int)(r % S);
+        long fb = r / S;
+        int f = (int)(fb / B), b = (int)(fb % B);
+        float xn = (2.f * x) / (S - 1) - 1.f;
+        float yn = (2.f * y) / (S - 1) - 1.f;
+        float gx = t00 * xn + t01 * yn + t02;
+        float gy = t10 * xn + t11 * yn + t12;
+        float ix = (gx + 1.f) * 0.5f * (S - 1);
+        float iy = (gy + 1.f) * 0.5f * (S - 1);
+        float fx0 = floorf(ix), fy0 = floorf(iy);
+        int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
+        float wx1 = ix - fx0, wx0 = 1.f - wx1, wy1 = iy - fy0, wy0 = 1.f - wy1;
+        const float* base = faces + (long)b * S * S * 3 * nface + 3 * f;
+        long pstride = 3L * nface;
+        float acc[3] = {0.f, 0.f, 0.f};
+        bool okx0 = x0 >= 0 && x0 < S, okx1 = x1 >= 0 && x1 < S, oky0 = y0 >= 0 && y0 < S, oky1 = y1 >= 0 && y1 < S;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = 0.f;
+            if (oky0 && okx0) v += base[((long)y0 * S + x0) * pstride + c] * (wy0 * wx0);
+            if (oky0 && okx1) v += base[((long)y0 * S + x1) * pstride + c] * (wy0 * wx1);
+            if (oky1 && okx0) v += base[((long)y1 * S + x0) * pstride + c] * (wy1 * wx0);
+            if (oky1 && okx1) v += base[((long)y1 * S + x1) * pstride + c] * (wy1 * wx1);
+            acc[c] = v;
+        }
+        float* o = out + i * 3;
+        o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
+    }
+}
+void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* th) {
+    LAUNCH(affine_warp_kernel, grid1d((long)nface * B * S * S), dim3(256), L, out, faces, B, S, nface, th[0], th[1], th[2], th[3],
+           th[4], th[5]);
+}
+// F.interpolate(mode='bilinear', align_corners=True), NHWC
+__global__ void resize_bilinear_ac_kernel(float* __restrict__ out, const float* __restrict__ in, int N, int Hin, int Win,
+                                          int Hout, int Wout, int C) {
+    long total = (long)N * Hout * Wout * C;
+    float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
+    float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        int x = (int)(r % Wout);
+        r /= Wout;
+        int y = (int)(r % Hout);
+        long n = r / Hout;
+        float fy = sy * y, fx = sx * x;
+        int y0 = (int)fy, x0 = (int)fx;
+        int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+        float ly = fy - y0, lx = fx - x0;
+        const float* p = in + n * (long)Hin * Win * C + c;
+        float v00 = p[((long)y0 * Win + x0) * C], v01 = p[((long)y0 * Win + x1) * C];
+        float v10 = p[((long)y1 * Win + x0) * C], v11 = p[((long)y1 * Win + x1) * C];
+        out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C) {
+    LAUNCH(resize_bilinear_ac_kernel, grid1d((long)N * Hout * Wout * C), dim3(256), L, out, in, N, Hin, Win, Hout, Wout, C);
+}
+
+// ------------------------------------------------------------------ coefficient head (meta_net.py:266-289)
+// F.normalize(x, dim=-1): y = x / max(||x||, 1e-12); one wave per row
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(float* __restrict__ y, float* __restrict__ norms,
+                                                          const float* __restrict__ x, long rows, int D) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) { float v = x[row * D + c]; s += v * v; }
+    float nrm = fmaxf(sqrtf(wave_sum(s)), 1e-12f);
+    if (lane == 0 && norms) norms[row] = nrm;
+    for (int c = lane; c < D; c += 64) y[row * D + c] = x[row * D + c] / nrm;
+}
+void k_l2norm_fwd(const Launch& L, float* y, float* norms, const float* x, long rows, int D) {
+    LAUNCH(l2norm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, y, norms, x, rows, D);
+}
+// dx = (dy - y * (y . dy)) / norm
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ y,
+                                                          const float* __restrict__ norms, const float* __restrict__ dy, long rows,
+                                                          int D) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float s = 0.f;
+    for (int c = lane; c < D; c += 64) s += y[row * D + c] * dy[row * D + c];
+    s = wave_sum(s);
+    float inv = 1.f / norms[row];
+    for (int c = lane; c < D; c += 64) dx[row * D + c] = (dy[row * D + c] - y[row * D + c] * s) * inv;
+}
+void k_l2norm_bwd(const Launch& L, float* dx, const float* y, const float* norms, const float* dy, long rows, int D) {
+    LAUNCH(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, y, norms, dy, rows, D);
+}
+// z[r,e,c] = sum_k coef[r,e,k] * basis[e,1+k,c] + basis[e,0,c]   (einsum 'behk,ekc->behc' with h=1)
+__global__ void basis_fwd_kernel(float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ basis, int R,
+                                 int E, int Kc, int Cz) {
+    long total = (long)R * E * Cz;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % Cz);
+        long re = i / Cz;
+        int e = (int)(re % E);
+        const float* bs = basis + (long)e * (Kc + 1) * Cz;
+        const float* cf = coef + re * Kc;
+        float acc = 0.f;
+        for (int k = 0; k < Kc; ++k) acc += cf[k] * bs[(long)(1 + k) * Cz + c];
+        z[i] = acc + bs[c];
+    }
+}
+void k_basis_fwd(const Launch& L, float* z, const float* coef, const float* basis, int R, int E, int Kc, int Cz) {
+    LAUNCH(basis_fwd_kernel, grid1d((long)R * E * Cz, 64), dim3(64), L, z, coef, basis, R, E, Kc, Cz);
+}
+// dcoef[r,e,k] = sum_c dz[r,e,c] * basis[e,1+k,c] : one wave per (r,e,k)
+__global__ __launch_bounds__(256) void basis_bwd_kernel(float* __restrict__ dcoef, const float* __restrict__ dz,
+                                                         const float* __restrict__ basis, int R, int E, int Kc, int Cz) {
+    long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    long total = (long)R * E * Kc;
+    if (w >= total) return;
+    int lane = threadIdx.x & 63;
+    int k = (int)(w % Kc);
+    long re = w / Kc;
+    int e = (int)(re % E);
+    const float* bs = basis + ((long)e * (Kc + 1) + 1 + k) * Cz;
+    const float* d = dz + re * Cz;
+    float s = 0.f;
+    for (int c = lane; c < Cz; c += 64) s += d[c] * bs[c];
+    s = wave_sum(s);
+    if (lane == 0) dcoef[w] = s;
+}
+void k_basis_bwd(const Launch& L, float* dcoef, const float* dz, const float* basis, int R, int E, int Kc, int Cz) {
+    LAUNCH(basis_bwd_kernel, dim3(cdiv((long)R * E * Kc, 4)), dim3(256), L, dcoef, dz, basis, R, E, Kc, Cz);
+}
+
+// Row surgery (helpers.py:13-41 shift_tensor_dim0 + embedding_manager.py:347-360), one block per sample.
+// map[b][o] = source row i >= 0 (copy in[b][i]) or -(1+j) (take z[b][j], j < reps).
+__global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                               const float* __restrict__ z, const int64_t* __restrict__ tokens,
+                                                               int32_t* __restrict__ map, int T, int C, int reps,
+                                                               int64_t placeholder) {
+    __shared__ int smap[256];
+    int b = blockIdx.x;
+    if (threadIdx.x == 0) {
+        int cnt = 0;
+        for (int i = 0; i < T; ++i) if (tokens[(long)b * T + i] == placeholder) ++cnt;
+        int keep = T - cnt * (reps - 1);  // rows of the source that survive ("drop the last")
+        for (int o = 0; o < T; ++o) smap[o] = o;  // untouched rows keep their own content
+        int shift = 0;
+        for (int i = 0; i < keep && i < T; ++i) {
+            int tgt = i + shift;
+            if (tgt < T) smap[tgt] = i;
+            if (tokens[(long)b * T + i] == placeholder) {
+                for (int j = 0; j < reps; ++j) if (tgt + j < T) smap[tgt + j] = -(1 + j);
+                shift += reps - 1;
+            }
+        }
+    }
+    __syncthreads();
+    for (int o = threadIdx.x; o < T; o += blockDim.x) map[(long)b * T + o] = smap[o];
+    for (int i = threadIdx.x; i < T * C; i += blockDim.x) {
+        int o = i / C, c = i - o * C;
+        int s = smap[o];
+        float v = (s >= 0) ? in[((long)b * T + s) * C + c] : z[((long)b * reps + (-s - 1)) * C + c];
+        out[((long)b * T + o) * C + c] = v;
+    }
+}
+void k_row_surgery_fwd(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens, int32_t* map, int B,
+                       int T, int C, int reps, int64_t placeholder) {
+    CB_CHECK(T <= 256, CB_ERR_SHAPE, "row surgery: T=%d > 256", T);
+    LAUNCH(row_surgery_fwd_kernel, dim3(B), dim3(256), L, out, in, z, tokens, map, T, C, reps, placeholder);
+}
+// dz[b][j][c] = sum over output rows o with map == -(1+j) of dout[b][o][c]
+__global__ void row_surgery_bwd_kernel(float* __restrict__ dz, const float* __restrict__ dout, const int32_t* __restrict__ map,
+                                       int B, int T, int C, int reps) {
+    long total = (long)B * reps * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long bj = i / C;
+        int j = (int)(bj % reps);
+        long b = bj / reps;
+        float acc = 0.f;
+        for (int o = 0; o < T; ++o)
+            if (map[b * T + o] == -(1 + j)) acc += dout[(b * T + o) * C + c];
+        dz[i] = acc;
+    }
+}
+void k_row_surgery_bwd(const Launch& L, float* dz, const float* dout, const int32_t* map, int B, int T, int C, int reps) {
+    LAUNCH(row_surgery_bwd_kernel, grid1d((long)B * reps * C), dim3(256), L, dz, dout, map, B, T, C, reps);
+}
+
+// embedding_manager.py:484-489: dict[id] = m*dict[id] + (1-m)*pred, samples applied in batch order
+__global__ void ema_update_kernel(float* __restrict__ id_emb, float* __restrict__ id_coef, const float* __restrict__ z,
+                                  const float* __restrict__ coef, const int64_t* __restrict__ ids, int ids_stride, int B,
+                                  int embN, int coefN, int max_ids, float m) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    for (int b = 0; b < B; ++b) {
+        int64_t id = ids[(long)b * ids_stride];
+        if (id < 0 || id >= max_ids) continue;
+        if (i < embN) id_emb[id * embN + i] = m * id_emb[id * embN + i] + (1.f - m) * z[(long)b * embN + i];
+        if (i < coefN) id_coef[id * coefN + i] = m * id_coef[id * coefN + i] + (1.f - m) * coef[(long)b * coefN + i];
+    }
+}
+void k_ema_update(const Launch& L, float* id_emb, float* id_coef, const float* z, const float* coef, const int64_t* ids,
+                  int ids_stride, int B, int embN, int coefN, int max_ids, float m) {
+    int n = embN > coefN ? embN : coefN;
+    LAUNCH(ema_update_kernel, dim3(cdiv(n, 256)), dim3(256), L, id_emb, id_coef, z, coef, ids, ids_stride, B, embN, coefN, max_ids,
+           m);
+}
+
+// dW[o][i] = sum_r dpre[r][o] * v[r][i] ; db[o] = sum_r dpre[r][o]   (EqualLinear wgrad, meta_net.py:41-48)
+__global__ void outer_grad_kernel(float* __restrict__ dW, float* __restrict__ db, const float* __restrict__ dpre,
+                                  const float* __restrict__ v, int R, int O, int I) {
+    long total = (long)O * I;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int o = (int)(idx / I), i = (int)(idx - (long)o * I);
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += dpre[(long)r * O + o] * v[(long)r * I + i];
+        dW[idx] = acc;
+        if (i == 0) {
+            float s = 0.f;
+            for (int r = 0; r < R; ++r) s += dpre[(long)r * O + o];
+            db[o] = s;
+        }
+    }
+}
+void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, const float* v, int R, int O, int I) {
+    LAUNCH(outer_grad_kernel, grid1d((long)O * I), dim3(256), L, dW, db, dpre, v, R, O, I);
+}
+
+// torch.optim.AdamW single-tensor update (ddpm.py:1454; defaults betas (0.9,0.999), eps 1e-8, wd 1e-2).
+// The step counter lives on the device so the whole training step can be replayed from a hipGraph.
+__global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
+                             long n, const int* __restrict__ step, float lr, float b1, float b2, float eps, float wd) {
+    int t = *step;
+    double bc1 = 1.0 - pow((double)b1, (double)t);
+    double bc2 = 1.0 - pow((double)b2, (double)t);
+    float step_size = (float)((double)lr / bc1);
+    float bc2s = (float)sqrt(bc2);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float gi = g[i];
+        float pi = p[i] * (1.f - lr * wd);
+        float mi = m[i] + (gi - m[i]) * (1.f - b1);   // exp_avg.lerp_(grad, 1-beta1)
+        float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        float denom = sqrtf(vi) / bc2s + eps;
+        p[i] = pi - step_size * (mi / denom);
+        m[i] = mi; v[i] = vi;
+    }
+}
+void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step, float lr, float b1, float b2,
+             float eps, float wd) {
+    LAUNCH(adamw_kernel, grid1d(n), dim3(256), L, p, m, v, g, n, step, lr, b1, b2, eps, wd);
+}
+__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+void k_step_inc(const Launch& L, int* step) { LAUNCH(step_inc_kernel, dim3(1), dim3(64), L, step); }
+
+// y[m][n] = sum_k x[m][k] W[n][k] + bias[n], M <= 8: one wave per output column, weight-streaming bound
+__global__ __launch_bounds__(256) void gemv_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ W,
+                                                    const float* __restrict__ bias, int M, int N, int K) {
+    int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    int lane = threadIdx.x & 63;
+    const float* w = W + (long)n * K;
+    float acc[8];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) acc[m] = 0.f;
+    if ((K & 3) == 0) {
+        for (int k = lane * 4; k < K; k += 256) {
+            float4 wv = *reinterpret_cast<const float4*>(w + k);
+#pragma unroll
+            for (int m = 0; m < 8; ++m)
+                if (m < M) {
+                    float4 xv = *reinterpret_cast<const float4*>(x + (long)m * K + k);
+                    acc[m] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+                }
+        }
+    } else {
+        for (int k = lane; k < K; k += 64) {
+            float wv = w[k];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) if (m < M) acc[m] += wv * x[(long)m * K + k];
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < 8; ++m)
+        if (m < M) {
+            float s = wave_sum(acc[m]);
+            if (lane == 0) y[(long)m * N + n] = s + (bias ? bias[n] : 0.f);
+        }
+}
+void k_gemv(const Launch& L, float* y, const float* x, const float* W, const float* bias, int M, int N, int K) {
+    CB_CHECK(M >= 1 && M <= 8, CB_ERR_SHAPE, "gemv: M=%d must be in 1..8", M);
+    if (L.stats) L.stats->gemm_flops += 2.0 * M * N * (double)K;
+    LAUNCH(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), L, y, x, W, bias, M, N, K);
+}
+
+// ------------------------------------------------------------------ one-time weight packing
+// OIHW -> [O][ky][kx][I]  (B operand of the implicit GEMM, k = (ky*ks+kx)*I + ci)
+__global__ void pack_conv_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
+    long total = (long)O * I * ks * ks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int ci = (int)(i % I);
+        long r = i / I;
+        int kx = (int)(r % ks);
+        r /= ks;
+        int ky = (int)(r % ks);
+        long o = r / ks;
+        out[i] = w[((o * I + ci) * ks + ky) * ks + kx];
+    }
+}
+void k_pack_conv(const Launch& L, float* out, const float* w, int O, int I, int ks) {
+    LAUNCH(pack_conv_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
+}
+// OIHW -> [I][ky'][kx'][O] with the kernel flipped: out[ci][ky'][kx'][co] = w[co][ci][ks-1-ky'][ks-1-kx']
+__global__ void pack_conv_dgrad_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
+    long total = (long)O * I * ks * ks;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % O);
+        long r = i / O;
+        int kx = (int)(r % ks);
+        r /= ks;
+        int ky = (int)(r % ks);
+        long ci = r / ks;
+        out[i] = w[(((long)co * I + ci) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+    }
+}
+void k_pack_conv_dgrad(const Launch& L, float* out, const float* w, int O, int I, int ks) {
+    LAUNCH(pack_conv_dgrad_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
+}
+// fc over torch.flatten(NCHW): w[o][c*HW + hw] -> out[o][hw*C + c]   (iresnet.py:176-179)
+__global__ void pack_fc_nhwc_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int C, int HW) {
+    long total = (long)O * C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        int hw = (int)(r % HW);
+        long o = r / HW;
+        out[i] = w[(o * C + c) * HW + hw];
+    }
+}
+void k_pack_fc_nhwc(const Launch& L, float* out, const float* w, int O, int C, int HW) {
+    LAUNCH(pack_fc_nhwc_kernel, grid1d((long)O * C * HW), dim3(256), L, out, w, O, C, HW);
+}
+// fold an eval BatchNorm that FOLLOWS a bias-free conv/linear into its packed weights [O][per_o] and a bias
+__global__ void fold_bn_kernel(float* __restrict__ wp, float* __restrict__ bias_out, const float* __restrict__ bw,
+                               const float* __restrict__ bb, const float* __restrict__ bm, const float* __restrict__ bv, float eps,
+                               int O, long per_o) {
+    long total = (long)O * per_o;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long o = i / per_o;
+        float s = bw[o] / sqrtf(bv[o] + eps);
+        wp[i] *= s;
+        if (i % per_o == 0) bias_out[o] = bb[o] - bm[o] * s;
+    }
+}
+void k_fold_bn(const Launch& L, float* wp, float* bias_out, const float* bw, const float* bb, const float* bm, const float* bv,
+               float eps, int O, long per_o) {
+    LAUNCH(fold_bn_kernel, grid1d((long)O * per_o), dim3(256), L, wp, bias_out, bw, bb, bm, bv, eps, O, per_o);
+}
+__global__ void bn_to_affine_kernel(float* __restrict__ scale, float* __restrict__ shift, const float* __restrict__ w,
+                                    const float* __restrict__ b, const float* __restrict__ m, const float* __restrict__ v, float eps,
+                                    int C) {
+    int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float s = w[c] / sqrtf(v[c] + eps);
+    scale[c] = s;
+    shift[c] = b[c] - m[c] * s;
+}
+void k_bn_to_affine(const Launch& L, float* scale, float* shift, const float* w, const float* b, const float* m, const float* v,
+                    float eps, int C) {
+    LAUNCH(bn_to_affine_kernel, dim3(cdiv(C, 256)), dim3(256), L, scale, shift, w, b, m, v, eps, C);
+}
+
+}  // namespace cb

@@ -1,0 +1,116 @@
+// cb_models.h — the frozen networks of the CelebBasis training step expressed on the native tape runtime.
+#pragma once
+#include "cb_engine.h"
+
+namespace cb {
+
+// ---------------------------------------------------------------- UNet (openaimodel.py:413-742)
+struct UNetCfg {
+    int in_channels = 4, out_channels = 4, model_channels = 320;
+    int num_res_blocks = 2;
+    int channel_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0}; int n_mult = 4;
+    int attention_resolutions[8] = {4, 2, 1, 0, 0, 0, 0, 0}; int n_attn = 3;
+    int num_heads = 8;
+    int context_dim = 768;
+};
+struct ResBlockW { Norm n1; Conv c1; Lin emb; Norm n2; Conv c2; bool has_skip = false; Lin skip; int cin = 0, cout = 0; };
+struct XfmrW { Norm norm; Lin proj_in; Norm ln1, ln2, ln3; Lin qkv1, out1, q2, kv2, out2, ff1, ff2, proj_out; int ch = 0, heads = 0; };
+struct UBlock { bool has_res = false; ResBlockW res; bool has_xf = false; XfmrW xf; bool has_down = false; Conv down;
+                bool has_up = false; Conv up; };
+struct UNet {
+    UNetCfg cfg;
+    Lin te0, te2;
+    Conv conv_in;
+    std::vector<UBlock> in_blocks;      // input_blocks[1..]
+    ResBlockW mid1, mid2; XfmrW midx;
+    std::vector<UBlock> out_blocks;
+    Norm out_norm; Conv out_conv;
+};
+void unet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const UNetCfg& cfg, UNet* U);
+// x: [B,H,W,Cin] NHWC, t: device int64[B], context: [B,L,ctx_dim]; returns eps_hat [B,H,W,Cout]
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context);
+
+// ---------------------------------------------------------------- VAE encoder (model.py:368-459, autoencoder.py:324-328)
+struct VaeCfg { int ch = 128; int ch_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0}; int n_mult = 4; int num_res_blocks = 2; int in_channels = 3;
+                int z_channels = 4; };
+struct VResW { Norm n1; Conv c1; Norm n2; Conv c2; bool has_nin = false; Lin nin; };
+struct VaeEnc {
+    VaeCfg cfg;
+    Conv conv_in;
+    std::vector<std::vector<VResW>> down; std::vector<Conv> downsample; std::vector<bool> has_down;
+    VResW mid1, mid2; Norm attn_norm; Lin attn_qkv, attn_proj;
+    Norm norm_out; Conv conv_out; Lin quant;
+};
+void vae_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const VaeCfg& cfg, VaeEnc* V);
+Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img /*[B,H,W,3]*/);   // -> [B,H/8,W/8,2*z]
+
+// ---------------------------------------------------------------- CLIP text transformer (modules.py:345-404 + HF 4.18 modeling_clip)
+struct ClipCfg { int vocab = 49408, width = 768, layers = 12, heads = 12, ctx_len = 77, mlp = 3072; };
+struct ClipLayerW { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
+struct Clip {
+    ClipCfg cfg;
+    float* tok_emb = nullptr; float* pos_emb = nullptr;
+    std::vector<ClipLayerW> layers;
+    Norm final_ln;
+};
+void clip_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const ClipCfg& cfg, Clip* C);
+// embedded: [B,L,width] token embeddings AFTER the manager hook (before position embedding)
+Ten* clip_encode(Graph& G, const Clip& C, Ten* embedded);
+
+// ---------------------------------------------------------------- face-recognition backbone (iresnet.py:67-181), frozen/eval
+struct IBlockW { float* bn1_s; float* bn1_b; Conv c1; float* prelu; Conv c2; bool has_ds = false; Conv ds; int stride = 1; };
+struct FrNet {
+    int layers[4] = {3, 13, 30, 3};
+    int width = 64;          // channels of layer1 (x1, x2, x4, x8)
+    int in_size = 112;
+    int feat = 512;
+    Conv conv1; float* prelu1 = nullptr;
+    std::vector<IBlockW> blocks;
+    float* bn2_s = nullptr; float* bn2_b = nullptr;
+    Lin fc;
+};
+void frnet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, FrNet* F, const int* layers, int width, int in_size);
+Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img /*[N,S,S,3]*/);   // -> [N,1,1,512] (not normalised)
+
+// ---------------------------------------------------------------- the training step
+struct TrainerCfg {
+    UNetCfg unet; VaeCfg vae; ClipCfg clip;
+    int fr_layers[4] = {3, 13, 30, 3}; int fr_width = 64; int fr_in = 112;
+    int image_size = 512;
+    int es = 2;                 // num_embeds_per_token
+    int inner_dim = 512;        // meta_inner_dim (number of basis vectors)
+    int max_ids = 10;
+    float momentum = 0.99f;
+    float scale_factor = 0.18215f;
+    float linear_start = 0.00085f, linear_end = 0.012f; int timesteps = 1000;
+    int64_t placeholder_token = 48136;   // 'sks' (modules.py:198-262)
+    float adam_b1 = 0.9f, adam_b2 = 0.999f, adam_eps = 1e-8f, weight_decay = 1e-2f;
+};
+struct Trainer {
+    Ctx* ctx = nullptr;
+    TrainerCfg cfg;
+    UNet unet; VaeEnc vae; Clip clip; FrNet fr;
+    float* basis = nullptr;                       // [es][1+inner][width]
+    float* W = nullptr; float* b = nullptr;       // EqualLinear(512 -> es*inner) — the only trainable tensors
+    float* mW = nullptr; float* vW = nullptr; float* mb = nullptr; float* vb = nullptr;
+    float* gW = nullptr; float* gb = nullptr;
+    int* step = nullptr;
+    float* id_emb = nullptr; float* id_coef = nullptr;   // [max_ids][es*width], [max_ids][es*inner]
+    float* sqrt_ac = nullptr; float* sqrt_1mac = nullptr;
+    float* loss = nullptr;                        // device scalar
+    size_t arena_need = 0; int arena_B = 0;
+};
+void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T);
+struct Batch {
+    const float* image = nullptr;     // [B,S,S,3] HWC in [-1,1]        (face_id.py:598-644 'image')
+    const float* faces = nullptr;     // [B,S,S,6]                      ('image_ori'['faces'])
+    const int64_t* ids = nullptr;     // [B,2]                          ('image_ori'['ids'])
+    const int64_t* tokens = nullptr;  // [B,77] CLIP BPE ids
+    const int64_t* t = nullptr;       // [B] diffusion timesteps
+    const float* noise = nullptr;     // [B,4,64,64] NCHW epsilon target
+    const float* post_noise = nullptr;// [B,4,64,64] NCHW VAE posterior noise
+    int B = 1;
+};
+void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only);
+
+}  // namespace cb

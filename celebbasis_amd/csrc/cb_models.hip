@@ -1,0 +1,499 @@
+// cb_models.hip — UNet / VAE encoder / CLIP text transformer / iresnet / CelebBasis head / training step,
+// expressed on the tape runtime. Weight names follow the reference state-dict keys.
+#include "cb_models.h"
+#include <cmath>
+
+namespace cb {
+
+static std::string S(const std::string& a, int i) { return a + std::to_string(i); }
+
+// ================================================================= UNet
+static ResBlockW load_resblock(Ctx* ctx, const WTab& wt, const std::string& p, int cin, int cout, int emb_dim) {
+    ResBlockW r; r.cin = cin; r.cout = cout;
+    r.n1 = load_norm(ctx, wt, p + ".in_layers.0", cin, 1e-5f);              // GroupNorm32, util.py:214-216
+    r.c1 = load_conv(ctx, wt, p + ".in_layers.2", cin, cout, 3, true);
+    r.emb = load_linear(ctx, wt, p + ".emb_layers.1", emb_dim, cout);
+    r.n2 = load_norm(ctx, wt, p + ".out_layers.0", cout, 1e-5f);
+    r.c2 = load_conv(ctx, wt, p + ".out_layers.3", cout, cout, 3, true);
+    if (cin != cout) { r.has_skip = true; r.skip = load_conv1x1_as_linear(ctx, wt, p + ".skip_connection", cin, cout); }
+    return r;
+}
+static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, int heads, int ctx_dim) {
+    XfmrW x; x.ch = ch; x.heads = heads;
+    x.norm = load_norm(ctx, wt, p + ".norm", ch, 1e-6f);                    // attention.py:76-77 Normalize eps 1e-6
+    x.proj_in = load_conv1x1_as_linear(ctx, wt, p + ".proj_in", ch, ch);
+    const std::string tb = p + ".transformer_blocks.0";
+    x.ln1 = load_norm(ctx, wt, tb + ".norm1", ch, 1e-5f);
+    x.ln2 = load_norm(ctx, wt, tb + ".norm2", ch, 1e-5f);
+    x.ln3 = load_norm(ctx, wt, tb + ".norm3", ch, 1e-5f);
+    x.qkv1 = load_linear_cat(ctx, wt, {tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"}, ch, ch, false);
+    x.out1 = load_linear(ctx, wt, tb + ".attn1.to_out.0", ch, ch);
+    x.q2 = load_linear(ctx, wt, tb + ".attn2.to_q", ch, ch, false);
+    x.kv2 = load_linear_cat(ctx, wt, {tb + ".attn2.to_k", tb + ".attn2.to_v"}, ctx_dim, ch, false);
+    x.out2 = load_linear(ctx, wt, tb + ".attn2.to_out.0", ch, ch);
+    x.ff1 = load_linear(ctx, wt, tb + ".ff.net.0.proj", ch, 8 * ch);
+    x.ff2 = load_linear(ctx, wt, tb + ".ff.net.2", 4 * ch, ch);
+    x.proj_out = load_conv1x1_as_linear(ctx, wt, p + ".proj_out", ch, ch);
+    return x;
+}
+
+void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& cfg, UNet* U) {
+    U->cfg = cfg;
+    const int mc = cfg.model_channels, ted = 4 * mc;
+    auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };
+    U->te0 = load_linear(ctx, wt, pre + "time_embed.0", mc, ted);
+    U->te2 = load_linear(ctx, wt, pre + "time_embed.2", ted, ted);
+    U->conv_in = load_conv(ctx, wt, pre + "input_blocks.0.0", cfg.in_channels, mc, 3, false);
+    std::vector<int> chans{mc};
+    int ch = mc, ds = 1, idx = 1;
+    for (int level = 0; level < cfg.n_mult; ++level) {
+        int mult = cfg.channel_mult[level];
+        for (int r = 0; r < cfg.num_res_blocks; ++r) {
+            UBlock b;
+            b.has_res = true;
+            b.res = load_resblock(ctx, wt, pre + S("input_blocks.", idx) + ".0", ch, mult * mc, ted);
+            ch = mult * mc;
+            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, pre + S("input_blocks.", idx) + ".1", ch, cfg.num_heads, cfg.context_dim); }
+            U->in_blocks.push_back(b);
+            chans.push_back(ch); ++idx;
+        }
+        if (level != cfg.n_mult - 1) {
+            UBlock b;
+            b.has_down = true;
+            b.down = load_conv(ctx, wt, pre + S("input_blocks.", idx) + ".0.op", ch, ch, 3, true);
+            U->in_blocks.push_back(b);
+            chans.push_back(ch); ds *= 2; ++idx;
+        }
+    }
+    U->mid1 = load_resblock(ctx, wt, pre + "middle_block.0", ch, ch, ted);
+    U->midx = load_xfmr(ctx, wt, pre + "middle_block.1", ch, cfg.num_heads, cfg.context_dim);
+    U->mid2 = load_resblock(ctx, wt, pre + "middle_block.2", ch, ch, ted);
+    int oidx = 0;
+    for (int level = cfg.n_mult - 1; level >= 0; --level) {
+        int mult = cfg.channel_mult[level];
+        for (int i = 0; i <= cfg.num_res_blocks; ++i) {
+            int ich = chans.back(); chans.pop_back();
+            UBlock b;
+            const std::string bp = pre + S("output_blocks.", oidx);
+            b.has_res = true;
+            b.res = load_resblock(ctx, wt, bp + ".0", ch + ich, mc * mult, ted);
+            ch = mc * mult;
+            int sub = 1;
+            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, bp + ".1", ch, cfg.num_heads, cfg.context_dim); sub = 2; }
+            if (level && i == cfg.num_res_blocks) {
+                b.has_up = true;
+                b.up = load_conv(ctx, wt, bp + "." + std::to_string(sub) + ".conv", ch, ch, 3, true);
+                ds /= 2;
+            }
+            U->out_blocks.push_back(b);
+            ++oidx;
+        }
+    }
+    U->out_norm = load_norm(ctx, wt, pre + "out.0", ch, 1e-5f);
+    U->out_conv = load_conv(ctx, wt, pre + "out.2", mc, cfg.out_channels, 3, true);
+}
+
+// openaimodel.py:255-275 ResBlock._forward (use_scale_shift_norm=False, no up/down, dropout 0)
+static Ten* resblock(Graph& G, const ResBlockW& r, Ten* x, Ten* semb) {
+    Ten* h = G.groupnorm(x, r.n1, true);
+    Ten* embo = G.linear(semb, r.emb);                 // emb_layers = SiLU -> Linear; SiLU(emb) is shared (semb)
+    h = G.conv(h, r.c1, CONV_SAME, embo);              // h + emb_out[..., None, None] fused as a per-image row bias
+    h = G.groupnorm(h, r.n2, true);
+    Ten* skip = r.has_skip ? G.linear(x, r.skip) : x;
+    return G.conv(h, r.c2, CONV_SAME, nullptr, skip);  // skip_connection(x) + h fused as a residual epilogue
+}
+// attention.py:250-261 SpatialTransformer + 211-215 BasicTransformerBlock
+static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* context) {
+    const int ch = w.ch, d = ch / w.heads;
+    const float scale = 1.f / sqrtf((float)d);
+    Ten* h = G.groupnorm(x, w.norm, false);
+    h = G.linear(h, w.proj_in);
+    Ten* n1 = G.layernorm(h, w.ln1);
+    Ten* qkv = G.linear(n1, w.qkv1);
+    Ten* a = G.attention(qkv, 0, qkv, ch, 2 * ch, ch, w.heads, scale, false);
+    h = G.linear(a, w.out1, h);
+    Ten* n2 = G.layernorm(h, w.ln2);
+    Ten* q = G.linear(n2, w.q2);
+    Ten* kv = G.linear(context, w.kv2);
+    a = G.attention(q, 0, kv, 0, ch, ch, w.heads, scale, false);
+    h = G.linear(a, w.out2, h);
+    Ten* n3 = G.layernorm(h, w.ln3);
+    Ten* f = G.linear(n3, w.ff1);
+    Ten* g = G.geglu(f);
+    h = G.linear(g, w.ff2, h);
+    return G.linear(h, w.proj_out, x);
+}
+
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context) {
+    const int B = x->n, mc = U.cfg.model_channels;
+    CB_CHECK(x->c == U.cfg.in_channels, CB_ERR_SHAPE, "unet: input channels %d vs %d", x->c, U.cfg.in_channels);
+    CB_CHECK(context->c == U.cfg.context_dim && context->n == B, CB_ERR_SHAPE, "unet: context shape");
+    Ten* temb = G.make(B, 1, 1, mc);
+    k_timestep_embedding(G.L, temb->p, t_dev, B, mc);
+    Ten* e = G.linear(temb, U.te0);
+    e = G.silu(e);
+    Ten* emb = G.linear(e, U.te2);
+    Ten* semb = G.silu(emb);
+    std::vector<Ten*> hs;
+    Ten* h = G.conv(x, U.conv_in, CONV_SAME);
+    hs.push_back(h);
+    int bi = 1;
+    for (const UBlock& b : U.in_blocks) {
+        if (b.has_res) h = resblock(G, b.res, h, semb);
+        if (b.has_xf) h = xfmr(G, b.xf, h, context);
+        if (b.has_down) h = G.conv(h, b.down, CONV_DOWN);
+        hs.push_back(h);
+        G.tap("unet.input_blocks." + std::to_string(bi++), h);
+    }
+    h = resblock(G, U.mid1, h, semb);
+    h = xfmr(G, U.midx, h, context);
+    h = resblock(G, U.mid2, h, semb);
+    G.tap("unet.middle_block", h);
+    bi = 0;
+    for (const UBlock& b : U.out_blocks) {
+        Ten* skip = hs.back(); hs.pop_back();
+        h = G.concat(h, skip);
+        h = resblock(G, b.res, h, semb);
+        if (b.has_xf) h = xfmr(G, b.xf, h, context);
+        if (b.has_up) h = G.conv(h, b.up, CONV_UP);
+        G.tap("unet.output_blocks." + std::to_string(bi++), h);
+    }
+    h = G.groupnorm(h, U.out_norm, true);
+    h = G.conv(h, U.out_conv, CONV_SAME);
+    G.tap("unet.out", h);
+    return h;
+}
+
+// ================================================================= VAE encoder
+static VResW load_vres(Ctx* ctx, const WTab& wt, const std::string& p, int cin, int cout) {
+    VResW r;
+    r.n1 = load_norm(ctx, wt, p + ".norm1", cin, 1e-6f);
+    r.c1 = load_conv(ctx, wt, p + ".conv1", cin, cout, 3, false);
+    r.n2 = load_norm(ctx, wt, p + ".norm2", cout, 1e-6f);
+    r.c2 = load_conv(ctx, wt, p + ".conv2", cout, cout, 3, false);
+    if (cin != cout) { r.has_nin = true; r.nin = load_conv1x1_as_linear(ctx, wt, p + ".nin_shortcut", cin, cout); }
+    return r;
+}
+void vae_load(Ctx* ctx, const WTab& wt, const std::string& pre, const VaeCfg& cfg, VaeEnc* V) {
+    V->cfg = cfg;
+    const std::string e = pre + "encoder.";
+    V->conv_in = load_conv(ctx, wt, e + "conv_in", cfg.in_channels, cfg.ch, 3, false);
+    int block_in = cfg.ch;
+    for (int l = 0; l < cfg.n_mult; ++l) {
+        int block_out = cfg.ch * cfg.ch_mult[l];
+        std::vector<VResW> blocks;
+        for (int b = 0; b < cfg.num_res_blocks; ++b) {
+            blocks.push_back(load_vres(ctx, wt, e + S("down.", l) + S(".block.", b), block_in, block_out));
+            block_in = block_out;
+        }
+        V->down.push_back(blocks);
+        bool hd = l != cfg.n_mult - 1;
+        V->has_down.push_back(hd);
+        V->downsample.push_back(hd ? load_conv(ctx, wt, e + S("down.", l) + ".downsample.conv", block_in, block_in, 3, false) : Conv());
+    }
+    V->mid1 = load_vres(ctx, wt, e + "mid.block_1", block_in, block_in);
+    V->attn_norm = load_norm(ctx, wt, e + "mid.attn_1.norm", block_in, 1e-6f);
+    V->attn_qkv = load_linear_cat(ctx, wt, {e + "mid.attn_1.q", e + "mid.attn_1.k", e + "mid.attn_1.v"}, block_in, block_in, true, true);
+    V->attn_proj = load_conv1x1_as_linear(ctx, wt, e + "mid.attn_1.proj_out", block_in, block_in);
+    V->mid2 = load_vres(ctx, wt, e + "mid.block_2", block_in, block_in);
+    V->norm_out = load_norm(ctx, wt, e + "norm_out", block_in, 1e-6f);
+    V->conv_out = load_conv(ctx, wt, e + "conv_out", block_in, 2 * cfg.z_channels, 3, false);
+    V->quant = load_conv1x1_as_linear(ctx, wt, pre + "quant_conv", 2 * cfg.z_channels, 2 * cfg.z_channels);
+}
+static Ten* vres(Graph& G, const VResW& r, Ten* x) {   // model.py:121-141, temb is None
+    Ten* h = G.groupnorm(x, r.n1, true);
+    h = G.conv(h, r.c1, CONV_SAME);
+    h = G.groupnorm(h, r.n2, true);
+    Ten* skip = r.has_nin ? G.linear(x, r.nin) : x;
+    return G.conv(h, r.c2, CONV_SAME, nullptr, skip);
+}
+Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img) {
+    Ten* h = G.conv(img, V.conv_in, CONV_SAME);
+    for (size_t l = 0; l < V.down.size(); ++l) {
+        for (const VResW& r : V.down[l]) h = vres(G, r, h);
+        if (V.has_down[l]) h = G.conv(h, V.downsample[l], CONV_DOWN_ASYM);   // pad (0,1,0,1) + stride 2, model.py:74-76
+        G.tap("vae.down." + std::to_string(l), h);
+    }
+    h = vres(G, V.mid1, h);
+    {   // AttnBlock model.py:176-202: single head, scale C^-0.5
+        const int C = h->c;
+        Ten* n = G.groupnorm(h, V.attn_norm, false);
+        Ten* qkv = G.linear(n, V.attn_qkv);
+        Ten* a = G.attention(qkv, 0, qkv, C, 2 * C, C, 1, 1.f / sqrtf((float)C), false);
+        h = G.linear(a, V.attn_proj, h);
+    }
+    h = vres(G, V.mid2, h);
+    G.tap("vae.mid", h);
+    h = G.groupnorm(h, V.norm_out, true);
+    h = G.conv(h, V.conv_out, CONV_SAME);
+    h = G.linear(h, V.quant);
+    G.tap("vae.moments", h);
+    return h;
+}
+
+// ================================================================= CLIP text transformer
+void clip_load(Ctx* ctx, const WTab& wt, const std::string& pre, const ClipCfg& cfg, Clip* C) {
+    C->cfg = cfg;
+    const int w = cfg.width;
+    C->tok_emb = ctx->upload(wt, pre + "embeddings.token_embedding.weight", {cfg.vocab, w});
+    C->pos_emb = ctx->upload(wt, pre + "embeddings.position_embedding.weight", {cfg.ctx_len, w});
+    for (int i = 0; i < cfg.layers; ++i) {
+        const std::string p = pre + S("encoder.layers.", i);
+        ClipLayerW l;
+        l.ln1 = load_norm(ctx, wt, p + ".layer_norm1", w, 1e-5f);
+        l.ln2 = load_norm(ctx, wt, p + ".layer_norm2", w, 1e-5f);
+        l.qkv = load_linear_cat(ctx, wt, {p + ".self_attn.q_proj", p + ".self_attn.k_proj", p + ".self_attn.v_proj"}, w, w, true);
+        l.out = load_linear(ctx, wt, p + ".self_attn.out_proj", w, w);
+        l.fc1 = load_linear(ctx, wt, p + ".mlp.fc1", w, cfg.mlp);
+        l.fc2 = load_linear(ctx, wt, p + ".mlp.fc2", cfg.mlp, w);
+        C->layers.push_back(l);
+    }
+    C->final_ln = load_norm(ctx, wt, pre + "final_layer_norm", w, 1e-5f);
+}
+Ten* clip_encode(Graph& G, const Clip& C, Ten* embedded) {
+    const int w = C.cfg.width, L = embedded->h * embedded->w;
+    CB_CHECK(embedded->c == w && L <= C.cfg.ctx_len, CB_ERR_SHAPE, "clip: embedded shape");
+    // embeddings = inputs_embeds + position_embedding (modules.py:295-296)
+    Ten* x = G.make(embedded->n, embedded->h, embedded->w, w, embedded->rg);
+    k_add_rowbcast(G.L, x->p, embedded->p, C.pos_emb, embedded->rows(), L, w);
+    if (embedded->rg) {
+        Graph* g = &G;
+        G.tape.push_back([g, x, embedded]() {
+            if (!x->ginit) return;
+            float beta; float* ge = g->grad(embedded, &beta);
+            k_axpby(g->L, ge, x->g, x->numel(), 1.f, beta);
+        });
+    }
+    const float scale = 1.f / sqrtf((float)(w / C.cfg.heads));
+    for (const ClipLayerW& l : C.layers) {       // HF CLIPEncoderLayer: pre-LN, causal self-attention, quick-GELU MLP
+        Ten* h = G.layernorm(x, l.ln1);
+        Ten* qkv = G.linear(h, l.qkv);
+        Ten* a = G.attention(qkv, 0, qkv, w, 2 * w, w, C.cfg.heads, scale, true);
+        x = G.linear(a, l.out, x);
+        h = G.layernorm(x, l.ln2);
+        h = G.linear(h, l.fc1);
+        h = G.quickgelu(h);
+        x = G.linear(h, l.fc2, x);
+    }
+    x = G.layernorm(x, C.final_ln);
+    G.tap("clip.last_hidden_state", x);
+    return x;
+}
+
+// ================================================================= iresnet (frozen, eval)
+static void bn_affine(Ctx* ctx, const WTab& wt, const std::string& p, int c, float** s, float** b) {
+    float* w = ctx->upload(wt, p + ".weight", {c});
+    float* bb = ctx->upload(wt, p + ".bias", {c});
+    float* m = ctx->upload(wt, p + ".running_mean", {c});
+    float* v = ctx->upload(wt, p + ".running_var", {c});
+    *s = ctx->pool.allocf(c); *b = ctx->pool.allocf(c);
+    k_bn_to_affine(ctx->launch(), *s, *b, w, bb, m, v, 1e-5f, c);
+}
+// conv (no bias) followed by an eval BatchNorm: fold the BN into the packed weights + a bias
+static Conv load_conv_bn(Ctx* ctx, const WTab& wt, const std::string& conv, const std::string& bn, int cin, int cout, int ks) {
+    Conv c = load_conv(ctx, wt, conv, cin, cout, ks, false, false);
+    float* w = ctx->upload(wt, bn + ".weight", {cout});
+    float* bb = ctx->upload(wt, bn + ".bias", {cout});
+    float* m = ctx->upload(wt, bn + ".running_mean", {cout});
+    float* v = ctx->upload(wt, bn + ".running_var", {cout});
+    c.b = ctx->pool.allocf(cout);
+    k_fold_bn(ctx->launch(), c.w, c.b, w, bb, m, v, 1e-5f, cout, (long)ks * ks * cin);
+    return c;
+}
+void frnet_load(Ctx* ctx, const WTab& wt, const std::string& pre, FrNet* F, const int* layers, int width, int in_size) {
+    for (int i = 0; i < 4; ++i) F->layers[i] = layers[i];
+    F->width = width; F->in_size = in_size;
+    F->conv1 = load_conv_bn(ctx, wt, pre + "conv1", pre + "bn1", 3, width, 3);
+    F->prelu1 = ctx->upload(wt, pre + "prelu.weight", {width});
+    int inpl = width;
+    for (int l = 0; l < 4; ++l) {
+        int planes = width << l;
+        for (int i = 0; i < layers[l]; ++i) {
+            const std::string p = pre + S("layer", l + 1) + S(".", i);
+            IBlockW b;
+            b.stride = (i == 0) ? 2 : 1;
+            bn_affine(ctx, wt, p + ".bn1", inpl, &b.bn1_s, &b.bn1_b);
+            b.c1 = load_conv_bn(ctx, wt, p + ".conv1", p + ".bn2", inpl, planes, 3);
+            b.prelu = ctx->upload(wt, p + ".prelu.weight", {planes});
+            b.c2 = load_conv_bn(ctx, wt, p + ".conv2", p + ".bn3", planes, planes, 3);
+            if (i == 0) { b.has_ds = true; b.ds = load_conv_bn(ctx, wt, p + ".downsample.0", p + ".downsample.1", inpl, planes, 1); }
+            F->blocks.push_back(b);
+            inpl = planes;
+        }
+    }
+    const int C = width * 8;
+    bn_affine(ctx, wt, pre + "bn2", C, &F->bn2_s, &F->bn2_b);
+    int fs = in_size / 16;   // four stride-2 stages
+    const int HW = fs * fs;
+    F->feat = (int)wt.get(pre + "fc.weight").dims[0];
+    float* fcw = ctx->upload(wt, pre + "fc.weight", {F->feat, (int64_t)C * HW});
+    float* fcb = ctx->upload(wt, pre + "fc.bias", {F->feat});
+    F->fc.in = C * HW; F->fc.out = F->feat;
+    F->fc.w = ctx->pool.allocf((size_t)F->feat * C * HW);
+    k_pack_fc_nhwc(ctx->launch(), F->fc.w, fcw, F->feat, C, HW);
+    // features = BatchNorm1d after fc (iresnet.py:180): y = (W x + b) * s + t
+    float *fs_, *ft_;
+    bn_affine(ctx, wt, pre + "features", F->feat, &fs_, &ft_);
+    float* dummy = ctx->pool.allocf(F->feat);
+    {   // scale rows of W by s (fold_bn with mean=0,var=1-eps would be clumsy: reuse channel math directly)
+        float* w = ctx->upload(wt, pre + "features.weight", {F->feat});
+        float* bb = ctx->upload(wt, pre + "features.bias", {F->feat});
+        float* m = ctx->upload(wt, pre + "features.running_mean", {F->feat});
+        float* v = ctx->upload(wt, pre + "features.running_var", {F->feat});
+        k_fold_bn(ctx->launch(), F->fc.w, dummy, w, bb, m, v, 1e-5f, F->feat, (long)C * HW);
+    }
+    F->fc.b = ctx->pool.allocf(F->feat);
+    k_channel_affine(ctx->launch(), F->fc.b, fcb, fs_, ft_, nullptr, 1, F->feat);   // b*s + t
+}
+Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
+    Ten* x = G.conv(img, F.conv1, CONV_SAME);
+    x = G.channel_affine(x, nullptr, nullptr, F.prelu1);
+    for (const IBlockW& b : F.blocks) {      // iresnet.py:52-63 IBasicBlock
+        Ten* o = G.channel_affine(x, b.bn1_s, b.bn1_b, nullptr);
+        o = G.conv(o, b.c1, CONV_SAME);
+        o = G.channel_affine(o, nullptr, nullptr, b.prelu);
+        Ten* idn = b.has_ds ? G.conv(x, b.ds, CONV_S2_1x1) : x;
+        x = G.conv(o, b.c2, b.stride == 2 ? CONV_DOWN : CONV_SAME, nullptr, idn);
+    }
+    x = G.channel_affine(x, F.bn2_s, F.bn2_b, nullptr);
+    Ten* flat = G.wrap(x->p, x->n, 1, 1, x->h * x->w * x->c);
+    Ten* f = G.linear(flat, F.fc);
+    G.tap("frnet.features", f);
+    return f;
+}
+
+// ================================================================= training step
+void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
+    T->ctx = ctx; T->cfg = cfg;
+    unet_load(ctx, wt, "model.diffusion_model.", cfg.unet, &T->unet);
+    vae_load(ctx, wt, "first_stage_model.", cfg.vae, &T->vae);
+    clip_load(ctx, wt, "cond_stage_model.transformer.text_model.", cfg.clip, &T->clip);
+    frnet_load(ctx, wt, "embedding_manager.meta_id_net.id_model.", &T->fr, cfg.fr_layers, cfg.fr_width, cfg.fr_in);
+    const int w = cfg.clip.width, O = cfg.es * cfg.inner_dim, I = T->fr.feat;
+    T->basis = ctx->upload(wt, "celeb_embeddings", {cfg.es, 1 + cfg.inner_dim, w});
+    T->W = ctx->upload(wt, "embedding_manager.meta_id_net.stylegan_mlp.net.0.weight", {O, I});
+    T->b = ctx->upload(wt, "embedding_manager.meta_id_net.stylegan_mlp.net.0.bias", {O});
+    Launch L = ctx->launch();
+    auto zeros = [&](size_t n) { float* p = ctx->pool.allocf(n); k_fill(L, p, (long)n, 0.f); return p; };
+    T->mW = zeros((size_t)O * I); T->vW = zeros((size_t)O * I); T->gW = zeros((size_t)O * I);
+    T->mb = zeros(O); T->vb = zeros(O); T->gb = zeros(O);
+    T->step = reinterpret_cast<int*>(zeros(64));
+    T->id_emb = wt.has("id_embeddings") ? ctx->upload(wt, "id_embeddings", {cfg.max_ids, cfg.es * w}) : zeros((size_t)cfg.max_ids * cfg.es * w);
+    T->id_coef = wt.has("id_coefficients") ? ctx->upload(wt, "id_coefficients", {cfg.max_ids, cfg.es * cfg.inner_dim})
+                                           : zeros((size_t)cfg.max_ids * cfg.es * cfg.inner_dim);
+    T->loss = zeros(64);
+    // ddpm.py:126-178 register_schedule with util.py:21-25 "linear" (sqrt-space linspace), float64 -> float32
+    std::vector<float> sa(cfg.timesteps), sb(cfg.timesteps);
+    double s0 = std::sqrt((double)cfg.linear_start), s1 = std::sqrt((double)cfg.linear_end), ac = 1.0;
+    for (int i = 0; i < cfg.timesteps; ++i) {
+        double r = cfg.timesteps > 1 ? s0 + (s1 - s0) * (double)i / (double)(cfg.timesteps - 1) : s0;
+        double beta = r * r;
+        ac *= (1.0 - beta);
+        sa[i] = (float)std::sqrt(ac);
+        sb[i] = (float)std::sqrt(1.0 - ac);
+    }
+    T->sqrt_ac = ctx->pool.allocf(cfg.timesteps); T->sqrt_1mac = ctx->pool.allocf(cfg.timesteps);
+    if (!ctx->dry) {
+        CB_HIP(hipMemcpy(T->sqrt_ac, sa.data(), sa.size() * sizeof(float), hipMemcpyHostToDevice));
+        CB_HIP(hipMemcpy(T->sqrt_1mac, sb.data(), sb.size() * sizeof(float), hipMemcpyHostToDevice));
+    }
+}
+
+static const float kTheta[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f,     // meta_net.py:131-142 trans_matrix
+                                0.03625215f, 1.07695457f, -5.32134629f / 512.f};
+
+static void step_impl(Trainer* T, const Batch& bt, float lr) {
+    Ctx* ctx = T->ctx;
+    const TrainerCfg& c = T->cfg;
+    Graph G(ctx);
+    const Launch& L = G.L;
+    const int B = bt.B, S_ = c.image_size, w = c.clip.width, es = c.es, K = c.inner_dim, T77 = c.clip.ctx_len;
+    const int zc = c.vae.z_channels;
+
+    // (1) first stage: VAE encode -> posterior sample * scale_factor   (ddpm.py:702-759, 590-597) — no grad
+    Ten* img = G.wrap(const_cast<float*>(bt.image), B, S_, S_, c.vae.in_channels);
+    Ten* mom = vae_encode_moments(G, T->vae, img);
+    Ten* z0 = G.make(B, mom->h, mom->w, zc);
+    k_vae_sample(L, z0->p, mom->p, bt.post_noise, B, mom->h * mom->w, zc, c.scale_factor);
+    G.tap("z0", z0);
+
+    // (2) identity branch: warp + resize + iresnet (no grad) -> MLP -> L2-norm -> basis   (meta_net.py:250-289)
+    const int NF = 2 * B;
+    Ten* warped = G.make(NF, S_, S_, 3);
+    k_affine_warp(L, warped->p, bt.faces, B, S_, 2, kTheta);
+    Ten* small = G.make(NF, c.fr_in, c.fr_in, 3);
+    k_resize_bilinear_ac(L, small->p, warped->p, NF, S_, S_, c.fr_in, c.fr_in, 3);
+    Ten* feat = frnet_forward(G, T->fr, small);
+    const int I = T->fr.feat, O = es * K;
+    Ten* v = G.make(NF, 1, 1, I);
+    k_l2norm_fwd(L, v->p, nullptr, feat->p, NF, I);
+    Lin head; head.w = T->W; head.b = T->b; head.in = I; head.out = O;
+    Ten* pre = G.linear(v, head);                         // EqualLinear with lr_mul = 1 (meta_net.py:41-48)
+    Ten* act = G.make(NF, 1, 1, O);
+    k_leakyrelu_fwd(L, act->p, pre->p, act->numel(), 0.2f);
+    Ten* xn = G.make(NF * es, 1, 1, K);                   // 'b (e h d) -> b e h d', h = 1
+    float* cn = ctx->arena.allocf((size_t)NF * es);
+    k_l2norm_fwd(L, xn->p, cn, act->p, (long)NF * es, K);
+    Ten* zz = G.make(NF, es, 1, w);
+    k_basis_fwd(L, zz->p, xn->p, T->basis, NF, es, K, w);
+    G.tap("coef", xn); G.tap("zz", zz);
+    // momentum dictionaries (embedding_manager.py:484-489) use the first face chunk (meta1 / cef1)
+    k_ema_update(L, T->id_emb, T->id_coef, zz->p, xn->p, bt.ids, 2, B, es * w, es * K, c.max_ids, c.momentum);
+
+    // (3) conditioning: token embedding -> manager hook (row surgery) -> CLIP   (modules.py:176-298, 345-404)
+    Ten* emb0 = G.make(B, T77, 1, w);
+    k_gather_rows(L, emb0->p, T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
+    Ten* emb1 = G.make(B, T77, 1, w, true);
+    int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
+    k_row_surgery_fwd(L, emb1->p, emb0->p, zz->p, bt.tokens, map, B, T77, w, es, c.placeholder_token);
+    Ten* cond = clip_encode(G, T->clip, emb1);
+
+    // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
+    Ten* xt = G.make(B, z0->h, z0->w, zc);
+    k_qsample(L, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
+    Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond);
+    float beta;
+    float* deps = G.grad(eps_hat, &beta);
+    k_mse_loss(L, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);
+
+    // (7) backward: UNet dgrad -> context -> CLIP dgrad -> rows p, p+1 -> basis^T -> norm -> LeakyReLU -> dW, db
+    G.backward();
+    CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");
+    if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());
+    float* dzz = ctx->arena.allocf((size_t)NF * es * w);
+    k_fill(L, dzz, (long)NF * es * w, 0.f);
+    k_row_surgery_bwd(L, dzz, emb1->g, map, B, T77, w, es);          // fills the first B samples
+    float* dxn = ctx->arena.allocf((size_t)NF * es * K);
+    k_basis_bwd(L, dxn, dzz, T->basis, NF, es, K, w);
+    float* dact = ctx->arena.allocf((size_t)NF * O);
+    k_l2norm_bwd(L, dact, xn->p, cn, dxn, (long)NF * es, K);
+    float* dpre = ctx->arena.allocf((size_t)NF * O);
+    k_leakyrelu_bwd(L, dpre, pre->p, dact, (long)NF * O, 0.2f);
+    k_outer_grad(L, T->gW, T->gb, dpre, v->p, NF, O, I);
+
+    // (8) AdamW on the 525 312 trainable floats (ddpm.py:1442-1454)
+    k_step_inc(L, T->step);
+    k_adamw(L, T->W, T->mW, T->vW, T->gW, (long)O * I, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
+    k_adamw(L, T->b, T->mb, T->vb, T->gb, (long)O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
+}
+
+void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only) {
+    Ctx* ctx = T->ctx;
+    CB_CHECK(bt.B >= 1 && bt.B <= 4, CB_ERR_ARG, "trainer: batch %d unsupported (1..4)", bt.B);
+    if (ctx->dry || dry_only || T->arena_B != bt.B) {
+        bool was_dry = ctx->dry;
+        Stats saved = ctx->stats;
+        ctx->dry = true; ctx->arena.dry = true; ctx->arena.reset(); ctx->arena.peak = 0;
+        try { step_impl(T, bt, lr); } catch (...) { ctx->dry = was_dry; ctx->arena.dry = was_dry; throw; }
+        T->arena_need = ctx->arena.peak;
+        ctx->dry = was_dry; ctx->arena.dry = was_dry;
+        if (was_dry || dry_only) return;       // keep the accounting of the dry pass
+        ctx->stats = saved;
+        ctx->ensure_arena(T->arena_need);
+        T->arena_B = bt.B;
+    }
+    ctx->arena.reset();
+    step_impl(T, bt, lr);
+}
+
+}  // namespace cb

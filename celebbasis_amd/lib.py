@@ -1,0 +1,423 @@
+"""ctypes binding of libcelebbasis_hip.so (include/celebbasis_hip.h).
+
+PyTorch is plumbing here: it owns the device buffers and the stream that are handed to the C ABI as raw
+pointers. The product path has NO fallback: if the shared library is missing or the device is not gfx950 the
+calls raise.
+"""
+import ctypes as C
+import os
+
+import torch  # imported BEFORE the .so so that the process holds a single HIP runtime (torch's libamdhip64.so.7)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcelebbasis_hip.so")
+_lib = None
+
+
+class CBError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libcelebbasis_hip error {code}: {msg}")
+        self.code = code
+
+
+# ---------------------------------------------------------------- C structs (mirror include/celebbasis_hip.h)
+class GemmDesc(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+                ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
+                ("a_layout", C.c_int), ("b_layout", C.c_int), ("batch", C.c_int),
+                ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
+                ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64), ("strideR", C.c_int64),
+                ("alpha", C.c_float), ("beta", C.c_float)]
+
+
+class AttentionDesc(C.Structure):
+    _fields_ = [("qbuf", C.c_void_p), ("ldq", C.c_int64), ("q_off", C.c_int),
+                ("kvbuf", C.c_void_p), ("ldkv", C.c_int64), ("k_off", C.c_int), ("v_off", C.c_int),
+                ("B", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("C", C.c_int), ("heads", C.c_int),
+                ("scale", C.c_float), ("causal", C.c_int),
+                ("out", C.c_void_p), ("dout", C.c_void_p), ("dqbuf", C.c_void_p), ("dkvbuf", C.c_void_p)]
+
+
+class UNetCfg(C.Structure):
+    _fields_ = [("in_channels", C.c_int), ("out_channels", C.c_int), ("model_channels", C.c_int), ("num_res_blocks", C.c_int),
+                ("channel_mult", C.c_int * 8), ("n_mult", C.c_int),
+                ("attention_resolutions", C.c_int * 8), ("n_attn", C.c_int),
+                ("num_heads", C.c_int), ("context_dim", C.c_int)]
+
+
+class VaeCfg(C.Structure):
+    _fields_ = [("ch", C.c_int), ("ch_mult", C.c_int * 8), ("n_mult", C.c_int), ("num_res_blocks", C.c_int),
+                ("in_channels", C.c_int), ("z_channels", C.c_int)]
+
+
+class ClipCfg(C.Structure):
+    _fields_ = [("vocab", C.c_int), ("width", C.c_int), ("layers", C.c_int), ("heads", C.c_int), ("ctx_len", C.c_int),
+                ("mlp", C.c_int)]
+
+
+class TrainerCfg(C.Structure):
+    _fields_ = [("unet", UNetCfg), ("vae", VaeCfg), ("clip", ClipCfg),
+                ("fr_layers", C.c_int * 4), ("fr_width", C.c_int), ("fr_in", C.c_int),
+                ("image_size", C.c_int), ("es", C.c_int), ("inner_dim", C.c_int), ("max_ids", C.c_int),
+                ("momentum", C.c_float), ("scale_factor", C.c_float), ("linear_start", C.c_float), ("linear_end", C.c_float),
+                ("timesteps", C.c_int), ("placeholder_token", C.c_int64),
+                ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("weight_decay", C.c_float)]
+
+
+class Batch(C.Structure):
+    _fields_ = [("image", C.c_void_p), ("faces", C.c_void_p), ("ids", C.c_void_p), ("tokens", C.c_void_p), ("t", C.c_void_p),
+                ("noise", C.c_void_p), ("post_noise", C.c_void_p), ("B", C.c_int)]
+
+
+# every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
+ABI_SYMBOLS = [
+    "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
+    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
+    "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
+    "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
+    "cb_q_sample", "cb_mse_loss", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
+    "cb_nhwc_to_nchw", "cb_unet_create", "cb_unet_destroy", "cb_unet_forward", "cb_unet_backward_context", "cb_vae_create",
+    "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
+    "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
+    "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
+]
+
+
+_P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
+_ARGTYPES = {
+    "cb_last_error": [], "cb_version": [],
+    "cb_ctx_create": [_I, _P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
+    "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
+    "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
+    "cb_gemm": [_P, _P], "cb_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _I],
+    "cb_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
+    "cb_conv2d_dgrad": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F],
+    "cb_groupnorm_silu_fwd": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _F, _I],
+    "cb_groupnorm_silu_bwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F],
+    "cb_layernorm_fwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "cb_layernorm_bwd": [_P, _P, _P, _P, _P, _P, _L, _I, _F],
+    "cb_geglu_fwd": [_P, _P, _P, _L, _I], "cb_geglu_bwd": [_P, _P, _P, _P, _L, _I],
+    "cb_attention": [_P, _P],
+    "cb_timestep_embedding": [_P, _P, _P, _I, _I],
+    "cb_q_sample": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
+    "cb_mse_loss": [_P, _P, _P, _P, _P, _I, _I, _I],
+    "cb_face_warp_resize": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "cb_row_surgery": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L],
+    "cb_adamw_step": [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F],
+    "cb_nchw_to_nhwc": [_P, _P, _P, _I, _I, _I, _I], "cb_nhwc_to_nchw": [_P, _P, _P, _I, _I, _I, _I],
+    "cb_unet_create": [_P, _P, C.c_char_p, _P, _P], "cb_unet_destroy": [_P],
+    "cb_unet_forward": [_P, _P, _P, _P, _I, _I, _I, _I, _P, _I], "cb_unet_backward_context": [_P, _P, _P],
+    "cb_vae_create": [_P, _P, C.c_char_p, _P, _P], "cb_vae_destroy": [_P],
+    "cb_vae_encode": [_P, _P, _P, _I, _I, _I, _F, _P, _P],
+    "cb_clip_create": [_P, _P, C.c_char_p, _P, _P], "cb_clip_destroy": [_P],
+    "cb_clip_embed_tokens": [_P, _P, _I, _I, _P], "cb_clip_forward": [_P, _P, _I, _I, _P, _I],
+    "cb_clip_backward_embeds": [_P, _P, _P],
+    "cb_frnet_create": [_P, _P, C.c_char_p, _P, _I, _I, _P], "cb_frnet_destroy": [_P], "cb_frnet_forward": [_P, _P, _I, _P],
+    "cb_trainer_cfg_default": [_P], "cb_trainer_create": [_P, _P, _P, _P], "cb_trainer_destroy": [_P],
+    "cb_trainer_step": [_P, _P, _F], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
+    "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
+}
+
+
+def load():
+    """dlopen the in-tree library. Raises if it has not been built (python -m celebbasis_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `python -m celebbasis_amd.build` "
+                           "(there is no CPU or PyTorch fallback for the CelebBasis hot path)")
+    lib = C.CDLL(LIB_PATH)
+    lib.cb_last_error.restype = C.c_char_p
+    for name in ABI_SYMBOLS:
+        fn = getattr(lib, name)
+        if name != "cb_last_error":
+            fn.restype = C.c_int
+        if name in _ARGTYPES:
+            fn.argtypes = _ARGTYPES[name]
+    _lib = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise CBError(code, load().cb_last_error().decode("utf-8", "replace"))
+
+
+def ptr(t, dtype=torch.float32):
+    """raw pointer of a contiguous tensor (or None)"""
+    if t is None:
+        return None
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("expected a torch.Tensor")
+    if t.dtype != dtype:
+        raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise ValueError("tensor must be contiguous")
+    return C.c_void_p(t.data_ptr())
+
+
+class Context:
+    """cb_ctx wrapper. device=None -> current torch device + current stream; device=-1 -> dry context (no GPU)."""
+
+    def __init__(self, device=None):
+        lib = load()
+        self.dry = device is not None and device < 0
+        if self.dry:
+            dev, stream = -1, None
+        else:
+            if not torch.cuda.is_available():
+                raise RuntimeError("celebbasis_amd needs an MI355X (gfx950) GPU; none is visible. "
+                                   "Use Context(device=-1) only for dry (no-compute) host-logic checks.")
+            dev = torch.cuda.current_device() if device is None else device
+            stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+        self.device = dev
+        self.h = C.c_void_p()
+        check(lib.cb_ctx_create(C.c_int(dev), stream, C.byref(self.h)))
+
+    def sync(self):
+        check(load().cb_ctx_sync(self.h))
+
+    def stats(self):
+        f = C.c_double(); l = C.c_int64(); a = C.c_int64(); p = C.c_int64()
+        check(load().cb_ctx_stats(self.h, C.byref(f), C.byref(l), C.byref(a), C.byref(p)))
+        return {"gemm_flops": f.value, "launches": l.value, "arena_peak_bytes": a.value, "pool_bytes": p.value}
+
+    def reset_stats(self):
+        check(load().cb_ctx_reset_stats(self.h))
+
+    def set_debug_taps(self, on=True):
+        check(load().cb_ctx_set_debug_taps(self.h, C.c_int(1 if on else 0)))
+
+    def tap(self, name):
+        n = C.c_int64()
+        check(load().cb_ctx_tap(self.h, name.encode(), None, C.c_int64(0), C.byref(n)))
+        out = torch.empty(n.value, dtype=torch.float32)
+        check(load().cb_ctx_tap(self.h, name.encode(), C.c_void_p(out.data_ptr()), C.c_int64(n.value), C.byref(n)))
+        return out
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            load().cb_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WeightTable:
+    """cb_wtab wrapper built from a {state-dict key: tensor} mapping. Shape-only entries (dry) pass torch.Size."""
+
+    def __init__(self, state=None):
+        self.h = C.c_void_p()
+        self._keep = []
+        check(load().cb_wtab_create(C.byref(self.h)))
+        if state:
+            for k, v in state.items():
+                self.add(k, v)
+
+    def add(self, name, value):
+        if isinstance(value, torch.Tensor):
+            if value.dtype != torch.float32:
+                return  # integer buffers (position_ids, num_batches_tracked) are not used by the engine
+            t = value.detach().contiguous()
+            self._keep.append(t)
+            dims = (C.c_int64 * max(1, t.dim()))(*t.shape)
+            check(load().cb_wtab_add(self.h, name.encode(), C.c_void_p(t.data_ptr()), C.c_int(1 if t.is_cuda else 0),
+                                     C.c_int(t.dim()), dims))
+        else:  # shape only
+            shape = tuple(value)
+            dims = (C.c_int64 * max(1, len(shape)))(*shape)
+            check(load().cb_wtab_add(self.h, name.encode(), None, C.c_int(0), C.c_int(len(shape)), dims))
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            load().cb_wtab_destroy(self.h)
+            self.h = C.c_void_p()
+        self._keep = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def unet_cfg(in_channels=4, out_channels=4, model_channels=320, num_res_blocks=2, channel_mult=(1, 2, 4, 4),
+             attention_resolutions=(4, 2, 1), num_heads=8, context_dim=768):
+    c = UNetCfg()
+    c.in_channels, c.out_channels, c.model_channels, c.num_res_blocks = in_channels, out_channels, model_channels, num_res_blocks
+    for i, v in enumerate(channel_mult):
+        c.channel_mult[i] = int(v)
+    c.n_mult = len(channel_mult)
+    for i, v in enumerate(attention_resolutions):
+        c.attention_resolutions[i] = int(v)
+    c.n_attn = len(attention_resolutions)
+    c.num_heads, c.context_dim = num_heads, context_dim
+    return c
+
+
+def vae_cfg(ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4):
+    c = VaeCfg()
+    c.ch = ch
+    for i, v in enumerate(ch_mult):
+        c.ch_mult[i] = int(v)
+    c.n_mult = len(ch_mult)
+    c.num_res_blocks, c.in_channels, c.z_channels = num_res_blocks, in_channels, z_channels
+    return c
+
+
+def clip_cfg(vocab=49408, width=768, layers=12, heads=12, ctx_len=77, mlp=3072):
+    c = ClipCfg()
+    c.vocab, c.width, c.layers, c.heads, c.ctx_len, c.mlp = vocab, width, layers, heads, ctx_len, mlp
+    return c
+
+
+def trainer_cfg_default():
+    c = TrainerCfg()
+    check(load().cb_trainer_cfg_default(C.byref(c)))
+    return c
+
+
+class _Handle:
+    _destroy = None
+
+    def close(self):
+        if getattr(self, "h", None) is not None and self.h.value:
+            getattr(load(), self._destroy)(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class UNet(_Handle):
+    _destroy = "cb_unet_destroy"
+
+    def __init__(self, ctx, wtab, cfg, prefix=""):
+        self.ctx, self.cfg = ctx, cfg
+        self.h = C.c_void_p()
+        check(load().cb_unet_create(ctx.h, wtab.h, prefix.encode(), C.byref(cfg), C.byref(self.h)))
+
+    def forward(self, x, t, context, need_grad=False):
+        """x [B,C,H,W] float32, t [B] int64, context [B,L,D] -> eps [B,Cout,H,W] (openaimodel.py:710-742)"""
+        B, _, H, W = x.shape
+        L = context.shape[1]
+        out = torch.empty((B, self.cfg.out_channels, H, W), dtype=torch.float32, device=x.device)
+        self._ctx_shape = context.shape
+        dry = self.ctx.dry
+        check(load().cb_unet_forward(self.h, None if dry else ptr(x), None if dry else ptr(t, torch.int64),
+                                     None if dry else ptr(context), B, H, W, L, None if dry else ptr(out),
+                                     C.c_int(1 if need_grad else 0)))
+        return out
+
+    def backward_context(self, deps):
+        dc = torch.empty(self._ctx_shape, dtype=torch.float32, device=deps.device)
+        dry = self.ctx.dry
+        check(load().cb_unet_backward_context(self.h, None if dry else ptr(deps), None if dry else ptr(dc)))
+        return dc
+
+
+class VAE(_Handle):
+    _destroy = "cb_vae_destroy"
+
+    def __init__(self, ctx, wtab, cfg, prefix=""):
+        self.ctx, self.cfg = ctx, cfg
+        self.h = C.c_void_p()
+        check(load().cb_vae_create(ctx.h, wtab.h, prefix.encode(), C.byref(cfg), C.byref(self.h)))
+
+    def encode(self, image_hwc, post_noise=None, scale=0.18215):
+        """image [B,H,W,3] -> (moments NHWC [B,H/8,W/8,2z], z NCHW [B,z,H/8,W/8])"""
+        B, H, W, _ = image_hwc.shape
+        f = 2 ** (self.cfg.n_mult - 1)
+        zc = self.cfg.z_channels
+        mom = torch.empty((B, H // f, W // f, 2 * zc), dtype=torch.float32, device=image_hwc.device)
+        z = torch.empty((B, zc, H // f, W // f), dtype=torch.float32, device=image_hwc.device)
+        dry = self.ctx.dry
+        check(load().cb_vae_encode(self.h, None if dry else ptr(image_hwc), None if dry else ptr(post_noise), B, H, W,
+                                   C.c_float(scale), None if dry else ptr(mom), None if dry else ptr(z)))
+        return mom, z
+
+
+class Clip(_Handle):
+    _destroy = "cb_clip_destroy"
+
+    def __init__(self, ctx, wtab, cfg, prefix=""):
+        self.ctx, self.cfg = ctx, cfg
+        self.h = C.c_void_p()
+        check(load().cb_clip_create(ctx.h, wtab.h, prefix.encode(), C.byref(cfg), C.byref(self.h)))
+
+    def embed_tokens(self, tokens):
+        B, L = tokens.shape
+        out = torch.empty((B, L, self.cfg.width), dtype=torch.float32, device=tokens.device)
+        check(load().cb_clip_embed_tokens(self.h, ptr(tokens, torch.int64), B, L, ptr(out)))
+        return out
+
+    def forward(self, embedded, need_grad=False):
+        B, L, _ = embedded.shape
+        out = torch.empty_like(embedded)
+        self._shape = embedded.shape
+        dry = self.ctx.dry
+        check(load().cb_clip_forward(self.h, None if dry else ptr(embedded), B, L, None if dry else ptr(out),
+                                     C.c_int(1 if need_grad else 0)))
+        return out
+
+    def backward_embeds(self, dhidden):
+        de = torch.empty(self._shape, dtype=torch.float32, device=dhidden.device)
+        dry = self.ctx.dry
+        check(load().cb_clip_backward_embeds(self.h, None if dry else ptr(dhidden), None if dry else ptr(de)))
+        return de
+
+
+class FrNet(_Handle):
+    _destroy = "cb_frnet_destroy"
+
+    def __init__(self, ctx, wtab, layers=(3, 13, 30, 3), width=64, in_size=112, prefix="", feat=512):
+        self.ctx, self.in_size, self.feat = ctx, in_size, feat
+        self.h = C.c_void_p()
+        arr = (C.c_int * 4)(*layers)
+        check(load().cb_frnet_create(ctx.h, wtab.h, prefix.encode(), arr, width, in_size, C.byref(self.h)))
+
+    def forward(self, img_nhwc):
+        N = img_nhwc.shape[0]
+        out = torch.empty((N, self.feat), dtype=torch.float32, device=img_nhwc.device)
+        dry = self.ctx.dry
+        check(load().cb_frnet_forward(self.h, None if dry else ptr(img_nhwc), N, None if dry else ptr(out)))
+        return out
+
+
+class Trainer(_Handle):
+    _destroy = "cb_trainer_destroy"
+
+    def __init__(self, ctx, wtab, cfg=None):
+        self.ctx = ctx
+        self.cfg = cfg if cfg is not None else trainer_cfg_default()
+        self.h = C.c_void_p()
+        check(load().cb_trainer_create(ctx.h, wtab.h, C.byref(self.cfg), C.byref(self.h)))
+
+    def step(self, image, faces, ids, tokens, t, noise, post_noise, lr):
+        b = Batch()
+        b.B = int(tokens.shape[0]) if tokens is not None else int(image)
+        if not self.ctx.dry:
+            b.image, b.faces = ptr(image), ptr(faces)
+            b.ids, b.tokens, b.t = ptr(ids, torch.int64), ptr(tokens, torch.int64), ptr(t, torch.int64)
+            b.noise, b.post_noise = ptr(noise), ptr(post_noise)
+        check(load().cb_trainer_step(self.h, C.byref(b), C.c_float(lr)))
+
+    def get_state(self, name):
+        n = C.c_int64()
+        check(load().cb_trainer_get_state(self.h, name.encode(), None, C.c_int64(0), C.byref(n)))
+        out = torch.zeros(n.value, dtype=torch.float32)
+        check(load().cb_trainer_get_state(self.h, name.encode(), C.c_void_p(out.data_ptr()), C.c_int64(n.value), C.byref(n)))
+        return out
+
+    def set_state(self, name, value):
+        v = value.detach().to(torch.float32).contiguous().cpu().reshape(-1)
+        check(load().cb_trainer_set_state(self.h, name.encode(), C.c_void_p(v.data_ptr()), C.c_int64(v.numel())))

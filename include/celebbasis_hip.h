@@ -1,0 +1,209 @@
+/* celebbasis_hip.h — C ABI of libcelebbasis_hip.so: the MI355X-native (gfx950) replacement for the
+ * CelebBasis personalization training step.
+ *
+ * The reference (ygtxr1997/CelebBasis) has no FFI: its seam is the config-driven Python plugin boundary
+ * `instantiate_from_config` (ldm/util.py:78-93) that resolves the YAML `target:` strings of
+ * configs/stable-diffusion/aigc_id.yaml:3,24,40,57,80 to Python classes. This header is the boundary the
+ * build's own `celebbasis_amd.ldm.*` classes bind (ctypes). Each entry point cites the
+ * reference function it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success or a negative cb_status; cb_last_error() returns a thread-local
+ *    message. No C++ exception crosses the boundary.
+ *  - all tensor arguments are raw DEVICE pointers to float32 unless stated (int64 for token / id / timestep
+ *    tensors, as in the reference). The caller owns every input/output buffer; the library never frees caller
+ *    memory and owns only its handles, its weight copies and its per-context step arena.
+ *  - work is enqueued on the context's stream (borrowed from the caller, e.g. PyTorch's current HIP stream);
+ *    calls are asynchronous with respect to the host except the _create, _destroy and _get_state calls.
+ *  - activation layout inside the library is NHWC ("tokens x channels"); NCHW appears only where the
+ *    reference's public tensors are NCHW (latents, noise, UNet I/O) and is converted at the boundary.
+ *  - a context created with device < 0 is a DRY context: no GPU is touched, kernels are not launched, but all
+ *    shape checks, weight-name lookups, arena sizing and FLOP accounting run. It exists so the host logic can
+ *    be tested on machines without a GPU. It computes nothing: there is no CPU fallback in this library.
+ */
+#ifndef CELEBBASIS_HIP_H
+#define CELEBBASIS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { CB_STATUS_OK = 0, CB_STATUS_ARG = -1, CB_STATUS_HIP = -2, CB_STATUS_SHAPE = -3, CB_STATUS_MISSING = -4,
+               CB_STATUS_OOM = -5, CB_STATUS_STATE = -6, CB_STATUS_INTERNAL = -7 } cb_status;
+
+typedef struct cb_ctx cb_ctx;
+typedef struct cb_wtab cb_wtab;
+typedef struct cb_unet cb_unet;
+typedef struct cb_vae cb_vae;
+typedef struct cb_clip cb_clip;
+typedef struct cb_frnet cb_frnet;
+typedef struct cb_trainer cb_trainer;
+
+const char* cb_last_error(void);
+int cb_version(void);
+
+/* ---- context ------------------------------------------------------------------------------------ */
+int cb_ctx_create(int device, void* hip_stream, cb_ctx** out);
+int cb_ctx_destroy(cb_ctx* ctx);
+int cb_ctx_sync(cb_ctx* ctx);
+/* accounting since the last reset: sum of 2*M*N*K over GEMM-class launches, kernel launches,
+ * peak step-arena bytes, bytes held by the persistent pool (weights + packs + optimiser state) */
+int cb_ctx_stats(cb_ctx* ctx, double* gemm_flops, int64_t* launches, int64_t* arena_peak_bytes, int64_t* pool_bytes);
+int cb_ctx_reset_stats(cb_ctx* ctx);
+/* debug taps: named intermediates of the last graph-level call (valid until the next call) */
+int cb_ctx_set_debug_taps(cb_ctx* ctx, int enable);
+int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);
+
+/* ---- weight table: mirrors a torch state_dict (names = the reference's state-dict keys) */
+int cb_wtab_create(cb_wtab** out);
+int cb_wtab_add(cb_wtab* wt, const char* name, const float* data, int on_device, int ndim, const int64_t* dims);
+int cb_wtab_destroy(cb_wtab* wt);
+
+/* ---- op level (each replaces one torch op family on the reference hot path) ---------------------- */
+typedef enum { CB_CONV_SAME = 0, CB_CONV_DOWN = 1, CB_CONV_DOWN_ASYM = 2, CB_CONV_UP = 3, CB_CONV_S2_1X1 = 4 } cb_conv_mode;
+typedef enum { CB_LD_ROW = 0, CB_LD_COL = 1 } cb_operand_layout;
+
+/* C[M,N] = alpha * A.B + bias[n] + R + beta*C, batched; ROW = K contiguous, COL = M/N contiguous.
+ * Replaces nn.Linear / einsum / bmm (ldm/modules/attention.py:170-193, openaimodel.py linear()). */
+typedef struct {
+    const float* A; const float* B; float* C;
+    int M, N, K;
+    int64_t lda, ldb, ldc;
+    int a_layout, b_layout;
+    int batch;
+    int64_t strideA, strideB, strideC;
+    const float* bias;
+    const float* R; int64_t ldr; int64_t strideR;
+    float alpha, beta;
+} cb_gemm_desc;
+int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
+
+/* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped. */
+int cb_pack_conv_weight(cb_ctx* ctx, const float* w_oihw, float* out, int O, int I, int ks, int dgrad);
+/* nn.Conv2d forward on NHWC (openaimodel.py conv_nd / model.py Conv2d), optional fused per-image row bias
+ * (ResBlock emb add, openaimodel.py:262-273) and residual (skip_connection(x) + h, openaimodel.py:275). */
+int cb_conv2d_fwd(cb_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* rowbias,
+                  const float* residual, float* y, int N, int H, int W, int Cin, int Cout, int ks, int mode);
+/* input gradient of the same conv (autograd of F.conv2d wrt input; weights are frozen, ddpm.py:491-500) */
+int cb_conv2d_dgrad(cb_ctx* ctx, const float* dy, const float* w_packed_dgrad, float* dx, int N, int H, int W, int Cin,
+                    int Cout, int ks, int mode, float beta);
+
+/* GroupNorm(32)(+SiLU): util.py:214-216 GroupNorm32 / attention.py:76-77 Normalize + nn.SiLU. stats: [N][32][2]. */
+int cb_groupnorm_silu_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                          int N, int HW, int C, float eps, int silu);
+int cb_groupnorm_silu_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* beta,
+                          const float* stats, float* dx, int N, int HW, int C, int silu, float acc_beta);
+/* nn.LayerNorm over the last dim (attention.py:203-205, HF CLIP layer norms). stats: [rows][2]. */
+int cb_layernorm_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                     int64_t rows, int C, float eps);
+int cb_layernorm_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* stats, float* dx,
+                     int64_t rows, int C, float acc_beta);
+/* GEGLU (attention.py:37-44) */
+int cb_geglu_fwd(cb_ctx* ctx, const float* x, float* y, int64_t M, int D);
+int cb_geglu_bwd(cb_ctx* ctx, const float* x, const float* dy, float* dx, int64_t M, int D);
+
+/* Multi-head attention softmax(scale * Q K^T [+causal]) V  (attention.py:170-193 CrossAttention, model.py:176-202
+ * AttnBlock, HF CLIPAttention). q lives in columns [q_off, q_off+C) of `qbuf` [B,Nq,ldq]; k and v in columns
+ * k_off / v_off of `kvbuf` [B,Nk,ldkv] (kvbuf may equal qbuf for fused QKV). out: [B,Nq,C].
+ * If dout != NULL the call also runs the backward and writes dq into dqbuf (same layout as qbuf, only the q columns)
+ * and dk/dv into dkvbuf (same layout as kvbuf; may equal dqbuf). */
+typedef struct {
+    const float* qbuf; int64_t ldq; int q_off;
+    const float* kvbuf; int64_t ldkv; int k_off, v_off;
+    int B, Nq, Nk, C, heads;
+    float scale; int causal;
+    float* out;
+    const float* dout; float* dqbuf; float* dkvbuf;
+} cb_attention_desc;
+int cb_attention(cb_ctx* ctx, const cb_attention_desc* d);
+
+/* small ops of the step, exported for parity tests */
+int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, float* out, int B, int dim);                  /* util.py:151-171 */
+int cb_q_sample(cb_ctx* ctx, const float* x0_nhwc, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
+                const float* sqrt_1mac, float* xt_nhwc, int B, int C, int HW);                        /* ddpm.py:289-292 */
+int cb_mse_loss(cb_ctx* ctx, const float* pred_nhwc, const float* target_nchw, float* loss, float* dpred, int B, int C,
+                int HW);                                                                              /* ddpm.py:294-307 */
+int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size); /* meta_net.py:253-260 */
+int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map,
+                   int B, int T, int C, int reps, int64_t placeholder);                               /* helpers.py:13-41 */
+int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int64_t n, int* step_dev, float lr, float b1,
+                  float b2, float eps, float wd);                                                     /* ddpm.py:1454 */
+int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W);
+int cb_nhwc_to_nchw(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W);
+
+/* ---- graph level --------------------------------------------------------------------------------- */
+typedef struct {
+    int in_channels, out_channels, model_channels, num_res_blocks;
+    int channel_mult[8]; int n_mult;
+    int attention_resolutions[8]; int n_attn;
+    int num_heads, context_dim;
+} cb_unet_cfg;
+/* UNetModel (openaimodel.py:413-742). Weights are looked up as prefix + state-dict key. */
+int cb_unet_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_unet_cfg* cfg, cb_unet** out);
+int cb_unet_destroy(cb_unet* u);
+/* UNetModel.forward(x, timesteps, context) (openaimodel.py:710-742): x/eps NCHW [B,C,H,W], t int64[B],
+ * context [B,L,context_dim]. need_grad=1 keeps the tape for cb_unet_backward_context. */
+int cb_unet_forward(cb_unet* u, const float* x_nchw, const int64_t* t, const float* context, int B, int H, int W, int L,
+                    float* eps_nchw, int need_grad);
+/* d(sum(eps * deps)) / d context : the input-gradient-only backward the reference gets from autograd */
+int cb_unet_backward_context(cb_unet* u, const float* deps_nchw, float* dcontext);
+
+typedef struct { int ch; int ch_mult[8]; int n_mult; int num_res_blocks; int in_channels; int z_channels; } cb_vae_cfg;
+/* AutoencoderKL.encode (autoencoder.py:324-328) + DiagonalGaussianDistribution.sample * scale (ddpm.py:590-597).
+ * image: [B,H,W,3] HWC (the dataset layout, face_id.py:598-644); moments_nhwc (optional) [B,H/8,W/8,2z];
+ * z_nchw [B,z,H/8,W/8]; post_noise_nchw may be NULL (mode()). */
+int cb_vae_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_vae_cfg* cfg, cb_vae** out);
+int cb_vae_destroy(cb_vae* v);
+int cb_vae_encode(cb_vae* v, const float* image_hwc, const float* post_noise_nchw, int B, int H, int W, float scale,
+                  float* moments_nhwc, float* z_nchw);
+
+typedef struct { int vocab, width, layers, heads, ctx_len, mlp; } cb_clip_cfg;
+/* CLIP text transformer as patched by FrozenCLIPEmbedder (modules.py:176-404): takes the token embeddings AFTER the
+ * embedding-manager hook, adds position embeddings, 12 causal layers, final LayerNorm. */
+int cb_clip_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_clip_cfg* cfg, cb_clip** out);
+int cb_clip_destroy(cb_clip* c);
+int cb_clip_embed_tokens(cb_clip* c, const int64_t* tokens, int B, int L, float* embedded);   /* token_embedding lookup */
+int cb_clip_forward(cb_clip* c, const float* embedded, int B, int L, float* hidden, int need_grad);
+int cb_clip_backward_embeds(cb_clip* c, const float* dhidden, float* dembedded);
+
+/* iresnet (iresnet.py:67-181), frozen eval: faces [N,S,S,3] NHWC -> features [N,feat] (before F.normalize) */
+int cb_frnet_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const int* layers4, int width, int in_size, cb_frnet** out);
+int cb_frnet_destroy(cb_frnet* f);
+int cb_frnet_forward(cb_frnet* f, const float* img_nhwc, int N, float* features);
+
+/* ---- the whole personalization training step (LatentDiffusion.training_step, ddpm.py:357-370 -> shared_step ->
+ *      get_input -> forward -> p_losses, loss.backward(), AdamW.step(); SURVEY §3.1 hot loop) ------------- */
+typedef struct {
+    cb_unet_cfg unet; cb_vae_cfg vae; cb_clip_cfg clip;
+    int fr_layers[4]; int fr_width; int fr_in;
+    int image_size, es, inner_dim, max_ids;
+    float momentum, scale_factor, linear_start, linear_end; int timesteps;
+    int64_t placeholder_token;
+    float adam_b1, adam_b2, adam_eps, weight_decay;
+} cb_trainer_cfg;
+int cb_trainer_cfg_default(cb_trainer_cfg* cfg);   /* SD v1-4 + aigc_id.yaml values */
+/* wt must hold: model.diffusion_model.*, first_stage_model.*, cond_stage_model.transformer.text_model.*,
+ * embedding_manager.meta_id_net.id_model.*, embedding_manager.meta_id_net.stylegan_mlp.net.0.{weight,bias},
+ * celeb_embeddings [es,1+inner,width]; optional id_embeddings [max_ids, es*width], id_coefficients [max_ids, es*inner] */
+int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg, cb_trainer** out);
+int cb_trainer_destroy(cb_trainer* t);
+typedef struct {
+    const float* image;       /* [B,S,S,3]  batch['image']                 */
+    const float* faces;       /* [B,S,S,6]  batch['image_ori']['faces']    */
+    const int64_t* ids;       /* [B,2]      batch['image_ori']['ids']      */
+    const int64_t* tokens;    /* [B,77]     tokenizer(caption).input_ids   */
+    const int64_t* t;         /* [B]        torch.randint(0, 1000)         */
+    const float* noise;       /* [B,4,64,64] NCHW  randn_like(x_start)     */
+    const float* post_noise;  /* [B,4,64,64] NCHW  posterior.sample noise  */
+    int B;
+} cb_batch;
+int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
+/* state names: "loss"(1) "mlp.weight" "mlp.bias" "mlp.grad_weight" "mlp.grad_bias" "adam.m_weight" "adam.v_weight"
+ * "adam.m_bias" "adam.v_bias" "id_embeddings" "id_coefficients" "step"(1, as float) */
+int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);
+int cb_trainer_set_state(cb_trainer* t, const char* name, const float* host_src, int64_t numel);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

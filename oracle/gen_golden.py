@@ -1,0 +1,366 @@
+"""Generate tests/golden/*.pt by running the REFERENCE's own modules (imported from /root/reference, read-only) on
+seeded inputs. Runs only in the build container (the reference never travels to the GPU box); the resulting
+fixtures are data (inputs + expected outputs), committed next to this script.
+
+    python oracle/gen_golden.py            # writes tests/golden/*.pt and tests/golden/MANIFEST.json
+
+Import shims (harness side only, no reference edits): omegaconf / pytorch_lightning / torchvision / taming / kornia /
+clip are absent from this image; the reference touches them only at import time or in code paths the fixtures do not
+exercise.
+"""
+import hashlib
+import json
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("CELEBBASIS_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+sys.path.insert(0, REPO)
+sys.path.insert(0, REF)
+
+from oracle import cb_oracle as O  # noqa: E402
+
+
+def _stub(name, **attrs):
+    m = types.ModuleType(name)
+    for k, v in attrs.items():
+        setattr(m, k, v)
+    sys.modules[name] = m
+    return m
+
+
+def install_shims():
+    class ListConfig(list):
+        pass
+    _stub("omegaconf", ListConfig=ListConfig, OmegaConf=object)
+    _stub("omegaconf.listconfig", ListConfig=ListConfig)
+
+    class LightningModule(nn.Module):
+        @property
+        def device(self):
+            return torch.device("cpu")
+    pl = _stub("pytorch_lightning", LightningModule=LightningModule)
+    _stub("pytorch_lightning.utilities")
+    _stub("pytorch_lightning.utilities.distributed", rank_zero_only=lambda f: f)
+    pl.utilities = sys.modules["pytorch_lightning.utilities"]
+    tv = _stub("torchvision")
+    _stub("torchvision.utils", make_grid=lambda *a, **k: None)
+    tr = _stub("torchvision.transforms")
+    for n in ("Compose", "Resize", "ToTensor", "Normalize", "RandomHorizontalFlip", "ColorJitter", "CenterCrop", "RandomCrop"):
+        setattr(tr, n, lambda *a, **k: None)
+    tr.functional = _stub("torchvision.transforms.functional")
+    tv.transforms = tr
+    tv.utils = sys.modules["torchvision.utils"]
+    _stub("taming"); _stub("taming.modules"); _stub("taming.modules.vqvae")
+    _stub("taming.modules.vqvae.quantize", VectorQuantizer2=object)
+    _stub("kornia")
+    _stub("clip")
+
+
+def sha(obj):
+    return hashlib.sha256(obj.encode()).hexdigest()
+
+
+def keys_digest(shapes):
+    lines = sorted(f"{k}:{tuple(int(x) for x in v)}" for k, v in shapes.items())
+    return dict(n=len(lines), params=int(sum(int(np.prod(v)) for v in shapes.values())), sha256=sha("\n".join(lines)))
+
+
+def sd_shapes(module, prefix="", skip=()):
+    return {prefix + k: tuple(v.shape) for k, v in module.state_dict().items()
+            if v.dtype.is_floating_point and not any(s in k for s in skip)}
+
+
+def load_into(module, W, prefix=""):
+    sd = module.state_dict()
+    new = {}
+    for k, v in sd.items():
+        if (prefix + k) in W:
+            assert tuple(W[prefix + k].shape) == tuple(v.shape), (k, W[prefix + k].shape, v.shape)
+            new[k] = W[prefix + k].clone()
+        else:
+            assert not v.dtype.is_floating_point or "num_batches" in k, f"oracle table lacks {prefix + k}"
+            new[k] = v
+    module.load_state_dict(new, strict=True)
+
+
+MINI_UNET = dict(in_channels=4, out_channels=4, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2),
+                 attention_resolutions=(1, 2), num_heads=2, context_dim=48)
+MINI_VAE = dict(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, in_channels=3, z_channels=4)
+MINI_FR = dict(layers=(1, 1, 1, 1), width=64, in_size=112, feat=512)
+MINI_CLIP = dict(vocab=120, width=64, layers=2, heads=4, ctx_len=77, mlp=128)
+
+
+def gen_schedule(manifest):
+    from ldm.modules.diffusionmodules.util import make_beta_schedule
+    betas = make_beta_schedule("linear", 1000, linear_start=0.00085, linear_end=0.012)   # util.py:21-25
+    alphas_cumprod = np.cumprod(1.0 - betas, axis=0)                                         # ddpm.py:133-134
+    fx = dict(betas=torch.tensor(betas, dtype=torch.float32), alphas_cumprod=torch.tensor(alphas_cumprod, dtype=torch.float32),
+              sqrt_alphas_cumprod=torch.tensor(np.sqrt(alphas_cumprod), dtype=torch.float32),
+              sqrt_one_minus_alphas_cumprod=torch.tensor(np.sqrt(1.0 - alphas_cumprod), dtype=torch.float32))
+    # q_sample through the reference's own extract_into_tensor (util.py:96-99, ddpm.py:289-292)
+    from ldm.modules.diffusionmodules.util import extract_into_tensor
+    g = torch.Generator().manual_seed(11)
+    x0 = torch.randn(3, 4, 8, 8, generator=g); eps = torch.randn(3, 4, 8, 8, generator=g); t = torch.tensor([0, 500, 999])
+    fx["q_x0"], fx["q_eps"], fx["q_t"] = x0, eps, t
+    fx["q_xt"] = (extract_into_tensor(fx["sqrt_alphas_cumprod"], t, x0.shape) * x0 +
+                  extract_into_tensor(fx["sqrt_one_minus_alphas_cumprod"], t, x0.shape) * eps)
+    from ldm.modules.diffusionmodules.util import timestep_embedding
+    fx["temb_t"] = torch.tensor([0, 1, 37, 999]); fx["temb"] = timestep_embedding(fx["temb_t"], 320)
+    torch.save(fx, os.path.join(OUT, "schedule.pt"))
+    manifest["schedule.pt"] = "ldm/modules/diffusionmodules/util.py make_beta_schedule, extract_into_tensor, timestep_embedding; ddpm.py:126-178,289-292"
+
+
+def gen_shift_rows(manifest):
+    from ldm.modules.id_embedding.helpers import get_rep_pos, shift_tensor_dim0
+    cases = []
+    g = torch.Generator().manual_seed(3)
+    specs = [
+        (torch.LongTensor([0, 1, 2, 2, 3, 4, 5, 6, 7, 99] + [99] * 20), 2, 2),          # helpers.py:44-54 own example (token 2)
+        (torch.LongTensor([49406, 320, 1125, 539, 320, 1710, 539, 48136, 2533, 49407] + [49407] * 67), 48136, 2),
+        (torch.LongTensor([49406, 48136] + [49407] * 75), 48136, 2),
+        (torch.LongTensor([49406] + [5] * 74 + [48136, 49407]), 48136, 2),                # placeholder near the end (tail dropped)
+        (torch.LongTensor([49406, 48136, 7, 48136, 9] + [49407] * 72), 48136, 3),         # two occurrences, reps 3
+        (torch.LongTensor([49406, 1, 2, 3] + [49407] * 73), 48136, 2),                    # no placeholder
+    ]
+    for toks, ph, reps in specs:
+        emb = torch.randn(toks.shape[0], 6, generator=g)
+        z = torch.randn(reps, 6, generator=g)
+        pos = get_rep_pos(toks, [ph])
+        out, final = shift_tensor_dim0(emb.clone(), pos, reps)
+        for one_pos in final[0]:                      # embedding_manager.py:359-360
+            out[one_pos] = z
+        cases.append(dict(tokens=toks, placeholder=ph, reps=reps, embedded=emb, z=z, out=out))
+    torch.save(cases, os.path.join(OUT, "shift_rows.pt"))
+    manifest["shift_rows.pt"] = "ldm/modules/id_embedding/helpers.py:6-41 + embedding_manager.py:347-360"
+
+
+def gen_unet(manifest):
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    cfg = MINI_UNET
+    torch.manual_seed(0)
+    m = UNetModel(image_size=32, in_channels=cfg["in_channels"], model_channels=cfg["model_channels"], out_channels=cfg["out_channels"],
+                  num_res_blocks=cfg["num_res_blocks"], attention_resolutions=list(cfg["attention_resolutions"]),
+                  channel_mult=list(cfg["channel_mult"]), num_heads=cfg["num_heads"], use_spatial_transformer=True,
+                  transformer_depth=1, context_dim=cfg["context_dim"], use_checkpoint=True, legacy=False).eval()
+    shapes = O.unet_param_shapes(cfg)
+    assert keys_digest(shapes) == keys_digest(sd_shapes(m)), "mini UNet key table mismatch"
+    W = O.init_weights(shapes, seed=7)
+    load_into(m, W)
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(2, 4, 16, 16, generator=g); t = torch.tensor([3, 721]); ctx = torch.randn(2, 77, cfg["context_dim"], generator=g)
+    dout = torch.randn(2, 4, 16, 16, generator=g)
+    ctx_r = ctx.clone().requires_grad_(True)
+    out = m(x, t, context=ctx_r)
+    (dctx,) = torch.autograd.grad((out * dout).sum(), [ctx_r])
+    torch.save(dict(cfg=cfg, weight_seed=7, x=x, t=t, context=ctx, dout=dout, out=out.detach(), dcontext=dctx),
+               os.path.join(OUT, "unet_mini.pt"))
+    manifest["unet_mini.pt"] = "ldm/modules/diffusionmodules/openaimodel.py UNetModel.forward:710-742 + autograd to context"
+    # full SD v1-4 key table (aigc_id.yaml:39-54): built on the meta device, no memory
+    with torch.device("meta"):
+        full = UNetModel(image_size=32, in_channels=4, model_channels=320, out_channels=4, num_res_blocks=2,
+                         attention_resolutions=[4, 2, 1], channel_mult=[1, 2, 4, 4], num_heads=8, use_spatial_transformer=True,
+                         transformer_depth=1, context_dim=768, use_checkpoint=True, legacy=False)
+    return keys_digest(sd_shapes(full))
+
+
+def gen_vae(manifest):
+    from ldm.modules.diffusionmodules.model import Encoder
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+    cfg = MINI_VAE
+    enc = Encoder(ch=cfg["ch"], out_ch=3, ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"], attn_resolutions=[],
+                  dropout=0.0, in_channels=3, resolution=64, z_channels=cfg["z_channels"], double_z=True).eval()
+    quant = nn.Conv2d(2 * cfg["z_channels"], 2 * cfg["z_channels"], 1)                           # autoencoder.py:302
+    shapes = O.vae_encoder_param_shapes(cfg)
+    ref_shapes = sd_shapes(enc, "encoder."); ref_shapes.update(sd_shapes(quant, "quant_conv."))
+    assert keys_digest(shapes) == keys_digest(ref_shapes), "mini VAE key table mismatch"
+    W = O.init_weights(shapes, seed=9)
+    load_into(enc, W, "encoder."); load_into(quant, W, "quant_conv.")
+    g = torch.Generator().manual_seed(31)
+    x = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    with torch.no_grad():
+        moments = quant(enc(x))
+        post = DiagonalGaussianDistribution(moments)
+        torch.manual_seed(77)
+        noise_same_stream = None
+        z = post.sample()                                                                        # distributions.py:35-37
+        torch.manual_seed(77)
+        noise_same_stream = torch.randn(post.mean.shape)
+    torch.save(dict(cfg=cfg, weight_seed=9, x=x, moments=moments, noise=noise_same_stream, z_scaled=0.18215 * z),
+               os.path.join(OUT, "vae_mini.pt"))
+    manifest["vae_mini.pt"] = "ldm/modules/diffusionmodules/model.py Encoder.forward:434-459, distributions.py:24-37, ddpm.py:597"
+    with torch.device("meta"):
+        full = Encoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+                       resolution=512, z_channels=4, double_z=True)
+        fq = nn.Conv2d(8, 8, 1)
+    fs = sd_shapes(full, "encoder."); fs.update(sd_shapes(fq, "quant_conv."))
+    return keys_digest(fs)
+
+
+def _fr_reinit(net, seed):
+    """the reference initialises convs with N(0, 0.1) which overflows at depth with random BN stats; re-seed small"""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for k, v in net.state_dict().items():
+            if not v.dtype.is_floating_point:
+                continue
+            if k.endswith("running_var"):
+                v.copy_(0.5 + torch.rand(v.shape, generator=g))
+            elif k.endswith("running_mean"):
+                v.copy_(0.1 * torch.randn(v.shape, generator=g))
+            elif v.dim() > 1:
+                fan = int(np.prod(v.shape[1:]))
+                v.copy_(torch.randn(v.shape, generator=g) / np.sqrt(fan))
+            elif "prelu" in k:
+                v.copy_(0.25 + 0.05 * torch.randn(v.shape, generator=g))
+            elif k.endswith("weight"):
+                v.copy_(1.0 + 0.1 * torch.randn(v.shape, generator=g))
+            else:
+                v.copy_(0.05 * torch.randn(v.shape, generator=g))
+
+
+def gen_frnet(manifest):
+    from ldm.modules.id_embedding.iresnet import IResNet, IBasicBlock, iresnet100
+    cfg = MINI_FR
+    net = IResNet(IBasicBlock, list(cfg["layers"])).eval()
+    shapes = O.frnet_param_shapes(cfg)
+    assert keys_digest(shapes) == keys_digest(sd_shapes(net)), "mini iresnet key table mismatch"
+    W = O.init_weights(shapes, seed=13)
+    load_into(net, W)
+    g = torch.Generator().manual_seed(41)
+    x = torch.rand(2, 3, 112, 112, generator=g) * 2 - 1
+    with torch.no_grad():
+        out = net(x)
+    torch.save(dict(cfg=cfg, weight_seed=13, x=x, out=out), os.path.join(OUT, "frnet_mini.pt"))
+    manifest["frnet_mini.pt"] = "ldm/modules/id_embedding/iresnet.py IResNet.forward:166-181 (eval)"
+    with torch.device("meta"):
+        full = iresnet100()
+    return keys_digest(sd_shapes(full))
+
+
+def gen_manager(manifest):
+    """EmbeddingManagerId.forward in training mode (embedding_manager.py:279-394) with MetaIdNet (meta_net.py:250-346);
+    the FR backbone is a seeded 1-1-1-1 iresnet (weights file absent) and the embedder is a minimal stand-in for
+    FrozenCLIPEmbedder's tokenizer / token-embedding attributes (the manager only uses them in __init__)."""
+    import ldm.modules.id_embedding.meta_net as meta_net
+    from ldm.modules.id_embedding.iresnet import IResNet, IBasicBlock
+
+    def load_fr_net(self):
+        self.id_model = IResNet(IBasicBlock, [1, 1, 1, 1]).eval()
+        for p in self.id_model.parameters():
+            p.requires_grad = False
+    meta_net.MetaIdNet.load_fr_net = load_fr_net
+    from ldm.modules.embedding_manager import EmbeddingManagerId
+
+    width, inner, es, vocab = 768, 16, 2, 50000
+    table = O.formula_table(vocab, width)
+    tok_of = {"sks": 48136, "ks": 662, "face": 1710}
+
+    class Tok:
+        def __call__(self, s, **kw):
+            ids = torch.full((1, 77), 49407, dtype=torch.long); ids[0, 0] = 49406; ids[0, 1] = tok_of[s]
+            return {"input_ids": ids}
+
+    class Emb(nn.Module):
+        def forward(self, ids, **kw):
+            return table[ids]
+    embedder = types.SimpleNamespace(tokenizer=Tok(), transformer=types.SimpleNamespace(
+        text_model=types.SimpleNamespace(embeddings=Emb())))
+    torch.manual_seed(5)
+    mgr = EmbeddingManagerId(embedder, placeholder_strings=["sks", "ks"], initializer_words=["face", "face"], max_ids=3,
+                             num_embeds_per_token=es, meta_mlp_depth=1, loss_type="none", meta_inner_dim=inner, meta_heads=1,
+                             use_rm_mlp=False, test_mode="coefficient", momentum=0.99, save_fp16=False)
+    mgr.train()
+    n_train = sum(p.numel() for p in mgr.meta_id_net.stylegan_mlp.parameters())
+    # seeded weights under the oracle's names
+    fr_shapes = O.frnet_param_shapes(MINI_FR, "embedding_manager.meta_id_net.id_model.")
+    W = O.init_weights(fr_shapes, seed=17)
+    load_into(mgr.meta_id_net.id_model, W, "embedding_manager.meta_id_net.id_model.")
+    g = torch.Generator().manual_seed(51)
+    Wm = torch.randn(es * inner, 512, generator=g); bm = 0.1 * torch.randn(es * inner, generator=g)
+    with torch.no_grad():
+        mgr.meta_id_net.stylegan_mlp.net[0].weight.copy_(Wm); mgr.meta_id_net.stylegan_mlp.net[0].bias.copy_(bm)
+    basis = O.init_weights({"celeb_embeddings": (es, 1 + inner, width)}, seed=19)["celeb_embeddings"]
+    id_coef0 = torch.randn(3, es, 1, inner, generator=g); id_emb0 = torch.randn(3, es, width, generator=g)
+    mgr.id_coefficients = [id_coef0[i].clone() for i in range(3)]
+    mgr.id_embeddings = [id_emb0[i].clone() for i in range(3)]
+    B, S = 2, 64
+    faces = torch.rand(B, S, S, 6, generator=g) * 2 - 1
+    ids = torch.tensor([[1, 1], [2, 2]])
+    tokens = torch.full((B, 77), 49407, dtype=torch.long); tokens[:, 0] = 49406
+    tokens[0, 1:9] = torch.tensor([320, 1125, 539, 320, 1710, 539, 48136, 2533]); tokens[1, 1:4] = torch.tensor([48136, 1125, 320])
+    embedded = table[tokens].clone()
+    out = mgr(tokens, embedded.clone(), None, {"faces": faces, "ids": ids, "num_ids": torch.tensor([1, 1])}, basis)
+    dout = O.formula_table(out.shape[0] * out.shape[1], out.shape[2], 0.9).reshape(out.shape) * 50.0
+    gW, gb = torch.autograd.grad((out * dout).sum(), [mgr.meta_id_net.stylegan_mlp.net[0].weight, mgr.meta_id_net.stylegan_mlp.net[0].bias])
+    torch.save(dict(fr_cfg=MINI_FR, fr_weight_seed=17, basis_seed=19, inner=inner, es=es, Wm=Wm, bm=bm, basis=basis,
+                    id_coef0=id_coef0.reshape(3, -1), id_emb0=id_emb0.reshape(3, -1), faces=faces, ids=ids, tokens=tokens,
+                    vocab=vocab, out=out.detach(), gW=gW, gb=gb, n_trainable=n_train,
+                    id_coef1=torch.stack([c.detach().reshape(-1) for c in mgr.id_coefficients]),
+                    id_emb1=torch.stack([e.detach().reshape(-1) for e in mgr.id_embeddings])),
+               os.path.join(OUT, "manager_mini.pt"))
+    manifest["manager_mini.pt"] = ("ldm/modules/embedding_manager.py EmbeddingManagerId.forward:279-394, _momentum_update:452-490; "
+                                   "meta_net.py forward_multi_faces:329-346, _celebs_forward:250-302")
+
+
+def gen_clip(manifest):
+    """third-party arithmetic (transformers CLIP text layers): cross-check the restatement against the INSTALLED transformers
+    CLIPTextModel on the same weights — the published algorithm, not the reference's monkey-patched wrapper."""
+    from transformers import CLIPTextConfig, CLIPTextModel
+    cfg = MINI_CLIP
+    hf = CLIPTextModel(CLIPTextConfig(vocab_size=cfg["vocab"], hidden_size=cfg["width"], intermediate_size=cfg["mlp"],
+                                      num_hidden_layers=cfg["layers"], num_attention_heads=cfg["heads"],
+                                      max_position_embeddings=cfg["ctx_len"], hidden_act="quick_gelu", layer_norm_eps=1e-5,
+                                      eos_token_id=cfg["vocab"] - 1, bos_token_id=cfg["vocab"] - 2, pad_token_id=1)).eval()
+    hf_prefix = "text_model." if any(k.startswith("text_model.") for k in hf.state_dict()) else ""
+    shapes = O.clip_param_shapes(cfg, hf_prefix)
+    assert keys_digest(shapes) == keys_digest(sd_shapes(hf, skip=("position_ids",))), "mini CLIP key table mismatch"
+    W = O.init_weights(shapes, seed=23)
+    load_into(hf, W)
+    g = torch.Generator().manual_seed(61)
+    tokens = torch.randint(0, cfg["vocab"] - 2, (2, 77), generator=g); tokens[:, -1] = cfg["vocab"] - 1
+    with torch.no_grad():
+        out = hf(input_ids=tokens).last_hidden_state
+    import transformers
+    torch.save(dict(cfg=cfg, weight_seed=23, weight_prefix=hf_prefix, tokens=tokens, last_hidden_state=out, transformers_version=transformers.__version__),
+               os.path.join(OUT, "clip_mini.pt"))
+    manifest["clip_mini.pt"] = f"installed transformers=={transformers.__version__} CLIPTextModel (published CLIP text algorithm; reference pins 4.18.0)"
+    with torch.device("meta"):
+        full = CLIPTextModel(CLIPTextConfig(vocab_size=49408, hidden_size=768, intermediate_size=3072, num_hidden_layers=12,
+                                            num_attention_heads=12, max_position_embeddings=77, hidden_act="quick_gelu"))
+    fs = {k[len("text_model."):] if k.startswith("text_model.") else k: v for k, v in sd_shapes(full, skip=("position_ids",)).items()}
+    return keys_digest(fs)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    import transformers  # noqa: F401  (resolve its optional-dependency probes before the torchvision stub exists)
+    from transformers import CLIPTokenizer, CLIPTextModel  # noqa: F401
+    install_shims()
+    torch.set_num_threads(8)
+    manifest = {}
+    gen_schedule(manifest)
+    gen_shift_rows(manifest)
+    digests = {}
+    digests["unet_sd14"] = gen_unet(manifest)
+    digests["vae_encoder_sd14"] = gen_vae(manifest)
+    digests["iresnet100"] = gen_frnet(manifest)
+    gen_manager(manifest)
+    digests["clip_l14_text"] = gen_clip(manifest)
+    with open(os.path.join(OUT, "state_dict_digests.json"), "w") as f:
+        json.dump(digests, f, indent=1, sort_keys=True)
+    manifest["state_dict_digests.json"] = "sha256 over sorted 'key:shape' lines of the reference modules' float state_dict at SD v1-4 sizes"
+    with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
+        json.dump(manifest, f, indent=1, sort_keys=True)
+    for k in sorted(os.listdir(OUT)):
+        print(f"{os.path.getsize(os.path.join(OUT, k)):9d}  {k}")
+
+
+if __name__ == "__main__":
+    main()

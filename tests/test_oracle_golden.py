@@ -1,0 +1,135 @@
+"""CPU: the oracle (oracle/cb_oracle.py) against the golden vectors produced by the reference's own modules
+(oracle/gen_golden.py, run in the build container). Tolerances are fp32 round-off class."""
+import json
+import os
+
+import torch
+import torch.nn.functional as F
+
+from oracle import cb_oracle as O
+from oracle.gen_golden import keys_digest
+
+
+def _load(golden_dir, name):
+    return torch.load(os.path.join(golden_dir, name), weights_only=False)
+
+
+def test_schedule_known_answers(golden_dir):
+    fx = _load(golden_dir, "schedule.pt")
+    s = O.make_schedule()
+    for k in ("betas", "alphas_cumprod", "sqrt_alphas_cumprod", "sqrt_one_minus_alphas_cumprod"):
+        assert torch.equal(s[k], fx[k]), k
+    # SURVEY §8 A1 known answers
+    assert abs(float(s["betas"][0]) - 0.00085) < 1e-9 and abs(float(s["betas"][999]) - 0.012) < 1e-8
+    assert abs(float(s["sqrt_alphas_cumprod"][500]) - 0.5256736) < 1e-6
+    assert abs(float(s["alphas_cumprod"][999]) - 0.0046601) < 1e-7
+    t = fx["q_t"]
+    xt = s["sqrt_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * fx["q_x0"] + s["sqrt_one_minus_alphas_cumprod"][t].reshape(-1, 1, 1, 1) * fx["q_eps"]
+    assert torch.equal(xt, fx["q_xt"])
+    assert torch.allclose(O.timestep_embedding(fx["temb_t"], 320), fx["temb"], atol=1e-6, rtol=0)
+
+
+def test_shift_rows_bit_exact(golden_dir):
+    for case in _load(golden_dir, "shift_rows.pt"):
+        out = O.shift_rows(case["tokens"], case["embedded"], case["z"], case["placeholder"], case["reps"])
+        assert torch.equal(out, case["out"]), case["tokens"][:12]
+
+
+def test_state_dict_tables_match_reference(golden_dir):
+    with open(os.path.join(golden_dir, "state_dict_digests.json")) as f:
+        d = json.load(f)
+    assert keys_digest(O.unet_param_shapes(O.UNET_SD14)) == d["unet_sd14"]
+    assert keys_digest(O.vae_encoder_param_shapes(O.VAE_SD14)) == d["vae_encoder_sd14"]
+    assert keys_digest(O.frnet_param_shapes(O.FR_R100)) == d["iresnet100"]
+    assert keys_digest(O.clip_param_shapes(O.CLIP_L14)) == d["clip_l14_text"]
+    assert d["unet_sd14"]["params"] == 859520964
+    # trainable tensors: EqualLinear(512 -> 1024) = 525 312 floats
+    s = O.trainer_param_shapes()
+    n = 1
+    for v in s["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"]:
+        n *= v
+    assert n + s["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"][0] == 525312
+
+
+def test_unet_forward_backward(golden_dir):
+    fx = _load(golden_dir, "unet_mini.pt")
+    W = O.init_weights(O.unet_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
+    ctx = fx["context"].clone().requires_grad_(True)
+    out = O.unet_forward(W, fx["cfg"], fx["x"], fx["t"], ctx)
+    (dctx,) = torch.autograd.grad((out * fx["dout"]).sum(), [ctx])
+    assert torch.allclose(out, fx["out"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(dctx, fx["dcontext"], atol=2e-5, rtol=1e-4)
+
+
+def test_vae_encode(golden_dir):
+    fx = _load(golden_dir, "vae_mini.pt")
+    W = O.init_weights(O.vae_encoder_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
+    with torch.no_grad():
+        mom = O.vae_encode_moments(W, fx["cfg"], fx["x"])
+        z = O.vae_sample(mom, fx["noise"])
+    assert torch.allclose(mom, fx["moments"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(z, fx["z_scaled"], atol=2e-5, rtol=1e-4)
+
+
+def test_frnet(golden_dir):
+    fx = _load(golden_dir, "frnet_mini.pt")
+    W = O.init_weights(O.frnet_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
+    with torch.no_grad():
+        out = O.frnet_forward(W, fx["cfg"], fx["x"])
+    assert torch.allclose(out, fx["out"], atol=1e-4, rtol=1e-4)
+
+
+def test_clip_text_layers(golden_dir):
+    fx = _load(golden_dir, "clip_mini.pt")
+    W = O.init_weights(O.clip_param_shapes(fx["cfg"], fx["weight_prefix"]), seed=fx["weight_seed"])
+    emb = W[fx["weight_prefix"] + "embeddings.token_embedding.weight"][fx["tokens"]]
+    with torch.no_grad():
+        out = O.clip_encode(W, fx["cfg"], emb, fx["weight_prefix"])
+    assert torch.allclose(out, fx["last_hidden_state"], atol=2e-5, rtol=1e-4)
+
+
+def test_manager_forward_backward_and_ema(golden_dir):
+    """EmbeddingManagerId.forward (training) = warp/resize -> FR-net -> normalize -> MLP head -> basis -> EMA -> row surgery"""
+    fx = _load(golden_dir, "manager_mini.pt")
+    es, inner = fx["es"], fx["inner"]
+    P = "embedding_manager.meta_id_net."
+    W = O.init_weights(O.frnet_param_shapes(fx["fr_cfg"], P + "id_model."), seed=fx["fr_weight_seed"])
+    Wm = fx["Wm"].clone().requires_grad_(True); bm = fx["bm"].clone().requires_grad_(True)
+    W[P + "stylegan_mlp.net.0.weight"] = Wm; W[P + "stylegan_mlp.net.0.bias"] = bm
+    W["celeb_embeddings"] = fx["basis"]
+    assert fx["n_trainable"] == Wm.numel() + bm.numel()
+    faces = torch.cat(fx["faces"].chunk(2, -1), 0)
+    with torch.no_grad():
+        _, small = O.face_warp_resize(faces, fx["fr_cfg"]["in_size"])
+        v = F.normalize(O.frnet_forward(W, fx["fr_cfg"], small, P + "id_model."), dim=-1)
+    coef, z = O.celeb_head(W, v, es, inner)
+    B = fx["tokens"].shape[0]
+    table = O.formula_table(fx["vocab"], 768)
+    emb_in = table[fx["tokens"]]
+    out = torch.stack([O.shift_rows(fx["tokens"][b], emb_in[b], z[b], 48136, es) for b in range(B)])
+    assert torch.allclose(out, fx["out"], atol=1e-5, rtol=1e-4)
+    dout = O.formula_table(out.shape[0] * out.shape[1], out.shape[2], 0.9).reshape(out.shape) * 50.0
+    gW, gb = torch.autograd.grad((out * dout).sum(), [Wm, bm])
+    assert torch.allclose(gW, fx["gW"], atol=1e-6, rtol=2e-3)
+    assert torch.allclose(gb, fx["gb"], atol=1e-6, rtol=2e-3)
+    id_coef, id_emb = fx["id_coef0"].clone(), fx["id_emb0"].clone()
+    for b in range(B):
+        i = int(fx["ids"][b, 0])
+        id_emb[i] = 0.99 * id_emb[i] + 0.01 * z[b].detach().reshape(-1)
+        id_coef[i] = 0.99 * id_coef[i] + 0.01 * coef[b].detach().reshape(-1)
+    assert torch.allclose(id_coef, fx["id_coef1"], atol=1e-6)
+    assert torch.allclose(id_emb, fx["id_emb1"], atol=1e-6)
+
+
+def test_adamw_matches_torch():
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(64, 8, generator=g)
+    ref = torch.nn.Parameter(p.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-2)
+    m = torch.zeros_like(p); v = torch.zeros_like(p)
+    for step in range(1, 6):
+        grad = torch.randn(64, 8, generator=g)
+        ref.grad = grad.clone()
+        opt.step()
+        p, m, v = O.adamw_step(p, grad, m, v, step, 1e-2)
+        assert torch.allclose(p, ref.detach(), atol=1e-6, rtol=1e-5)
