@@ -1,0 +1,164 @@
+#!/usr/bin/env python
+"""bench.py — CelebBasis personalization training step on MI355X (BASELINE.json metric, config 2).
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full personalization training step of ONE identity at SD v1-4 / 512x512 / bs=1 / fp32:
+VAE encode -> FR-net + MLP + basis (+EMA) -> CLIP text (with the manager hook) -> q_sample -> UNet fwd -> MSE ->
+input-gradient backward through UNet and CLIP -> dW/db -> AdamW. Nothing is cached or skipped inside the timed region.
+Inputs (a replay stream of synthetic batches) are resident in HBM before the timed region starts.
+With N > 1 every rank personalises its own identity (SURVEY.md §8 e: independent units, no data-path collective); the only
+collective is the checkpoint-merge all_gather after the timed region. `value` = steps of all ranks / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, measured live with HIP
+events around every GEMM-class launch in a separate profiled step) and `cpu_baseline` (the CPU oracle, a from-scratch
+restatement = kind "port", timed on this box's host cores on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+STEPS_PER_IDENTITY = 800           # aigc_id.yaml:135 max_steps
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no GPU is visible")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+
+    from celebbasis_amd import build as cb_build
+    if rank == 0:
+        cb_build.build(verbose=False)
+    if world > 1:
+        dist.barrier()
+    from celebbasis_amd import lib, synthetic, sharding
+
+    # ---- seeded synthetic weights at the true SD v1-4 shapes (no checkpoints offline), same on every rank
+    shapes = synthetic.trainer_shapes()
+    state = synthetic.synthetic_state(shapes, seed=0)
+    ctx = lib.Context()
+    tr = lib.Trainer(ctx, lib.WeightTable(state))
+    n_params = sum(v.numel() for v in state.values())
+
+    identity = 1 + (rank % 9)
+    batches = [synthetic.synthetic_batch(1, step=s, device=dev, identity=identity, seed=23 + rank) for s in range(args.batches)]
+    lr = 5e-3       # base_learning_rate 5e-3 * bs 1 * ngpu 1 * accum 1 (main_id_embed.py:767-786)
+
+    def run(i):
+        b = batches[i % len(batches)]
+        tr.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr)
+
+    for i in range(args.warmup):
+        run(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        run(args.warmup + i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    loss = float(tr.get_state("loss")[0])
+
+    # ---- checkpoint merge (outside the timed region): the one collective of the job
+    coef = tr.get_state("id_coefficients").reshape(10, -1)
+    merged = sharding.gather_identity_blocks([identity], coef[identity:identity + 1], 10, device=dev)
+
+    out = None
+    if rank == 0:
+        # ---- live roofline: one extra step with a HIP-event pair around every GEMM-class launch
+        ctx.reset_stats()
+        ctx.profile_begin()
+        run(0)
+        prof = ctx.profile_end()
+        st = ctx.stats()
+        tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
+        dom = max(prof, key=lambda p: p["ms"])
+        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 5),
+                        algorithmic_gflop_per_step=round(dom["flops"] / 1e9, 1),
+                        all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
+                                              achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
+                        by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
+                                   for p in sorted(prof, key=lambda p: -p["ms"])])
+        ms_per_step = elapsed / args.steps * 1e3
+        value = world * args.steps / elapsed
+        out = {
+            "metric": "personalization train steps/sec @ SD v1-4 512x512 bs=1", "value": round(value, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: single identity, SD v1-4 512x512, bs=1, fp32, full step "
+                                   "(VAE encode + FR-net + CLIP fwd/bwd + UNet fwd/bwd + AdamW)",
+                       "identities_per_gpu": 1, "global_batch": world, "latent": "4x64x64", "tokens": 77,
+                       "parallelism": f"identity-sharded x{world} (no data-path collective)", "params_frozen": int(n_params),
+                       "trainable": 525312, "kernel_launches_per_step": st["launches"]},
+            "identities_per_sec": round(value / STEPS_PER_IDENTITY, 6),
+            "step_tflop": round(st["gemm_flops"] / 1e12, 4),
+            "step_tflops_per_gpu": round(st["gemm_flops"] / 1e12 / (ms_per_step * 1e-3), 2),
+            "loss": loss,
+            "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()),
+            "roofline": roofline,
+        }
+    # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import cb_oracle as O
+        cores = os.cpu_count() or 1
+        torch.set_num_threads(cores)
+        cpu_state = {k: v for k, v in state.items()}
+        st_cpu = O.TrainState(cpu_state)
+        times = []
+        for s in range(args.cpu_steps):
+            b = {k: v.cpu() for k, v in batches[s % len(batches)].items()}
+            c0 = time.perf_counter()
+            O.train_step(cpu_state, st_cpu, b, lr)
+            times.append(time.perf_counter() - c0)
+        best = min(times)
+        out["cpu_baseline"] = {"value": round(1.0 / best, 5), "unit": "steps/s", "cores": torch.get_num_threads(), "kind": "port",
+                               "sample": f"{args.cpu_steps} full steps of the same workload (oracle/cb_oracle.train_step, torch-CPU fp32), "
+                                         f"best of {args.cpu_steps}: {best:.2f} s/step"}
+    elif rank == 0:
+        out["cpu_baseline"] = None
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

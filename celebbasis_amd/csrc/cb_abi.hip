@@ -100,6 +100,44 @@ int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems
     CB_END
 }
 
+int cb_ctx_profile_begin(cb_ctx* ctx) {
+    CB_TRY
+    require(ctx, "ctx");
+    CB_CHECK(!ctx->c.dry, CB_ERR_STATE, "profiling needs a real device context");
+    for (auto& r : ctx->c.prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
+    ctx->c.prof.recs.clear();
+    ctx->c.prof.on = true;
+    CB_END
+}
+int cb_ctx_profile_end(cb_ctx* ctx, char* json, int64_t cap) {
+    CB_TRY
+    require(ctx, "ctx"); require(json, "json");
+    Profiler& P = ctx->c.prof;
+    P.on = false;
+    CB_HIP(hipStreamSynchronize(ctx->c.stream));
+    std::vector<double> ms(P.names.size(), 0.0), fl(P.names.size(), 0.0);
+    std::vector<long> cnt(P.names.size(), 0);
+    for (auto& r : P.recs) {
+        float t = 0.f;
+        CB_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
+        ms[r.variant] += t; fl[r.variant] += r.flops; cnt[r.variant]++;
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+    }
+    P.recs.clear();
+    std::string out = "[";
+    for (size_t i = 0; i < P.names.size(); ++i) {
+        if (!cnt[i]) continue;
+        char buf[256];
+        snprintf(buf, sizeof buf, "%s{\"kernel\":\"%s\",\"launches\":%ld,\"flops\":%.6e,\"ms\":%.6f}", out.size() > 1 ? "," : "",
+                 P.names[i].c_str(), cnt[i], fl[i], ms[i]);
+        out += buf;
+    }
+    out += "]";
+    CB_CHECK((int64_t)out.size() + 1 <= cap, CB_ERR_ARG, "profile_end: buffer too small (%zu needed)", out.size() + 1);
+    memcpy(json, out.c_str(), out.size() + 1);
+    CB_END
+}
+
 // ------------------------------------------------------------------ weight table
 int cb_wtab_create(cb_wtab** out) {
     CB_TRY

@@ -9,6 +9,7 @@
 #include <string>
 #include <stdexcept>
 #include <cstdarg>
+#include <vector>
 
 namespace cb {
 
@@ -38,10 +39,23 @@ struct Stats {
     long   launches = 0;
     long   gemm_launches = 0;
 };
+// per-launch HIP-event timing of the GEMM-class kernels (bench.py's live roofline measurement)
+struct ProfRec { int variant; double flops; hipEvent_t e0, e1; };
+struct Profiler {
+    bool on = false;
+    std::vector<ProfRec> recs;
+    std::vector<std::string> names;
+    int id_of(const std::string& n) {
+        for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
+        names.push_back(n);
+        return (int)names.size() - 1;
+    }
+};
 struct Launch {
     hipStream_t stream = nullptr;
     bool dry = false;
     Stats* stats = nullptr;
+    Profiler* prof = nullptr;
     void count(long n = 1) const { if (stats) stats->launches += n; }
 };
 

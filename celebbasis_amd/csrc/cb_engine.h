@@ -63,9 +63,10 @@ struct Ctx {
     Arena arena;                 // per-step activations
     Pool pool;                   // persistent
     Stats stats;
+    Profiler prof;
     bool debug_taps = false;
     std::map<std::string, std::pair<const float*, long>> taps;
-    Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; return L; }
+    Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; return L; }
     void ensure_arena(size_t bytes);
     // upload a table entry to the device (raw copy); dims are checked against `expect` (-1 = any)
     float* upload(const WTab& wt, const std::string& name, std::initializer_list<int64_t> expect);

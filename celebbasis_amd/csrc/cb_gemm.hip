@@ -398,6 +398,16 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     ka.b_vec = aligned16(a.B) && (a.ldb % 4 == 0) && strides_ok(a.sBb, a.sBh);
 
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    ProfRec rec; bool prof = L.prof && L.prof->on;
+    if (prof) {
+        static const char* kn[3] = {"ROW", "COL", "CONV"};
+        char nm[96];
+        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s>%s", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], pl.splitk > 1 ? "+splitk" : "");
+        rec.variant = L.prof->id_of(nm);
+        rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+        CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
+        CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
     if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka);
     else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka);
     else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka);
@@ -411,6 +421,7 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, L.stream, ka);
         CB_HIP(hipGetLastError());
     }
+    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
 }
 
 }  // namespace cb

@@ -1,0 +1,144 @@
+"""Host-side mirror of ldm/modules/embedding_manager.py `EmbeddingManagerId` (reference :187-532): same constructor keywords
+(aigc_id.yaml:23-37), same public surface (`forward`, `save`, `load`, `trainable_parameters`, `embedding_parameters`,
+`embedding_neg_loss`, `id_coefficients`, `id_embeddings`) and the same on-disk format. In training the whole forward
+(FR-net -> MLP -> L2-norm -> basis -> EMA -> row surgery) runs fused inside cb_trainer_step; this class owns the state."""
+import ctypes as C
+
+import torch
+
+from ... import lib as _lib
+from .frozen import context_for
+from .id_embedding.iresnet import IResNet
+
+# single-token CLIP BPE ids quoted by the reference itself (modules.py:198-262, 02_start_test.sh:106-107)
+KNOWN_TOKENS = {"sks": 48136, "ks": 662, "ata": 4236, "tre": 6033, "face": 1710, "a": 320, "photo": 1125, "of": 539}
+
+
+class MetaIdNet:
+    """state holder for meta_net.py:103-377: frozen id_model + the trainable EqualLinear (`stylegan_mlp.net.0`)"""
+
+    def __init__(self, inner_dim=512, num_embeds_per_token=2, heads=1, fr_dim=512, mlp_depth=1, generator=None):
+        assert heads == 1 and mlp_depth == 1, "the shipped configuration (meta_heads 1, meta_mlp_depth 1) is the hot path"
+        self.id_model = IResNet((3, 13, 30, 3))
+        out = inner_dim * num_embeds_per_token * heads
+        self.weight = torch.randn(out, fr_dim, generator=generator)      # EqualLinear init (meta_net.py:30-32)
+        self.bias = torch.zeros(out)
+
+    def trainable_state_dict(self):
+        return {"stylegan_mlp.net.0.weight": self.weight, "stylegan_mlp.net.0.bias": self.bias}
+
+    def load_trainable_state_dict(self, sd):
+        self.weight = sd["stylegan_mlp.net.0.weight"].float().clone()
+        self.bias = sd["stylegan_mlp.net.0.bias"].float().clone()
+
+
+class EmbeddingManagerId:
+    def __init__(self, embedder, placeholder_strings=None, initializer_words=None, max_ids=10, num_embeds_per_token=1,
+                 momentum=0.9, meta_mlp_depth=2, loss_type=None, meta_inner_dim=512, meta_heads=1, use_rm_mlp=False,
+                 test_mode="coefficient", save_fp16=True, **kwargs):
+        if use_rm_mlp:
+            raise NotImplementedError("use_rm_mlp (ablation switch, meta_net.py:173-175) is not on the default hot path")
+        if loss_type not in (None, "none"):
+            raise NotImplementedError("only loss_type 'none' (aigc_id.yaml:31) is on the hot path")
+        assert test_mode in ("coefficient", "embedding", "image")
+        self.embedder = embedder
+        self.placeholder_strings = list(placeholder_strings or ["sks"])
+        self.max_ids, self.num_es, self.meta_heads = max_ids, num_embeds_per_token, meta_heads
+        self.momentum, self.test_mode, self.save_fp16, self.loss_type = momentum, test_mode, save_fp16, loss_type
+        self.token_dim = embedder.cfg["width"] if hasattr(embedder, "cfg") else 768
+        self.inner_dim = meta_inner_dim
+        self.training = True
+        self.string_to_token_dict = {}
+        for s in self.placeholder_strings:
+            self.string_to_token_dict[s] = self._token_for(s)
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        self.meta_id_net = MetaIdNet(meta_inner_dim, num_embeds_per_token, meta_heads, mlp_depth=meta_mlp_depth, generator=g)
+        # dictionaries (embedding_manager.py:229-231, 239-253); embeddings start at the initializer word when available
+        self.id_coefficients = [torch.randn(num_embeds_per_token, meta_heads, meta_inner_dim, generator=g)] * max_ids
+        self.id_embeddings = [torch.zeros(num_embeds_per_token * meta_heads, self.token_dim) for _ in range(max_ids)]
+        self.celeb_embeddings = None
+
+    def _token_for(self, s):
+        try:
+            ids = self.embedder.tokenize(s)
+        except RuntimeError:
+            return KNOWN_TOKENS.get(s)
+        assert int((ids != 49407).sum()) == 2, f"String '{s}' maps to more than a single token"   # embedding_manager.py:18-24
+        return int(ids[0, 1])      # None for strings whose id is unknown offline (only [0] is used when num_ids == 1)
+
+    # ---- reference API
+    def embedding_parameters(self):
+        return []
+
+    def trainable_parameters(self):
+        return [self.meta_id_net.weight, self.meta_id_net.bias]
+
+    def embedding_neg_loss(self):
+        return 0.0
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def save(self, ckpt_path):
+        """embedding_manager.py:396-410 — {"id_coefficients": [max_ids x (es, h, inner)]} (fp16 when save_fp16)"""
+        cast = (lambda x: x.detach().cpu().half()) if self.save_fp16 else (lambda x: x.detach().cpu().float())
+        d = {}
+        if self.test_mode == "coefficient":
+            d["id_coefficients"] = [cast(x) for x in self.id_coefficients]
+        if self.test_mode == "embedding":
+            d["id_embeddings"] = [cast(x) for x in self.id_embeddings]
+        if self.test_mode == "image":
+            d["meta_id_net"] = {k: v.detach().cpu() for k, v in self.meta_id_net.trainable_state_dict().items()}
+        torch.save(d, ckpt_path)
+
+    def load(self, ckpt_path):
+        """embedding_manager.py:412-426"""
+        ckpt = torch.load(ckpt_path, map_location="cpu", weights_only=False)
+        if ckpt.get("id_coefficients") is not None:
+            self.id_coefficients = [x.float() for x in ckpt["id_coefficients"]]
+        if ckpt.get("id_embeddings") is not None:
+            self.id_embeddings = [x.float() for x in ckpt["id_embeddings"]]
+        if ckpt.get("meta_id_net") is not None:
+            self.meta_id_net.load_trainable_state_dict(ckpt["meta_id_net"])
+
+    # ---- inference-time hook (embedding_manager.py:312-319 test branch + 464-475): coefficients -> embedding -> row surgery
+    def forward(self, tokenized_text, embedded_text, face_image=None, img_ori=None, celeb_embeddings=None):
+        if img_ori is None:
+            return embedded_text
+        if self.training:
+            raise RuntimeError("the training-mode manager forward is fused into the native training step "
+                               "(LatentDiffusion.training_step -> cb_trainer_step); call it through the trainer")
+        dev = embedded_text.device
+        ctx = context_for(dev)
+        L = _lib.load()
+        B, T, W = embedded_text.shape
+        es, K = self.num_es, self.inner_dim
+        basis = (celeb_embeddings if celeb_embeddings is not None else self.celeb_embeddings).to(dev).float().contiguous()
+        ids = img_ori["ids"]
+        z = torch.empty(B, es, W, device=dev)
+        if self.test_mode == "coefficient":
+            for b in range(B):
+                coef = self.id_coefficients[int(ids[b][0])].to(dev).float().reshape(es, K).contiguous()
+                for e in range(es):      # z[e] = coef[e] @ basis[e,1:] + basis[e,0]   (einsum 'e h k, e k c -> e h c')
+                    d = _lib.GemmDesc()
+                    d.A = coef[e].data_ptr(); d.B = basis[e, 1:].data_ptr(); d.C = z[b, e].data_ptr()
+                    d.M, d.N, d.K = 1, W, K
+                    d.lda, d.ldb, d.ldc = K, W, W
+                    d.a_layout, d.b_layout, d.batch = 0, 1, 1
+                    d.bias = basis[e, 0].data_ptr(); d.alpha, d.beta = 1.0, 0.0
+                    _lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+        else:
+            for b in range(B):
+                z[b] = self.id_embeddings[int(ids[b][0])].to(dev).reshape(es, W)
+        out = torch.empty_like(embedded_text)
+        mp = torch.empty(B * T, dtype=torch.int32, device=dev)
+        ph = self.string_to_token_dict[self.placeholder_strings[0]]
+        _lib.check(L.cb_row_surgery(ctx.h, _lib.ptr(embedded_text.contiguous()), _lib.ptr(z), _lib.ptr(tokenized_text.contiguous(), torch.int64),
+                                    _lib.ptr(out), C.c_void_p(mp.data_ptr()), B, T, W, es * self.meta_heads, ph))
+        return out
+
+    __call__ = forward

@@ -1,0 +1,79 @@
+"""Base of the host-side mirror classes: a frozen parameter container with the reference's state-dict keys whose
+compute lives in libcelebbasis_hip.so. It deliberately has no torch-op forward: without the native library it raises."""
+import torch
+
+from ... import lib as _lib
+
+_CTX = {}
+
+
+def context_for(device):
+    """one cb_ctx per (device, stream) the caller is on"""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("celebbasis_amd runs on an MI355X (gfx950) only: move inputs to the GPU "
+                           "(there is no CPU / PyTorch-eager fallback for the hot path)")
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    if key not in _CTX:
+        with torch.cuda.device(idx):
+            _CTX[key] = _lib.Context(idx)
+    return _CTX[key]
+
+
+class FrozenModule:
+    """parameters are plain tensors keyed by the reference state-dict names; all frozen (ddpm.py:491-500)"""
+
+    def __init__(self, shapes):
+        self._shapes = dict(shapes)
+        self._params = {}
+        self._native = None
+        self.training = False
+
+    # -- torch.nn.Module-like surface used by the reference's callers
+    def state_dict(self, prefix=""):
+        missing = [k for k in self._shapes if k not in self._params]
+        if missing:
+            raise RuntimeError(f"{type(self).__name__}: {len(missing)} parameters were never loaded (e.g. {missing[0]})")
+        return {prefix + k: v for k, v in self._params.items()}
+
+    def load_state_dict(self, sd, strict=True, prefix=""):
+        unexpected, loaded = [], 0
+        for k, v in sd.items():
+            if not k.startswith(prefix):
+                continue
+            name = k[len(prefix):]
+            if name not in self._shapes:
+                unexpected.append(k)
+                continue
+            if tuple(v.shape) != tuple(self._shapes[name]):
+                raise RuntimeError(f"size mismatch for {k}: checkpoint {tuple(v.shape)} vs model {self._shapes[name]}")
+            self._params[name] = v.detach().to(torch.float32).contiguous()
+            loaded += 1
+        missing = [prefix + k for k in self._shapes if k not in self._params]
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict: missing {missing[:3]}… unexpected {unexpected[:3]}…")
+        self._native = None
+        return missing, unexpected
+
+    def parameters(self):
+        return iter(())          # nothing here is trainable
+
+    def eval(self):
+        self.training = False
+        return self
+
+    def train(self, mode=True):
+        self.training = mode
+        return self
+
+    def to(self, *a, **k):
+        return self
+
+    def native(self, device):
+        if self._native is None:
+            self._native = self._build(context_for(device))
+        return self._native
+
+    def _build(self, ctx):
+        raise NotImplementedError

@@ -73,7 +73,7 @@ class Batch(C.Structure):
 # every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
-    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
+    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
     "cb_q_sample", "cb_mse_loss", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
@@ -89,6 +89,7 @@ _ARGTYPES = {
     "cb_last_error": [], "cb_version": [],
     "cb_ctx_create": [_I, _P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
     "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
+    "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
     "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
     "cb_gemm": [_P, _P], "cb_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _I],
     "cb_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
@@ -196,6 +197,15 @@ class Context:
         out = torch.empty(n.value, dtype=torch.float32)
         check(load().cb_ctx_tap(self.h, name.encode(), C.c_void_p(out.data_ptr()), C.c_int64(n.value), C.byref(n)))
         return out
+
+    def profile_begin(self):
+        check(load().cb_ctx_profile_begin(self.h))
+
+    def profile_end(self):
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        check(load().cb_ctx_profile_end(self.h, buf, C.c_int64(len(buf))))
+        return json.loads(buf.value.decode())
 
     def close(self):
         if getattr(self, "h", None) is not None and self.h.value:

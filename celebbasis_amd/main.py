@@ -1,0 +1,168 @@
+"""CLI mirror of the reference's trainer harness main_id_embed.py (SURVEY §2 'Trainer harness'): same flags for the
+personalization run (`--base cfg.yaml -t --actual_resume sd.ckpt -n name --gpus 0, [--embedding_manager_ckpt …]`), the
+reference YAML consumed unchanged (its `target:` strings resolve to celebbasis_amd.ldm.* through install_ldm_alias()),
+the same LR rule lr = accum * ngpu * bs * base_lr (main_id_embed.py:767-786) and the same checkpoint cadence/format
+(embeddings_gs-{step}.pt every `every_n_train_steps`). PyTorch-Lightning is replaced by a plain loop; multi-GPU runs are one
+process per GPU (torchrun), identities sharded across ranks, coefficients merged with one all_gather at every save."""
+import argparse
+import os
+import random
+import sys
+
+import torch
+import yaml
+
+
+def load_config(paths, dotlist=()):
+    """OmegaConf.load/merge + `key=value` dotlist (main_id_embed.py:588-592) on plain dicts"""
+    def merge(a, b):
+        for k, v in b.items():
+            if isinstance(v, dict) and isinstance(a.get(k), dict):
+                merge(a[k], v)
+            else:
+                a[k] = v
+        return a
+    cfg = {}
+    for p in paths:
+        with open(p) as f:
+            merge(cfg, yaml.safe_load(f))
+    for item in dotlist:
+        key, val = item.split("=", 1)
+        node = cfg
+        parts = key.split(".")
+        for k in parts[:-1]:
+            node = node.setdefault(k, {})
+        node[parts[-1]] = yaml.safe_load(val)
+    return cfg
+
+
+class DataModuleFromConfig:
+    """main_id_embed.py:217-292: `data.params.{batch_size, train, validation}` -> dataloaders"""
+
+    def __init__(self, batch_size, train=None, validation=None, test=None, num_workers=0, wrap=False, **ignored):
+        from .ldm.util import instantiate_from_config
+        self.batch_size, self.num_workers = batch_size, num_workers
+        self.datasets = {}
+        if train is not None:
+            self.datasets["train"] = instantiate_from_config(train)
+        if validation is not None:
+            self.datasets["validation"] = instantiate_from_config(validation)
+
+    @staticmethod
+    def collate(samples):
+        out = dict(image=torch.stack([s["image"] for s in samples]), caption=[s["caption"] for s in samples],
+                   id_idx=torch.tensor([s["id_idx"] for s in samples]), img_idx=torch.tensor([s["img_idx"] for s in samples]))
+        out["image_ori"] = dict(faces=torch.stack([s["image_ori"]["faces"] for s in samples]),
+                                ids=torch.stack([s["image_ori"]["ids"] for s in samples]),
+                                num_ids=torch.tensor([s["image_ori"]["num_ids"] for s in samples]))
+        return out
+
+    def train_dataloader(self):
+        return torch.utils.data.DataLoader(self.datasets["train"], batch_size=self.batch_size, shuffle=True,
+                                           num_workers=self.num_workers, collate_fn=self.collate)
+
+
+def get_parser():
+    p = argparse.ArgumentParser(description="CelebBasis personalization on MI355X (flags of main_id_embed.py:47-178)")
+    p.add_argument("-n", "--name", type=str, default="celebbasis")
+    p.add_argument("-b", "--base", nargs="*", default=[], metavar="base_config.yaml")
+    p.add_argument("-t", "--train", action="store_true")
+    p.add_argument("-s", "--seed", type=int, default=23)
+    p.add_argument("-l", "--logdir", type=str, default="logs")
+    p.add_argument("--actual_resume", type=str, default=None, help="Stable Diffusion checkpoint (.ckpt / .safetensors)")
+    p.add_argument("--embedding_manager_ckpt", type=str, default="")
+    p.add_argument("--celeb_basis", type=str, default=None, help="celeb_basis.pt (es, 1+K, 768), the format written by extract_pt.py")
+    p.add_argument("--fr_ckpt", type=str, default="./weights/glint360k_cosface_r100_fp16_0.1/backbone.pth")
+    p.add_argument("--data_root", type=str, default=None)
+    p.add_argument("--gpus", type=str, default="0,")
+    p.add_argument("--max_steps", type=int, default=None)
+    p.add_argument("--synthetic", action="store_true", help="seeded random weights at the true shapes (no checkpoints needed)")
+    return p
+
+
+def load_sd_checkpoint(path):
+    """main_id_embed.py:25-44: .ckpt (torch.load -> ['state_dict']) or .safetensors"""
+    if path.endswith(".safetensors"):
+        from safetensors.torch import load_file
+        return load_file(path)
+    sd = torch.load(path, map_location="cpu", weights_only=False)
+    return sd.get("state_dict", sd)
+
+
+def main(argv=None):
+    opt, unknown = get_parser().parse_known_args(argv)
+    from . import install_ldm_alias, sharding
+    install_ldm_alias()
+    from .ldm.util import instantiate_from_config
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    random.seed(opt.seed); torch.manual_seed(opt.seed)                      # seed_everything(opt.seed) main_id_embed.py:586
+    config = load_config(opt.base, [u for u in unknown if "=" in u])
+    if not torch.cuda.is_available():
+        raise SystemExit("celebbasis_amd.main needs an MI355X (gfx950); there is no CPU training path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+    model = instantiate_from_config(config["model"])
+    if opt.synthetic:
+        from . import synthetic
+        model.load_state_dict(synthetic.synthetic_state(synthetic.trainer_shapes(), seed=0))
+    else:
+        sd = load_sd_checkpoint(opt.actual_resume)
+        fr = torch.load(opt.fr_ckpt, map_location="cpu", weights_only=False)
+        sd.update({"embedding_manager.meta_id_net.id_model." + k: v.float() for k, v in fr.items()})
+        if opt.celeb_basis:
+            sd["celeb_embeddings"] = torch.load(opt.celeb_basis, map_location="cpu", weights_only=False)
+        model.load_state_dict(sd, strict=False)
+    if opt.embedding_manager_ckpt:
+        model.embedding_manager.load(opt.embedding_manager_ckpt)
+    data_cfg = config["data"]["params"]
+    if opt.data_root:
+        for split in ("train", "validation"):
+            if split in data_cfg:
+                data_cfg[split]["params"]["pickle_path"] = os.path.join(opt.data_root, "ffhq.pickle")
+    # identity sharding: each rank personalises its own subset (SURVEY §8 e); the frozen weights are replicated
+    all_ids = list(data_cfg["train"]["params"].get("specific_ids") or range(1, data_cfg["train"]["params"].get("num_ids", 1) + 1))
+    mine = [all_ids[i] for i in sharding.identities_for_rank(len(all_ids), rank, world)]
+    data_cfg["train"]["params"]["specific_ids"] = mine or all_ids[:1]
+    data = DataModuleFromConfig(**data_cfg)
+    bs, base_lr = data_cfg["batch_size"], config["model"]["base_learning_rate"]
+    model.learning_rate = 1 * 1 * bs * base_lr       # accumulate_grad_batches * ngpu(per identity) * bs * base_lr
+    lcfg = config.get("lightning", {})
+    max_steps = opt.max_steps or lcfg.get("trainer", {}).get("max_steps", 800)
+    every = lcfg.get("modelcheckpoint", {}).get("params", {}).get("every_n_train_steps", 200)
+    ckptdir = os.path.join(opt.logdir, opt.name, "checkpoints")
+    model.train()
+    step = 0
+    while step < max_steps:
+        for batch in data.train_dataloader():
+            batch["image"] = batch["image"].to(dev)
+            model.training_step(batch, step)
+            step += 1
+            if step % every == 0 or step == max_steps:
+                save_merged(model, ckptdir, all_ids, mine, rank, world, sharding)
+                if rank == 0:
+                    print(f"[celebbasis_amd] step {step}/{max_steps} loss {model.last_loss():.5f} -> {ckptdir}", flush=True)
+            if step >= max_steps:
+                break
+
+
+def save_merged(model, ckptdir, all_ids, mine, rank, world, sharding):
+    """gather every rank's identity coefficients (4 KiB each) and let rank 0 write the reference format"""
+    model.sync_manager_from_trainer()
+    em = model.embedding_manager
+    if world > 1:
+        blocks = torch.stack([em.id_coefficients[i].reshape(-1) for i in mine]) if mine else torch.zeros(0, em.num_es * em.inner_dim)
+        merged = sharding.gather_identity_blocks(mine, blocks, em.max_ids)
+        for i in all_ids:
+            em.id_coefficients[i] = merged[i].reshape(em.num_es, em.meta_heads, em.inner_dim)
+    if rank == 0:
+        os.makedirs(ckptdir, exist_ok=True)
+        em.save(os.path.join(ckptdir, "embeddings.pt"))
+        em.save(os.path.join(ckptdir, f"embeddings_gs-{model.global_step}.pt"))
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,11 @@ int cb_ctx_reset_stats(cb_ctx* ctx);
 int cb_ctx_set_debug_taps(cb_ctx* ctx, int enable);
 int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);
 
+/* per-launch HIP-event timing of the GEMM-class kernels between begin/end (events are recorded on the context stream);
+ * profile_end writes a JSON array [{"kernel": name, "launches": n, "flops": algorithmic 2MNK sum, "ms": summed duration}] */
+int cb_ctx_profile_begin(cb_ctx* ctx);
+int cb_ctx_profile_end(cb_ctx* ctx, char* json, int64_t cap);
+
 /* ---- weight table: mirrors a torch state_dict (names = the reference's state-dict keys) */
 int cb_wtab_create(cb_wtab** out);
 int cb_wtab_add(cb_wtab* wt, const char* name, const float* data, int on_device, int ndim, const int64_t* dims);

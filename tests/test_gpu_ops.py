@@ -1,0 +1,334 @@
+"""GPU parity tests, op level: every HIP kernel family called THROUGH THE C ABI (celebbasis_amd.lib -> libcelebbasis_hip.so)
+against plain torch fp32 ops evaluated on the CPU. Tolerance: fp32 round-off class, stated per test as
+max|hip - ref| <= tol * max|ref| (the reductions differ in order from torch's, nothing else)."""
+import ctypes as C
+import json
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+REPORT = {}
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def cb(built_lib):
+    from celebbasis_amd import lib
+    ctx = lib.Context()
+    yield lib, ctx
+    ctx.sync()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/ops_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def close(name, got, ref, tol):
+    got = got.detach().float().cpu(); ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (name, got.shape, ref.shape)
+    assert torch.isfinite(got).all(), f"{name}: non-finite output"
+    err = (got - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-30)
+    REPORT[name] = dict(max_abs_err=err, ref_max=scale, rel=err / scale, tol=tol)
+    assert err <= tol * scale, f"{name}: max abs err {err:.3e} vs ref max {scale:.3e} (rel {err / scale:.3e} > {tol})"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+# ------------------------------------------------------------------------------------------------ GEMM
+@pytest.mark.parametrize("M,N,K,al,bl,batch,extra", [
+    (256, 192, 320, 0, 0, 1, "bias"),
+    (77, 40, 96, 0, 0, 3, "none"),          # ragged M/N, small K
+    (4096, 320, 320, 0, 0, 1, "bias+res"),
+    (64, 1280, 11520, 0, 0, 1, "bias"),     # split-K path (deep 8x8 conv shape)
+    (300, 77, 40, 0, 0, 8, "alpha"),        # QK^T-like: K=40 (not a multiple of 16)
+    (300, 40, 77, 0, 1, 8, "none"),         # PV-like: B is [K][N]
+    (77, 40, 300, 1, 1, 8, "beta"),         # dK/dV-like: both operands K-strided, K=300
+    (130, 66, 50, 1, 0, 2, "none"),
+    (1, 1280, 1280, 0, 0, 1, "bias"),       # single row through the GEMM kernel
+])
+def test_gemm(cb, M, N, K, al, bl, batch, extra):
+    lib, ctx = cb
+    A = rnd(batch, M, K, seed=1); B = rnd(batch, K, N, seed=2)
+    bias = rnd(N, seed=3) if "bias" in extra else None
+    R = rnd(batch, M, N, seed=4) if "res" in extra else None
+    C0 = rnd(batch, M, N, seed=5)
+    alpha = 0.37 if "alpha" in extra else 1.0
+    beta = 1.0 if "beta" in extra else 0.0
+    ref = alpha * torch.matmul(A, B)
+    if bias is not None:
+        ref = ref + bias
+    if R is not None:
+        ref = ref + R
+    ref = ref + beta * C0
+    # memory layouts: ROW = [rows][K] (K contiguous); COL = [K][rows]
+    Ad = (A if al == 0 else A.transpose(1, 2)).contiguous().to(_dev())
+    Bd = (B.transpose(1, 2) if bl == 0 else B).contiguous().to(_dev())
+    Cd = C0.clone().to(_dev())
+    d = lib.GemmDesc()
+    d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+    d.M, d.N, d.K = M, N, K
+    d.lda = K if al == 0 else M
+    d.ldb = K if bl == 0 else N
+    d.ldc = N
+    d.a_layout, d.b_layout, d.batch = al, bl, batch
+    d.strideA, d.strideB, d.strideC = M * K, K * N, M * N
+    if bias is not None:
+        bd = bias.to(_dev()); d.bias = bd.data_ptr()
+    if R is not None:
+        Rd = R.to(_dev()); d.R = Rd.data_ptr(); d.ldr = N; d.strideR = M * N
+    d.alpha, d.beta = alpha, beta
+    lib.check(lib.load().cb_gemm(ctx.h, C.byref(d)))
+    ctx.sync()
+    close(f"gemm[{M}x{N}x{K},a{al}b{bl},batch{batch},{extra}]", Cd, ref, 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ conv
+MODES = {"same": 0, "down": 1, "down_asym": 2, "up": 3, "s2_1x1": 4}
+
+
+def torch_conv(x_nchw, w, b, mode):
+    if mode == "same":
+        return F.conv2d(x_nchw, w, b, 1, w.shape[-1] // 2)
+    if mode == "down":
+        return F.conv2d(x_nchw, w, b, 2, 1)
+    if mode == "down_asym":
+        return F.conv2d(F.pad(x_nchw, (0, 1, 0, 1)), w, b, 2, 0)
+    if mode == "up":
+        return F.conv2d(F.interpolate(x_nchw, scale_factor=2, mode="nearest"), w, b, 1, 1)
+    if mode == "s2_1x1":
+        return F.conv2d(x_nchw, w, b, 2, 0)
+    raise ValueError(mode)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,mode,extra", [
+    (2, 16, 16, 32, 64, 3, "same", "rowbias+res"),
+    (1, 64, 64, 320, 320, 3, "same", "none"),       # level-0 ResBlock conv
+    (1, 8, 8, 1280, 1280, 3, "same", "none"),       # level-3 conv: split-K
+    (2, 12, 10, 4, 32, 3, "same", "none"),          # conv_in: Cin = 4
+    (2, 12, 10, 3, 16, 3, "same", "none"),          # VAE / FR conv_in: Cin = 3 (scalar gather path)
+    (2, 12, 10, 32, 4, 3, "same", "none"),          # UNet out: Cout = 4
+    (2, 16, 16, 32, 48, 1, "same", "none"),         # 1x1
+    (2, 16, 16, 32, 32, 3, "down", "none"),
+    (2, 16, 16, 32, 32, 3, "down_asym", "none"),
+    (2, 8, 8, 32, 32, 3, "up", "none"),
+    (2, 14, 14, 32, 64, 1, "s2_1x1", "none"),
+])
+def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
+    lib, ctx = cb
+    L = lib.load()
+    x = rnd(N, Cin, H, W, seed=1); w = rnd(Cout, Cin, ks, ks, seed=2, scale=(Cin * ks * ks) ** -0.5); b = rnd(Cout, seed=3)
+    xr = x.clone().requires_grad_(True)
+    ref = torch_conv(xr, w, b, mode)
+    Ho, Wo = ref.shape[2], ref.shape[3]
+    rowbias = rnd(N, Cout, seed=4) if "rowbias" in extra else None
+    res = rnd(N, Cout, Ho, Wo, seed=5) if "res" in extra else None
+    if rowbias is not None:
+        ref = ref + rowbias[:, :, None, None]
+    if res is not None:
+        ref = ref + res
+    dy = rnd(N, Cout, Ho, Wo, seed=6)
+    nhwc = lambda t: t.permute(0, 2, 3, 1).contiguous().to(_dev())
+    xd = nhwc(x); wd = w.to(_dev()); bd = b.to(_dev())
+    wp = torch.empty(w.numel(), device=_dev()); wpd = torch.empty(w.numel(), device=_dev())
+    lib.check(L.cb_pack_conv_weight(ctx.h, lib.ptr(wd), lib.ptr(wp), Cout, Cin, ks, 0))
+    lib.check(L.cb_pack_conv_weight(ctx.h, lib.ptr(wd), lib.ptr(wpd), Cout, Cin, ks, 1))
+    y = torch.empty(N, Ho, Wo, Cout, device=_dev())
+    rbd = rowbias.to(_dev()) if rowbias is not None else None
+    rsd = nhwc(res) if res is not None else None
+    lib.check(L.cb_conv2d_fwd(ctx.h, lib.ptr(xd), lib.ptr(wp), lib.ptr(bd), lib.ptr(rbd), lib.ptr(rsd), lib.ptr(y), N, H, W, Cin,
+                              Cout, ks, MODES[mode]))
+    ctx.sync()
+    tag = f"conv[{mode},{N}x{H}x{W},{Cin}->{Cout},k{ks},{extra}]"
+    close(tag + ".fwd", y.permute(0, 3, 1, 2), ref, 2e-5)
+    if mode in ("same", "down", "up"):
+        (dx_ref,) = torch.autograd.grad((ref * dy).sum(), [xr])
+        dx0 = rnd(N, H, W, Cin, seed=7)
+        for beta in (0.0, 1.0):
+            dx = dx0.clone().to(_dev())
+            lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(nhwc(dy)), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
+            ctx.sync()
+            close(tag + f".dgrad(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 64, 320, 1, 1e-5), (1, 4096, 320, 1, 1e-5), (2, 100, 64, 0, 1e-6),
+                                             (1, 64, 2560, 1, 1e-5), (1, 5000, 128, 1, 1e-6), (2, 256, 960, 0, 1e-6)])
+def test_groupnorm(cb, N, HW, C, silu, eps):
+    lib, ctx = cb
+    L = lib.load()
+    x = rnd(N, HW, C, seed=1) * 2.0 + 3.0   # non-zero mean stresses the variance computation
+    gam = 1 + 0.1 * rnd(C, seed=2); bet = 0.1 * rnd(C, seed=3); dy = rnd(N, HW, C, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.group_norm(xr.permute(0, 2, 1), 32, gam, bet, eps)
+    if silu:
+        yr = F.silu(yr)
+    yr = yr.permute(0, 2, 1)
+    (dxr,) = torch.autograd.grad((yr * dy).sum(), [xr])
+    xd, gd, bd, dyd = x.to(_dev()), gam.to(_dev()), bet.to(_dev()), dy.to(_dev())
+    y = torch.empty_like(xd); stats = torch.empty(N * 32 * 2, device=_dev()); dx = torch.empty_like(xd)
+    lib.check(L.cb_groupnorm_silu_fwd(ctx.h, lib.ptr(xd), lib.ptr(gd), lib.ptr(bd), lib.ptr(y), lib.ptr(stats), N, HW, C, eps, silu))
+    lib.check(L.cb_groupnorm_silu_bwd(ctx.h, lib.ptr(xd), lib.ptr(dyd), lib.ptr(gd), lib.ptr(bd), lib.ptr(stats), lib.ptr(dx), N, HW, C, silu, 0.0))
+    ctx.sync()
+    tag = f"groupnorm[{N}x{HW}x{C},silu{silu}]"
+    close(tag + ".fwd", y, yr, 1e-5)
+    close(tag + ".bwd", dx, dxr, 5e-5)
+
+
+@pytest.mark.parametrize("rows,C", [(77, 768), (4096, 320), (256, 1280), (9, 64)])
+def test_layernorm(cb, rows, C):
+    lib, ctx = cb
+    L = lib.load()
+    x = rnd(rows, C, seed=1) + 0.5; gam = 1 + 0.1 * rnd(C, seed=2); bet = 0.1 * rnd(C, seed=3); dy = rnd(rows, C, seed=4)
+    xr = x.clone().requires_grad_(True)
+    yr = F.layer_norm(xr, (C,), gam, bet, 1e-5)
+    (dxr,) = torch.autograd.grad((yr * dy).sum(), [xr])
+    xd, gd, bd, dyd = x.to(_dev()), gam.to(_dev()), bet.to(_dev()), dy.to(_dev())
+    y = torch.empty_like(xd); stats = torch.empty(rows * 2, device=_dev()); dx = torch.empty_like(xd)
+    lib.check(L.cb_layernorm_fwd(ctx.h, lib.ptr(xd), lib.ptr(gd), lib.ptr(bd), lib.ptr(y), lib.ptr(stats), rows, C, 1e-5))
+    lib.check(L.cb_layernorm_bwd(ctx.h, lib.ptr(xd), lib.ptr(dyd), lib.ptr(gd), lib.ptr(stats), lib.ptr(dx), rows, C, 0.0))
+    ctx.sync()
+    close(f"layernorm[{rows}x{C}].fwd", y, yr, 1e-5)
+    close(f"layernorm[{rows}x{C}].bwd", dx, dxr, 2e-5)
+
+
+def test_geglu(cb):
+    lib, ctx = cb
+    L = lib.load()
+    M, D = 300, 160
+    x = rnd(M, 2 * D, seed=1) * 1.5; dy = rnd(M, D, seed=2)
+    xr = x.clone().requires_grad_(True)
+    a, g = xr.chunk(2, dim=-1)
+    yr = a * F.gelu(g)
+    (dxr,) = torch.autograd.grad((yr * dy).sum(), [xr])
+    xd, dyd = x.to(_dev()), dy.to(_dev())
+    y = torch.empty(M, D, device=_dev()); dx = torch.empty_like(xd)
+    lib.check(L.cb_geglu_fwd(ctx.h, lib.ptr(xd), lib.ptr(y), M, D))
+    lib.check(L.cb_geglu_bwd(ctx.h, lib.ptr(xd), lib.ptr(dyd), lib.ptr(dx), M, D))
+    ctx.sync()
+    close("geglu.fwd", y, yr, 1e-5)
+    close("geglu.bwd", dx, dxr, 1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def torch_attention(q, k, v, heads, scale, causal):
+    B, Nq, Cc = q.shape
+    d = Cc // heads
+    sp = lambda t: t.reshape(B, t.shape[1], heads, d).permute(0, 2, 1, 3)
+    s = torch.matmul(sp(q), sp(k).transpose(-1, -2)) * scale
+    if causal:
+        s = s + torch.full((Nq, k.shape[1]), torch.finfo(torch.float32).min).triu_(1)
+    return torch.matmul(s.softmax(-1), sp(v)).permute(0, 2, 1, 3).reshape(B, Nq, Cc)
+
+
+@pytest.mark.parametrize("B,Nq,Nk,Cc,heads,causal,fused", [
+    (2, 256, 256, 320, 8, 0, 1),     # self-attention d=40, fused QKV buffer
+    (1, 1024, 77, 640, 8, 0, 0),     # cross-attention, Nk=77, d=80
+    (2, 77, 77, 768, 12, 1, 1),      # CLIP causal
+    (1, 300, 300, 512, 1, 0, 1),     # VAE AttnBlock: one head, d=512
+    (1, 64, 77, 1280, 8, 0, 0),      # d=160
+])
+def test_attention(cb, B, Nq, Nk, Cc, heads, causal, fused):
+    lib, ctx = cb
+    L = lib.load()
+    d = Cc // heads
+    scale = d ** -0.5
+    q = rnd(B, Nq, Cc, seed=1); k = rnd(B, Nk, Cc, seed=2); v = rnd(B, Nk, Cc, seed=3); do = rnd(B, Nq, Cc, seed=4)
+    qr, kr, vr = (t.clone().requires_grad_(True) for t in (q, k, v))
+    oref = torch_attention(qr, kr, vr, heads, scale, causal)
+    dq, dk, dv = torch.autograd.grad((oref * do).sum(), [qr, kr, vr])
+    desc = lib.AttentionDesc()
+    if fused:
+        qkv = torch.cat([q, k, v], dim=-1).contiguous().to(_dev())
+        dqkv = torch.full_like(qkv, float("nan"))
+        desc.qbuf = desc.kvbuf = qkv.data_ptr(); desc.ldq = desc.ldkv = 3 * Cc
+        desc.q_off, desc.k_off, desc.v_off = 0, Cc, 2 * Cc
+        desc.dqbuf = desc.dkvbuf = dqkv.data_ptr()
+    else:
+        qd = q.to(_dev()); kv = torch.cat([k, v], dim=-1).contiguous().to(_dev())
+        dqd = torch.full_like(qd, float("nan")); dkv = torch.full_like(kv, float("nan"))
+        desc.qbuf = qd.data_ptr(); desc.ldq = Cc; desc.q_off = 0
+        desc.kvbuf = kv.data_ptr(); desc.ldkv = 2 * Cc; desc.k_off, desc.v_off = 0, Cc
+        desc.dqbuf = dqd.data_ptr(); desc.dkvbuf = dkv.data_ptr()
+    desc.B, desc.Nq, desc.Nk, desc.C, desc.heads = B, Nq, Nk, Cc, heads
+    desc.scale, desc.causal = scale, causal
+    out = torch.empty(B, Nq, Cc, device=_dev()); dod = do.to(_dev())
+    desc.out = out.data_ptr(); desc.dout = dod.data_ptr()
+    lib.check(L.cb_attention(ctx.h, C.byref(desc)))
+    ctx.sync()
+    tag = f"attention[B{B},{Nq}x{Nk},C{Cc},h{heads},causal{causal}]"
+    close(tag + ".out", out, oref, 2e-5)
+    if fused:
+        gq, gk, gv = dqkv[..., :Cc], dqkv[..., Cc:2 * Cc], dqkv[..., 2 * Cc:]
+    else:
+        gq, gk, gv = dqd, dkv[..., :Cc], dkv[..., Cc:]
+    close(tag + ".dq", gq, dq, 5e-5)
+    close(tag + ".dk", gk, dk, 5e-5)
+    close(tag + ".dv", gv, dv, 5e-5)
+
+
+# ------------------------------------------------------------------------------------------------ step glue vs the oracle
+def test_glue_ops_vs_oracle(cb, golden_dir):
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    L = lib.load()
+    fx = torch.load(os.path.join(golden_dir, "schedule.pt"), weights_only=False)
+    # timestep embedding
+    t = fx["temb_t"].to(_dev()); out = torch.empty(t.shape[0], 320, device=_dev())
+    lib.check(L.cb_timestep_embedding(ctx.h, lib.ptr(t, torch.int64), lib.ptr(out), t.shape[0], 320))
+    close("timestep_embedding", out, fx["temb"], 2e-4)   # cos/sin of arguments up to ~1e3: device libm vs host libm
+    # q_sample + mse
+    x0, eps, tt = fx["q_x0"], fx["q_eps"], fx["q_t"]
+    B, Cc, H, W = x0.shape
+    x0d = x0.permute(0, 2, 3, 1).contiguous().to(_dev()); xt = torch.empty_like(x0d)
+    sa, sb = fx["sqrt_alphas_cumprod"].to(_dev()), fx["sqrt_one_minus_alphas_cumprod"].to(_dev())
+    lib.check(L.cb_q_sample(ctx.h, lib.ptr(x0d), lib.ptr(eps.to(_dev())), lib.ptr(tt.to(_dev()), torch.int64), lib.ptr(sa), lib.ptr(sb),
+                            lib.ptr(xt), B, Cc, H * W))
+    close("q_sample", xt.permute(0, 3, 1, 2), fx["q_xt"], 1e-6)
+    pred = rnd(B, Cc, H, W, seed=9)
+    pr = pred.clone().requires_grad_(True)
+    lref = F.mse_loss(eps, pr, reduction="none").mean([1, 2, 3]).mean()
+    (gref,) = torch.autograd.grad(lref, [pr])
+    loss = torch.zeros(1, device=_dev()); dp = torch.empty_like(x0d)
+    lib.check(L.cb_mse_loss(ctx.h, lib.ptr(pred.permute(0, 2, 3, 1).contiguous().to(_dev())), lib.ptr(eps.to(_dev())), lib.ptr(loss),
+                            lib.ptr(dp), B, Cc, H * W))
+    close("mse.loss", loss, lref.reshape(1), 1e-5)
+    close("mse.grad", dp.permute(0, 3, 1, 2), gref, 1e-5)
+    # face warp + resize
+    Bf, S = 2, 96
+    faces = torch.rand(Bf, S, S, 6, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    cat = torch.cat(faces.chunk(2, -1), 0)
+    wref, sref = O.face_warp_resize(cat, 112)
+    warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
+    lib.check(L.cb_face_warp_resize(ctx.h, lib.ptr(faces.to(_dev())), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
+    close("face.warp", warped.permute(0, 3, 1, 2), wref, 2e-5)
+    close("face.resize", small.permute(0, 3, 1, 2), sref, 2e-5)
+    # row surgery: bit-exact against the reference golden cases (copies only)
+    for i, case in enumerate(torch.load(os.path.join(golden_dir, "shift_rows.pt"), weights_only=False)):
+        toks = case["tokens"][None].contiguous().to(_dev())
+        T, Cw = case["embedded"].shape
+        o = torch.empty(1, T, Cw, device=_dev()); mp = torch.empty(T, dtype=torch.int32, device=_dev())
+        lib.check(L.cb_row_surgery(ctx.h, lib.ptr(case["embedded"][None].contiguous().to(_dev())), lib.ptr(case["z"][None].contiguous().to(_dev())),
+                                   lib.ptr(toks, torch.int64), lib.ptr(o), C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], case["placeholder"]))
+        ctx.sync()
+        assert torch.equal(o[0].cpu(), case["out"]), f"row surgery case {i} is not bit-exact"
+    # AdamW, 5 steps
+    g = torch.Generator().manual_seed(0)
+    p = torch.randn(1000, generator=g); m = torch.zeros(1000); v = torch.zeros(1000)
+    pd, md, vd = p.to(_dev()), m.to(_dev()), v.to(_dev()); step = torch.zeros(1, dtype=torch.int32, device=_dev())
+    for s in range(1, 6):
+        gr = torch.randn(1000, generator=g)
+        p, m, v = O.adamw_step(p, gr, m, v, s, 1e-2)
+        lib.check(L.cb_adamw_step(ctx.h, lib.ptr(pd), lib.ptr(md), lib.ptr(vd), lib.ptr(gr.to(_dev())), 1000, C.c_void_p(step.data_ptr()),
+                                  1e-2, 0.9, 0.999, 1e-8, 1e-2))
+    close("adamw.p", pd, p, 1e-5)
+    assert int(step.item()) == 5
