@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=64, help="host threads for the CPU baseline (reported as `cores`)")
     ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
     args = ap.parse_args()
 
@@ -137,7 +138,7 @@ def main():
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import cb_oracle as O
-        cores = os.cpu_count() or 1
+        cores = min(args.cpu_threads, os.cpu_count() or 1)
         torch.set_num_threads(cores)
         cpu_state = {k: v for k, v in state.items()}
         st_cpu = O.TrainState(cpu_state)

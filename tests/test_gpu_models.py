@@ -35,6 +35,20 @@ def close(name, got, ref, tol):
     assert err <= tol * scale, f"{name}: max abs err {err:.3e} vs ref max {scale:.3e} (rel {err / scale:.3e} > {tol})"
 
 
+_KEEP = []
+
+
+def dv(t):
+    """device copy that stays referenced: a freed temporary's block can be refilled by the next pageable H2D copy before the
+    queued kernels have read it"""
+    t = t.contiguous().to(DEV)
+    _KEEP.append(t)
+    if len(_KEEP) > 48:
+        torch.cuda.synchronize()
+        del _KEEP[:24]
+    return t
+
+
 def load(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
@@ -47,8 +61,8 @@ def test_unet_mini_vs_reference_golden(cb, golden_dir):
     W = O.init_weights(O.unet_param_shapes(cfg), seed=fx["weight_seed"])
     wt = lib.WeightTable(W)
     u = lib.UNet(ctx, wt, lib.unet_cfg(**cfg))
-    out = u.forward(fx["x"].to(DEV), fx["t"].to(DEV), fx["context"].to(DEV), need_grad=True)
-    dctx = u.backward_context(fx["dout"].to(DEV))
+    out = u.forward(dv(fx["x"]), dv(fx["t"]), dv(fx["context"]), need_grad=True)
+    dctx = u.backward_context(dv(fx["dout"]))
     ctx.sync()
     close("unet_mini.out", out, fx["out"], 5e-5)
     close("unet_mini.dcontext", dctx, fx["dcontext"], 1e-4)
@@ -60,8 +74,8 @@ def test_vae_mini_vs_reference_golden(cb, golden_dir):
     fx = load(golden_dir, "vae_mini.pt")
     W = O.init_weights(O.vae_encoder_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
     v = lib.VAE(ctx, lib.WeightTable(W), lib.vae_cfg(**fx["cfg"]))
-    img = fx["x"].permute(0, 2, 3, 1).contiguous().to(DEV)
-    mom, z = v.encode(img, fx["noise"].to(DEV), 0.18215)
+    img = dv(fx["x"].permute(0, 2, 3, 1))
+    mom, z = v.encode(img, dv(fx["noise"]), 0.18215)
     ctx.sync()
     close("vae_mini.moments", mom.permute(0, 3, 1, 2), fx["moments"], 5e-5)
     close("vae_mini.z", z, fx["z_scaled"], 5e-5)
@@ -74,7 +88,7 @@ def test_frnet_mini_vs_reference_golden(cb, golden_dir):
     c = fx["cfg"]
     W = O.init_weights(O.frnet_param_shapes(c), seed=fx["weight_seed"])
     f = lib.FrNet(ctx, lib.WeightTable(W), layers=c["layers"], width=c["width"], in_size=c["in_size"], feat=c["feat"])
-    out = f.forward(fx["x"].permute(0, 2, 3, 1).contiguous().to(DEV))
+    out = f.forward(dv(fx["x"].permute(0, 2, 3, 1)))
     ctx.sync()
     close("frnet_mini.features", out, fx["out"], 1e-4)
 
@@ -86,12 +100,12 @@ def test_clip_mini_vs_hf_golden_and_backward(cb, golden_dir):
     cfg, pre = fx["cfg"], fx["weight_prefix"]
     W = O.init_weights(O.clip_param_shapes(cfg, pre), seed=fx["weight_seed"])
     k = lib.Clip(ctx, lib.WeightTable(W), lib.clip_cfg(**cfg), prefix=pre)
-    tokens = fx["tokens"].to(DEV)
+    tokens = dv(fx["tokens"])
     emb = k.embed_tokens(tokens)
     close("clip_mini.token_embedding", emb, W[pre + "embeddings.token_embedding.weight"][fx["tokens"]], 0.0)
     hidden = k.forward(emb, need_grad=True)
     dh = torch.randn(hidden.shape, generator=torch.Generator().manual_seed(3))
-    de = k.backward_embeds(dh.to(DEV))
+    de = k.backward_embeds(dv(dh))
     ctx.sync()
     close("clip_mini.last_hidden_state", hidden, fx["last_hidden_state"], 5e-5)
     e = emb.cpu().clone().requires_grad_(True)
@@ -142,7 +156,7 @@ def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux):
     for s in range(steps):
         batch = make_batch(B, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"])
         ctx.set_debug_taps(check_aux and s == 0)
-        dev = {k: v.to(DEV).contiguous() for k, v in batch.items()}
+        dev = {k: dv(v) for k, v in batch.items()}
         tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], lr)
         loss_ref, aux = O.train_step(W, st, batch, lr, m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"],
                                      placeholder=m["placeholder"], return_aux=True)
@@ -194,10 +208,10 @@ def test_unet_sd14_vs_oracle(cb):
     g = torch.Generator().manual_seed(4)
     x = torch.randn(1, 4, 64, 64, generator=g); t = torch.tensor([417]); c = torch.randn(1, 77, 768, generator=g)
     dout = torch.randn(1, 4, 64, 64, generator=g)
-    out = u.forward(x.to(DEV), t.to(DEV), c.to(DEV), need_grad=True)
-    dctx = u.backward_context(dout.to(DEV))
+    out = u.forward(dv(x), dv(t), dv(c), need_grad=True)
+    dctx = u.backward_context(dv(dout))
     ctx.sync()
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     cr = c.clone().requires_grad_(True)
     ref = O.unet_forward(W, cfg, x, t, cr)
     (dref,) = torch.autograd.grad((ref * dout).sum(), [cr])
@@ -212,5 +226,5 @@ def test_train_step_sd14_vs_oracle(cb):
     lib, ctx = cb
     full = dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
                 placeholder=O.PLACEHOLDER_SKS)
-    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
     run_steps(lib, ctx, full, B=1, steps=1, lr=5e-3, seed=5, check_aux=True)

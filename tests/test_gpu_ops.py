@@ -39,6 +39,20 @@ def close(name, got, ref, tol):
     assert err <= tol * scale, f"{name}: max abs err {err:.3e} vs ref max {scale:.3e} (rel {err / scale:.3e} > {tol})"
 
 
+_KEEP = []
+
+
+def dv(t):
+    """move to the device and KEEP a reference until the module ends: a temporary passed as a raw pointer would be freed
+    (and its block reused by the caching allocator) before the asynchronous kernel reads it"""
+    t = t.contiguous().to(_dev())
+    _KEEP.append(t)
+    if len(_KEEP) > 64:
+        torch.cuda.synchronize()
+        del _KEEP[:32]
+    return t
+
+
 def rnd(*shape, seed=0, scale=1.0):
     g = torch.Generator().manual_seed(seed)
     return torch.randn(*shape, generator=g) * scale
@@ -155,7 +169,7 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
         dx0 = rnd(N, H, W, Cin, seed=7)
         for beta in (0.0, 1.0):
             dx = dx0.clone().to(_dev())
-            lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(nhwc(dy)), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
+            lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(dv(nhwc(dy))), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
             ctx.sync()
             close(tag + f".dgrad(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
 
@@ -291,7 +305,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     B, Cc, H, W = x0.shape
     x0d = x0.permute(0, 2, 3, 1).contiguous().to(_dev()); xt = torch.empty_like(x0d)
     sa, sb = fx["sqrt_alphas_cumprod"].to(_dev()), fx["sqrt_one_minus_alphas_cumprod"].to(_dev())
-    lib.check(L.cb_q_sample(ctx.h, lib.ptr(x0d), lib.ptr(eps.to(_dev())), lib.ptr(tt.to(_dev()), torch.int64), lib.ptr(sa), lib.ptr(sb),
+    lib.check(L.cb_q_sample(ctx.h, lib.ptr(x0d), lib.ptr(dv(eps)), lib.ptr(dv(tt), torch.int64), lib.ptr(sa), lib.ptr(sb),
                             lib.ptr(xt), B, Cc, H * W))
     close("q_sample", xt.permute(0, 3, 1, 2), fx["q_xt"], 1e-6)
     pred = rnd(B, Cc, H, W, seed=9)
@@ -299,7 +313,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     lref = F.mse_loss(eps, pr, reduction="none").mean([1, 2, 3]).mean()
     (gref,) = torch.autograd.grad(lref, [pr])
     loss = torch.zeros(1, device=_dev()); dp = torch.empty_like(x0d)
-    lib.check(L.cb_mse_loss(ctx.h, lib.ptr(pred.permute(0, 2, 3, 1).contiguous().to(_dev())), lib.ptr(eps.to(_dev())), lib.ptr(loss),
+    lib.check(L.cb_mse_loss(ctx.h, lib.ptr(dv(pred.permute(0, 2, 3, 1))), lib.ptr(dv(eps)), lib.ptr(loss),
                             lib.ptr(dp), B, Cc, H * W))
     close("mse.loss", loss, lref.reshape(1), 1e-5)
     close("mse.grad", dp.permute(0, 3, 1, 2), gref, 1e-5)
@@ -309,7 +323,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     cat = torch.cat(faces.chunk(2, -1), 0)
     wref, sref = O.face_warp_resize(cat, 112)
     warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
-    lib.check(L.cb_face_warp_resize(ctx.h, lib.ptr(faces.to(_dev())), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
+    lib.check(L.cb_face_warp_resize(ctx.h, lib.ptr(dv(faces)), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
     close("face.warp", warped.permute(0, 3, 1, 2), wref, 2e-5)
     close("face.resize", small.permute(0, 3, 1, 2), sref, 2e-5)
     # row surgery: bit-exact against the reference golden cases (copies only)
@@ -317,7 +331,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
         toks = case["tokens"][None].contiguous().to(_dev())
         T, Cw = case["embedded"].shape
         o = torch.empty(1, T, Cw, device=_dev()); mp = torch.empty(T, dtype=torch.int32, device=_dev())
-        lib.check(L.cb_row_surgery(ctx.h, lib.ptr(case["embedded"][None].contiguous().to(_dev())), lib.ptr(case["z"][None].contiguous().to(_dev())),
+        lib.check(L.cb_row_surgery(ctx.h, lib.ptr(dv(case["embedded"][None])), lib.ptr(dv(case["z"][None])),
                                    lib.ptr(toks, torch.int64), lib.ptr(o), C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], case["placeholder"]))
         ctx.sync()
         assert torch.equal(o[0].cpu(), case["out"]), f"row surgery case {i} is not bit-exact"
@@ -328,7 +342,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     for s in range(1, 6):
         gr = torch.randn(1000, generator=g)
         p, m, v = O.adamw_step(p, gr, m, v, s, 1e-2)
-        lib.check(L.cb_adamw_step(ctx.h, lib.ptr(pd), lib.ptr(md), lib.ptr(vd), lib.ptr(gr.to(_dev())), 1000, C.c_void_p(step.data_ptr()),
+        lib.check(L.cb_adamw_step(ctx.h, lib.ptr(pd), lib.ptr(md), lib.ptr(vd), lib.ptr(dv(gr)), 1000, C.c_void_p(step.data_ptr()),
                                   1e-2, 0.9, 0.999, 1e-8, 1e-2))
     close("adamw.p", pd, p, 1e-5)
     assert int(step.item()) == 5
