@@ -95,6 +95,23 @@ struct GemmArgs {
 void gemm(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
 size_t gemm_ws_bytes(const GemmArgs& a);
 
+// ---------------------------------------------------------------- fused attention (cb_flash.hip)
+struct FlashArgs {
+    const float* q = nullptr; long ldq = 0, sqb = 0, sqh = 0;
+    const float* k = nullptr; const float* v = nullptr; long ldk = 0, skb = 0, skh = 0;
+    float* o = nullptr; long ldo = 0, sob = 0, soh = 0;
+    float* lse = nullptr;            // [B*H][Nq]
+    int H = 1, Nq = 0, Nk = 0, d = 0;
+    float scale = 1.f; int causal = 0;
+    const float* dout = nullptr;     // layout of o
+    float* dvec = nullptr;           // [B*H][Nq]  rowsum(dO * O)
+    float* dq = nullptr; float beta_q = 0.f;                      // layout of q
+    float* dk = nullptr; float* dv = nullptr; float beta_kv = 0.f; // layout of k / v
+};
+bool flash_supported(int d, const FlashArgs& a);
+void flash_forward(const Launch& L, const FlashArgs& a, int B);
+void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv);
+
 // ---------------------------------------------------------------- other kernels (cb_kernels.hip)
 void k_fill(const Launch& L, float* p, long n, float v);
 void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b);          // dst = a*src + b*dst

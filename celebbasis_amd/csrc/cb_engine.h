@@ -110,6 +110,8 @@ struct Graph {
     Ten* layernorm(Ten* x, const Norm& nm);
     // q: columns [qoff, qoff+C) of qt ; k/v: columns of kt at koff/voff. Output [B, Nq, C].
     Ten* attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal);
+    Ten* attention_materialised(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal, Ten* o);
+    bool use_flash = true;                  // fused attention for head dims <= 160 (cb_flash.hip); false = materialised path
     Ten* geglu(Ten* x);
     Ten* quickgelu(Ten* x);
     Ten* silu(Ten* x);                      // no grad path only

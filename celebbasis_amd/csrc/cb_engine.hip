@@ -324,7 +324,7 @@ Ten* Graph::layernorm(Ten* x, const Norm& nm) {
     return y;
 }
 
-// ---------------------------------------------------------------- attention (materialised scores, round 1)
+// ---------------------------------------------------------------- attention: fused (cb_flash.hip) or materialised scores
 // attention.py:170-193 CrossAttention (scale after QK^T, softmax over context), model.py:186-198 AttnBlock,
 // transformers-4.18 CLIPAttention (causal additive mask).
 Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal) {
@@ -332,11 +332,45 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
     CB_CHECK(kt->n == B && C % heads == 0, CB_ERR_SHAPE, "attention: batch/head mismatch");
     CB_CHECK(qoff + C <= qt->c && koff + C <= kt->c && voff + C <= kt->c, CB_ERR_SHAPE, "attention: column views out of range");
     const long ldq = qt->c, ldk = kt->c;
+    bool rg = qt->rg || kt->rg;
+    {   // fused path (cb_flash.hip) for head dims <= 160: scores/probabilities never touch HBM
+        FlashArgs f;
+        f.q = qt->p + qoff; f.ldq = ldq; f.sqb = (long)Nq * ldq; f.sqh = d;
+        f.k = kt->p + koff; f.v = kt->p + voff; f.ldk = ldk; f.skb = (long)Nk * ldk; f.skh = d;
+        f.ldo = C; f.sob = (long)Nq * C; f.soh = d;
+        f.H = heads; f.Nq = Nq; f.Nk = Nk; f.d = d; f.scale = scale; f.causal = causal ? 1 : 0;
+        Ten* o = make(B, qt->h, qt->w, C, rg);
+        f.o = o->p;
+        if (use_flash && flash_supported(d, f)) {
+            f.lse = ctx->arena.allocf((size_t)B * heads * Nq);
+            flash_forward(L, f, B);
+            if (rg) {
+                tape.push_back([this, f, o, qt, kt, qoff, koff, voff, B, Nq]() mutable {
+                    if (!o->ginit) return;
+                    f.dout = o->g;
+                    f.dvec = ctx->arena.allocf((size_t)B * f.H * Nq);
+                    float bq = 0.f, bk = 0.f; float* gq = nullptr; float* gk = nullptr;
+                    if (qt->rg) gq = grad(qt, &bq);
+                    if (kt->rg) { if (kt == qt) { gk = gq; bk = bq; } else gk = grad(kt, &bk); }
+                    if (gq) { f.dq = gq + qoff; f.beta_q = bq; }
+                    if (gk) { f.dk = gk + koff; f.dv = gk + voff; f.beta_kv = bk; }
+                    flash_backward(L, f, B, gq != nullptr, gk != nullptr);
+                });
+            }
+            return o;
+        }
+        // otherwise (VAE AttnBlock, d = 512) fall through to the materialised path below, reusing `o`
+        return attention_materialised(qt, qoff, kt, koff, voff, C, heads, scale, causal, o);
+    }
+}
+
+Ten* Graph::attention_materialised(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int heads, float scale, bool causal, Ten* o) {
+    const int B = qt->n, Nq = qt->h * qt->w, Nk = kt->h * kt->w, d = C / heads;
+    const long ldq = qt->c, ldk = kt->c;
     const int ldS = (int)rup(Nk, 4);
     const int BH = B * heads;
     bool rg = qt->rg || kt->rg;
     float* P = ctx->arena.allocf((size_t)BH * Nq * ldS);
-    Ten* o = make(B, qt->h, qt->w, C, rg);
 
     GemmArgs s;   // S = scale * Q K^T
     s.A = qt->p + qoff; s.lda = ldq; s.sAb = (long)Nq * ldq; s.sAh = d;

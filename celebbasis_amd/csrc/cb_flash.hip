@@ -1,0 +1,423 @@
+// cb_flash.hip — fused (flash-style) multi-head attention forward + backward in exact fp32 on the gfx950 matrix cores.
+//
+// Replaces the materialised softmax(QK^T)V of the reference (ldm/modules/attention.py:170-193 keeps the (8B, N, N) score
+// tensor and its softmax alive for backward: 5 x 512 MiB at bs=1) for head dims d <= 160:
+// UNet self/cross attention (d = 40/80/160, ctx = N or 77) and the CLIP causal attention (d = 64, 77x77).
+//
+// Mapping (v_mfma_f32_16x16x4_f32, wave64): every contraction is computed TRANSPOSED so that the softmax axis of a
+// query lives inside one lane quartet:
+//   S^T[key][query] = K . Q^T     A = K tile (LDS, K-style read), B = Q^T (registers, loaded once per block)
+//   C/D layout: col = query = lane&15, row = key = 4*(lane>>4) + reg  ->  a query's 16 keys of a 16x16 tile sit in the
+//   4 lanes {j, j+16, j+32, j+48}: row max / row sum = 16 in-register ops + two 64-wide xor-shuffles, no LDS.
+//   O^T[d][query] += V^T . P^T    A = V tile (LDS), B = P^T = the S^T accumulator registers AS THEY ARE (the MFMA k index
+//   = lane>>4 selects key 4*(lane>>4)+t at step t): probabilities never leave the register file and the running
+//   max/sum/rescale factors of query j are already in the lanes that hold O^T[:, j].
+// Backward = two kernels with the same trick (no atomics, deterministic): dQ (block owns 64 queries, loops over K/V tiles)
+// and dK/dV (block owns 64 keys, loops over Q/dO tiles); both recompute P from the saved log-sum-exp.
+// LDS tiles are row-major [row][S2] with S2 = 2 (mod 32): the K-style fragment read (16 rows x one column per quarter)
+// is conflict-free, the V-style read (one row x 16 columns per quarter) is 2-way on half of its lanes; the fp32 MFMA
+// (32 cycles per 16x16x4) leaves ample LDS slack for that.
+#include "cb_common.h"
+
+namespace cb {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FL_ROWS = 64;      // rows (queries or keys) owned by a block: 4 waves x 16
+
+__device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
+__device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
+
+template <int DT> struct FlCfg {
+    static constexpr int DP = DT * 16;                          // padded head dim
+    static constexpr int KS = DT * 4;                           // MFMA k-steps over the head dim
+    static constexpr int S2 = ((DP + 31) / 32) * 32 + 2;        // LDS row stride, = 2 (mod 32), >= DP
+    static constexpr int TK = (DT >= 8) ? 32 : 64;              // rows of the streamed tile
+    static constexpr int NT = TK / 16;                          // 16-row sub-tiles of the streamed tile
+};
+
+// cooperative load of `rows` x d floats (row-major source, row stride ld) into T[rows][S2]; zero-fills rows >= limit and
+// columns in [d, DP)
+template <int DT>
+__device__ __forceinline__ void fl_load_tile(float* T, const float* __restrict__ src, long ld, int row0, int limit, int d, int rows) {
+    constexpr int DP = FlCfg<DT>::DP, S2 = FlCfg<DT>::S2, Q = DP / 4;
+    for (int i = threadIdx.x; i < rows * Q; i += 256) {
+        int r = i / Q, c = (i - r * Q) * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < limit && c < d) v = *reinterpret_cast<const float4*>(src + (long)(row0 + r) * ld + c);   // d % 4 == 0
+        float* t = T + r * S2 + c;
+        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+    }
+}
+
+// per-lane register copy of row `row` (B operand of a transposed MFMA): reg[s] = src[row][4*s + quarter] * mul, 0 beyond d / limit
+template <int DT>
+__device__ __forceinline__ void fl_load_rowregs(float (&reg)[FlCfg<DT>::KS], const float* __restrict__ src, long ld, int row, int limit,
+                                                int d, int quarter, float mul) {
+#pragma unroll
+    for (int s = 0; s < FlCfg<DT>::KS; ++s) {
+        int c = 4 * s + quarter;
+        reg[s] = (row < limit && c < d) ? src[(long)row * ld + c] * mul : 0.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- forward
+template <int DT>
+__global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
+    using C = FlCfg<DT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;                         // [TK][S2]
+    float* Vs = lds + C::TK * C::S2;         // [TK][S2]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int q0 = blockIdx.x * FL_ROWS;
+    const int qrow = q0 + wave * 16 + l15;
+    const float* Q = a.q + b * a.sqb + h * a.sqh;
+    const float* K = a.k + b * a.skb + h * a.skh;
+    const float* V = a.v + b * a.skb + h * a.skh;
+
+    float qreg[C::KS];
+    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale);
+    f32x4 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float m = -INFINITY, l = 0.f;
+
+    int kend = a.Nk;
+    if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);      // keys beyond the last query of the block are fully masked
+    for (int k0 = 0; k0 < kend; k0 += C::TK) {
+        __syncthreads();
+        fl_load_tile<DT>(Ks, K, a.ldk, k0, a.Nk, a.d, C::TK);
+        fl_load_tile<DT>(Vs, V, a.ldk, k0, a.Nk, a.d, C::TK);
+        __syncthreads();
+        f32x4 s[C::NT];
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+            for (int kt = 0; kt < C::NT; ++kt) {
+                float av = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qreg[st], s[kt], 0, 0, 0);
+            }
+        // mask + online softmax (per query = per lane quartet)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = k0 + kt * 16 + quarter * 4 + r;
+                bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                float v = ok ? s[kt][r] : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = quad_max(mx);
+        float mnew = fmaxf(m, mx);
+        float muse = (mnew == -INFINITY) ? 0.f : mnew;
+        float alpha = __expf(m - muse);            // m = -inf -> 0
+        float ps = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float p = __expf(s[kt][r] - muse);
+                s[kt][r] = p;
+                ps += p;
+            }
+        l = l * alpha + quad_sum(ps);
+        m = mnew;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) o[t] *= alpha;
+        // O^T += V^T P^T
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    float av = Vs[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                    o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[kt][r], o[t], 0, 0, 0);
+                }
+    }
+    if (qrow < a.Nq) {
+        float inv = l > 0.f ? 1.f / l : 0.f;
+        float* O = a.o + b * a.sob + h * a.soh + (long)qrow * a.ldo;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            int c = t * 16 + quarter * 4;
+            if (c < a.d) *reinterpret_cast<float4*>(O + c) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
+        }
+        if (quarter == 0 && a.lse) a.lse[(long)bh * a.Nq + qrow] = m + __logf(l);
+    }
+}
+
+// D[bh][q] = sum_d dO[q][d] * O[q][d] : one wave per query row
+__global__ __launch_bounds__(256) void flash_dvec_kernel(const FlashArgs a, int BH) {
+    long w = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (w >= (long)BH * a.Nq) return;
+    int lane = threadIdx.x & 63;
+    int bh = (int)(w / a.Nq), qi = (int)(w - (long)bh * a.Nq), b = bh / a.H, h = bh - b * a.H;
+    const float* O = a.o + b * a.sob + h * a.soh + (long)qi * a.ldo;
+    const float* dO = a.dout + b * a.sob + h * a.soh + (long)qi * a.ldo;
+    float s = 0.f;
+    for (int c = lane; c < a.d; c += 64) s += O[c] * dO[c];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (lane == 0) a.dvec[w] = s;
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dQ
+template <int DT>
+__global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
+    using C = FlCfg<DT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Ks = lds;
+    float* Vs = lds + C::TK * C::S2;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int q0 = blockIdx.x * FL_ROWS;
+    const int qrow = q0 + wave * 16 + l15;
+    const float* Q = a.q + b * a.sqb + h * a.sqh;
+    const float* K = a.k + b * a.skb + h * a.skh;
+    const float* V = a.v + b * a.skb + h * a.skh;
+    const float* dO = a.dout + b * a.sob + h * a.soh;
+
+    float qreg[C::KS], dreg[C::KS];
+    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale);
+    fl_load_rowregs<DT>(dreg, dO, a.ldo, qrow, a.Nq, a.d, quarter, 1.f);
+    const float lse = qrow < a.Nq ? a.lse[(long)bh * a.Nq + qrow] : 0.f;
+    const float Dq = qrow < a.Nq ? a.dvec[(long)bh * a.Nq + qrow] : 0.f;
+    f32x4 g[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) g[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    int kend = a.Nk;
+    if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);
+    for (int k0 = 0; k0 < kend; k0 += C::TK) {
+        __syncthreads();
+        fl_load_tile<DT>(Ks, K, a.ldk, k0, a.Nk, a.d, C::TK);
+        fl_load_tile<DT>(Vs, V, a.ldk, k0, a.Nk, a.d, C::TK);
+        __syncthreads();
+        f32x4 s[C::NT], dp[C::NT];
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt) { s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+            for (int kt = 0; kt < C::NT; ++kt) {
+                float ak = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                float av = Vs[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qreg[st], s[kt], 0, 0, 0);      // S^T  = K Q^T
+                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dreg[st], dp[kt], 0, 0, 0);    // dP^T = V dO^T
+            }
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = k0 + kt * 16 + quarter * 4 + r;
+                bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                float p = ok ? __expf(s[kt][r] - lse) : 0.f;
+                s[kt][r] = p * (dp[kt][r] - Dq) * a.scale;                                        // d(q.k)
+            }
+        // dQ^T += K^T dS^T
+#pragma unroll
+        for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    float ak = Ks[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                    g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, s[kt][r], g[t], 0, 0, 0);
+                }
+    }
+    if (qrow < a.Nq) {
+        float* G = a.dq + b * a.sqb + h * a.sqh + (long)qrow * a.ldq;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            int c = t * 16 + quarter * 4;
+            if (c < a.d) {
+                float4 v = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
+                if (a.beta_q != 0.f) { float4 old = *reinterpret_cast<float4*>(G + c); v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w; }
+                *reinterpret_cast<float4*>(G + c) = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- backward: dK, dV
+// block owns 64 keys (wave: 16 keys, key = lane&15 is the MFMA column); streams Q / dO tiles.
+//   S[q][key]    = Q K^T         A = Q tile (K-style), B = K^T regs (unscaled; scale applied after)
+//   dP[q][key]   = dO V^T        A = dO tile (K-style), B = V^T regs
+//   dV^T[d][key] += dO^T P       A = dO tile (V-style), B = P regs
+//   dK^T[d][key] += Q^T dS       A = Q tile (V-style),  B = dS regs
+template <int DT>
+__global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
+    using C = FlCfg<DT>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    float* Qs = lds;                              // [TK][S2]
+    float* Ds = lds + C::TK * C::S2;              // dO tile [TK][S2]
+    float* Ls = lds + 2 * C::TK * C::S2;          // lse[TK], D[TK]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
+    const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
+    const int k0 = blockIdx.x * FL_ROWS;
+    const int krow = k0 + wave * 16 + l15;
+    const float* Q = a.q + b * a.sqb + h * a.sqh;
+    const float* K = a.k + b * a.skb + h * a.skh;
+    const float* V = a.v + b * a.skb + h * a.skh;
+    const float* dO = a.dout + b * a.sob + h * a.soh;
+
+    float kreg[C::KS], vreg[C::KS];
+    fl_load_rowregs<DT>(kreg, K, a.ldk, krow, a.Nk, a.d, quarter, 1.f);
+    fl_load_rowregs<DT>(vreg, V, a.ldk, krow, a.Nk, a.d, quarter, 1.f);
+    f32x4 gk[DT], gv[DT];
+#pragma unroll
+    for (int t = 0; t < DT; ++t) { gk[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; gv[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+
+    int qbeg = 0;
+    if (a.causal) qbeg = (k0 / C::TK) * C::TK;        // queries before the first key of the block see none of its keys
+    for (int q0 = qbeg; q0 < a.Nq; q0 += C::TK) {
+        __syncthreads();
+        fl_load_tile<DT>(Qs, Q, a.ldq, q0, a.Nq, a.d, C::TK);
+        fl_load_tile<DT>(Ds, dO, a.ldo, q0, a.Nq, a.d, C::TK);
+        if (threadIdx.x < C::TK) {
+            int qi = q0 + threadIdx.x;
+            Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
+            Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
+        }
+        __syncthreads();
+        f32x4 s[C::NT], dp[C::NT];
+#pragma unroll
+        for (int qt = 0; qt < C::NT; ++qt) { s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+            for (int qt = 0; qt < C::NT; ++qt) {
+                float aq = Qs[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
+                float ad = Ds[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
+                s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, kreg[st], s[qt], 0, 0, 0);
+                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, vreg[st], dp[qt], 0, 0, 0);
+            }
+        // rows of the C layout are queries 4*quarter + r of sub-tile qt, the column is this lane's key
+#pragma unroll
+        for (int qt = 0; qt < C::NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int ql = qt * 16 + quarter * 4 + r, qi = q0 + ql;
+                bool ok = qi < a.Nq && krow < a.Nk && (!a.causal || krow <= qi);
+                float p = ok ? __expf(s[qt][r] * a.scale - Ls[ql]) : 0.f;
+                float ds = p * (dp[qt][r] - Ls[C::TK + ql]) * a.scale;
+                s[qt][r] = p;
+                dp[qt][r] = ds;
+            }
+#pragma unroll
+        for (int qt = 0; qt < C::NT; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int t = 0; t < DT; ++t) {
+                    float ad = Ds[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                    float aq = Qs[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                    gv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s[qt][r], gv[t], 0, 0, 0);
+                    gk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dp[qt][r], gk[t], 0, 0, 0);
+                }
+    }
+    if (krow < a.Nk) {
+        float* GK = a.dk + b * a.skb + h * a.skh + (long)krow * a.ldk;
+        float* GV = a.dv + b * a.skb + h * a.skh + (long)krow * a.ldk;
+#pragma unroll
+        for (int t = 0; t < DT; ++t) {
+            int c = t * 16 + quarter * 4;
+            if (c < a.d) {
+                float4 vk = make_float4(gk[t][0], gk[t][1], gk[t][2], gk[t][3]);
+                float4 vv = make_float4(gv[t][0], gv[t][1], gv[t][2], gv[t][3]);
+                if (a.beta_kv != 0.f) {
+                    float4 ok = *reinterpret_cast<float4*>(GK + c), ov = *reinterpret_cast<float4*>(GV + c);
+                    vk.x += ok.x; vk.y += ok.y; vk.z += ok.z; vk.w += ok.w;
+                    vv.x += ov.x; vv.y += ov.y; vv.z += ov.z; vv.w += ov.w;
+                }
+                *reinterpret_cast<float4*>(GK + c) = vk;
+                *reinterpret_cast<float4*>(GV + c) = vv;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------- host
+bool flash_supported(int d, const FlashArgs& a) {
+    auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    bool strides = (a.ldq % 4 == 0) && (a.ldk % 4 == 0) && (a.ldo % 4 == 0) && (a.sqb % 4 == 0) && (a.sqh % 4 == 0) &&
+                   (a.skb % 4 == 0) && (a.skh % 4 == 0) && (a.sob % 4 == 0) && (a.soh % 4 == 0);
+    return d >= 4 && d <= 160 && d % 4 == 0 && strides && al(a.q) && al(a.k) && al(a.v) && al(a.o);
+}
+
+template <int DT> static size_t fl_lds_bytes(bool dkv) {
+    using C = FlCfg<DT>;
+    return (size_t)(2 * C::TK * C::S2 + (dkv ? 2 * C::TK : 0)) * sizeof(float);
+}
+
+#define FL_DISPATCH(DTV, KERNEL, GRID, LDSB, ...)                                                                     \
+    switch (DTV) {                                                                                                   \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), LDSB(1), L.stream, __VA_ARGS__); break;               \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), LDSB(2), L.stream, __VA_ARGS__); break;               \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), LDSB(3), L.stream, __VA_ARGS__); break;               \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), LDSB(4), L.stream, __VA_ARGS__); break;               \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(256), LDSB(5), L.stream, __VA_ARGS__); break;               \
+        default: hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), LDSB(10), L.stream, __VA_ARGS__); break;            \
+    }
+
+static int fl_dt(int d) { int dt = (d + 15) / 16; return dt <= 5 ? dt : 10; }
+
+static size_t lds_fwd(int dt) {
+    switch (dt) { case 1: return fl_lds_bytes<1>(false); case 2: return fl_lds_bytes<2>(false); case 3: return fl_lds_bytes<3>(false);
+                  case 4: return fl_lds_bytes<4>(false); case 5: return fl_lds_bytes<5>(false); default: return fl_lds_bytes<10>(false); }
+}
+static size_t lds_dkv(int dt) {
+    switch (dt) { case 1: return fl_lds_bytes<1>(true); case 2: return fl_lds_bytes<2>(true); case 3: return fl_lds_bytes<3>(true);
+                  case 4: return fl_lds_bytes<4>(true); case 5: return fl_lds_bytes<5>(true); default: return fl_lds_bytes<10>(true); }
+}
+
+void flash_forward(const Launch& L, const FlashArgs& a, int B) {
+    const int BH = B * a.H, dt = fl_dt(a.d);
+    if (L.stats) { L.stats->gemm_flops += 4.0 * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
+    L.count();
+    if (L.dry) return;
+    dim3 grid(cdiv(a.Nq, FL_ROWS), BH);
+    ProfRec rec; bool prof = L.prof && L.prof->on;
+    if (prof) {
+        rec.variant = L.prof->id_of("flash_fwd_kernel"); rec.flops = 4.0 * BH * (double)a.Nq * a.Nk * a.d;
+        CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
+#define LDSF(x) lds_fwd(x)
+    FL_DISPATCH(dt, flash_fwd_kernel, grid, LDSF, a)
+    CB_HIP(hipGetLastError());
+    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
+}
+
+void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv) {
+    const int BH = B * a.H, dt = fl_dt(a.d);
+    // algorithmic (reference-equivalent) work: dP, dQ | dK, dV — the recomputation of S inside both kernels is not counted
+    double fl = 2.0 + (need_dq ? 2.0 : 0.0) + (need_dkv ? 4.0 : 0.0);
+    if (L.stats) { L.stats->gemm_flops += fl * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
+    L.count(1 + (need_dq ? 1 : 0) + (need_dkv ? 1 : 0));
+    if (L.dry) return;
+    ProfRec rec; bool prof = L.prof && L.prof->on;
+    if (prof) {
+        rec.variant = L.prof->id_of("flash_bwd_kernels"); rec.flops = fl * BH * (double)a.Nq * a.Nk * a.d;
+        CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
+    hipLaunchKernelGGL(flash_dvec_kernel, dim3(cdiv((long)BH * a.Nq, 4)), dim3(256), 0, L.stream, a, BH);
+    if (need_dq) {
+        dim3 grid(cdiv(a.Nq, FL_ROWS), BH);
+        FL_DISPATCH(dt, flash_bwd_dq_kernel, grid, LDSF, a)
+    }
+    if (need_dkv) {
+        dim3 grid(cdiv(a.Nk, FL_ROWS), BH);
+#define LDSK(x) lds_dkv(x)
+        FL_DISPATCH(dt, flash_bwd_dkv_kernel, grid, LDSK, a)
+    }
+    CB_HIP(hipGetLastError());
+    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
+}
+
+}  // namespace cb

@@ -102,43 +102,67 @@ __device__ __forceinline__ float conv_fetch(const float* __restrict__ p, const C
     return p[(((long)n * g.H + iy) * g.W + ix) * g.C + ci];
 }
 
+// Per-thread conv gather state: the rows a thread loads are fixed for the whole k loop, so the row -> (image, oy, ox)
+// decode (three integer divisions) is hoisted out of it; the k -> (tap, ci) decode advances incrementally by BK.
+template <int ROWS>
+struct ConvRows {
+    int nb[ROWS / 64];    // n*H*W (pixel offset of the image), or -1 when the row is out of range
+    int vy0[ROWS / 64];   // oy*stride - pad
+    int vx0[ROWS / 64];   // ox*stride - pad
+    int tap, ci;          // decode of this thread's first k of the current tile
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int kfirst, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            if (r < R) {
+                int n = r / HWo;
+                int rem = r - n * HWo;
+                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                nb[i] = n * g.H * g.W; vy0[i] = oy * g.stride - g.pad; vx0[i] = ox * g.stride - g.pad;
+            } else { nb[i] = -1; vy0[i] = 0; vx0[i] = 0; }
+        }
+        int k = kfirst + ((tid & 3) << 2);
+        tap = k / g.C; ci = k - tap * g.C;
+    }
+    __device__ __forceinline__ void advance(const ConvGeom& g) {
+        ci += BK;
+        while (ci >= g.C) { ci -= g.C; ++tap; }
+    }
+};
+
 template <int ROWS>
 __device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float* __restrict__ p, const ConvGeom& g,
-                                          int r0, int R, int k0, int Kend, int vec, int tid) {
-    const int HWo = g.Ho * g.Wo;
+                                          const ConvRows<ROWS>& cr, int k0, int Kend, int vec, int tid) {
+    const int k = k0 + ((tid & 3) << 2);
+    const int sh = (g.up | g.tr);
+    const int Hv = g.H << sh, Wv = g.W << sh;
+    if (vec && k + 3 < Kend) {      // C % 4 == 0: the 4 k's of this thread share one tap
+        const int ky = (g.ks == 3) ? ((cr.tap * 11) >> 5) : 0;
+        const int kx = cr.tap - ky * g.ks;
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        int idx = tid + i * 256;
-        int r = r0 + (idx >> 2);
-        int k = k0 + ((idx & 3) << 2);
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < R && k < Kend) {
-            int n = r / HWo;
-            int rem = r - n * HWo;
-            int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-            if (vec && k + 3 < Kend) {
-                // C % 4 == 0: the 4 k's share one tap
-                int tap = k / g.C;
-                int ci = k - tap * g.C;
-                int ky = tap / g.ks, kx = tap - ky * g.ks;
-                int vy = oy * g.stride + ky - g.pad;
-                int vx = ox * g.stride + kx - g.pad;
-                int sh = (g.up | g.tr);
-                int Hv = g.H << sh, Wv = g.W << sh;
-                bool ok = (vy >= 0) && (vx >= 0) && (vy < Hv) && (vx < Wv);
-                if (g.tr && ((vy | vx) & 1)) ok = false;
-                if (ok) {
-                    int iy = vy >> sh, ix = vx >> sh;
-                    v = *reinterpret_cast<const float4*>(p + (((long)n * g.H + iy) * g.W + ix) * g.C + ci);
-                }
-            } else {
+        for (int i = 0; i < ROWS / 64; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            int vy = cr.vy0[i] + ky, vx = cr.vx0[i] + kx;
+            bool ok = (cr.nb[i] >= 0) && (vy >= 0) && (vx >= 0) && (vy < Hv) && (vx < Wv);
+            if (g.tr && ((vy | vx) & 1)) ok = false;
+            if (ok) v = *reinterpret_cast<const float4*>(p + ((long)(cr.nb[i] + (vy >> sh) * g.W + (vx >> sh))) * g.C + cr.ci);
+            reg[i] = v;
+        }
+    } else {                        // generic path (Cin = 3, K tails): per-element decode
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cr.nb[i] >= 0 && k < Kend) {
+                int n = cr.nb[i] / (g.H * g.W);
+                int oy = (cr.vy0[i] + g.pad) / g.stride, ox = (cr.vx0[i] + g.pad) / g.stride;
                 v.x = conv_fetch(p, g, n, oy, ox, k);
                 if (k + 1 < Kend) v.y = conv_fetch(p, g, n, oy, ox, k + 1);
                 if (k + 2 < Kend) v.z = conv_fetch(p, g, n, oy, ox, k + 2);
                 if (k + 3 < Kend) v.w = conv_fetch(p, g, n, oy, ox, k + 3);
             }
+            reg[i] = v;
         }
-        reg[i] = v;
     }
 }
 
@@ -209,11 +233,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 64], rb[BN / 64];
+    ConvRows<BM> cr;
+    if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
 
     auto loadA = [&](int k0) {
         if constexpr (AK == LD_ROW) load_row<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
         else if constexpr (AK == LD_COL) load_col<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
-        else load_conv<BM>(ra, Ap, a.g, m0, a.M, k0, kend, p.a_vec, tid);
+        else { load_conv<BM>(ra, Ap, a.g, cr, k0, kend, p.a_vec, tid); cr.advance(a.g); }
     };
     auto loadB = [&](int k0) {
         if constexpr (BKIND == LD_ROW) load_row<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
@@ -325,29 +351,33 @@ __global__ void splitk_reduce_kernel(const KArgs p) {
 struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
 
 static Plan make_plan(const GemmArgs& a) {
-    Plan pl;
-    // tile choice: big tiles only when they still give >= ~2 waves of blocks over 256 CUs
-    auto tiles = [&](int bm, int bn) { return (long)cdiv(a.M, bm) * cdiv(a.N, bn) * a.batch; };
-    int BM = 128, BN = 128;
-    if (a.N <= 64) BN = 64;
-    if (a.M <= 64) BM = 64;
-    if (tiles(BM, BN) < 512 && BM == 128 && a.M > 64) { BM = 64; }
-    if (tiles(BM, BN) < 512 && BN == 128 && a.N > 64) { BN = 64; }
-    pl.BM = BM; pl.BN = BN;
-    pl.tiles_m = cdiv(a.M, BM); pl.tiles_n = cdiv(a.N, BN);
-    long nb = (long)pl.tiles_m * pl.tiles_n * a.batch;
-    int ksteps = cdiv(a.K, BK);
-    int split = 1;
-    if (nb < 256 && ksteps >= 8) {
-        split = (int)((512 + nb - 1) / nb);
-        int maxsplit = ksteps / 4;           // keep >= 4 k-tiles (64 k) per split
-        if (split > maxsplit) split = maxsplit;
-        if (split > 64) split = 64;
-        if (split < 1) split = 1;
+    // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
+    // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
+    // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
+    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const double eff[4] = {1.0, 0.80, 0.80, 0.58};
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    const int ksteps = cdiv(a.K, BK);
+    double best = 1e300;
+    Plan pl{128, 128, 1, 1, 1, ksteps * BK};
+    for (int t = 0; t < 4; ++t) {
+        const int BM = tiles[t][0], BN = tiles[t][1];
+        if (BM == 128 && a.M <= 64) continue;
+        if (BN == 128 && a.N <= 64) continue;
+        const long tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
+        for (int sp : splits) {
+            if (sp > 1 && ksteps / sp < 4) break;            // keep >= 4 k-tiles (64 k) per split
+            int kps = cdiv(ksteps, sp) * BK;
+            int split = cdiv(a.K, kps);
+            double blocks = (double)tm * tn * a.batch * split;
+            double waves = blocks / 256.0;
+            if (blocks <= 1024) waves = (double)cdiv((long)blocks, 256);
+            double tcost = waves * (double)BM * BN * kps / eff[t];
+            // split-K traffic: partial writes + reduce reads/writes ~ (2*split+1)*M*N*4 B at ~3 TB/s, plus one more launch
+            if (split > 1) tcost += 1.0e6 + 0.41 * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
+            if (tcost < best) { best = tcost; pl = Plan{BM, BN, (int)tm, (int)tn, split, kps}; }
+        }
     }
-    int kps = cdiv(ksteps, split) * BK;
-    split = cdiv(a.K, kps);
-    pl.splitk = split; pl.k_per_split = kps;
     return pl;
 }
 

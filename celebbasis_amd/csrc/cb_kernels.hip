@@ -248,98 +248,161 @@ void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H,
 
 // ------------------------------------------------------------------ GroupNorm (NHWC)
 // util.py:214-216 GroupNorm32 (eps 1e-5), attention.py:76-77 / model.py:38-39 Normalize (eps 1e-6).
-// Stage 1: per (image, row-chunk) block computes shifted per-group partial sums (shift = first element of
-// the group in the image, which keeps E[x^2]-E[x]^2 well conditioned); stage 2 combines in double.
-constexpr int GN_ROWS = 64;  // rows of HW per partial block
-constexpr int GN_MAXC_PER_T = 10;  // C <= 2560 with 256 threads
+// HBM-bound: fwd reads x twice and writes y once, bwd reads x,dy twice and writes dx once; all global accesses are 16-byte
+// per lane over the contiguous channel axis. Statistics are deterministic (no global atomics): stage 1 gives per-(image,
+// row-chunk, group) partial sums (shifted by the first element of the group so E[x^2]-E[x]^2 stays well conditioned),
+// stage 2 reduces the chunks with one wave per (image, group) in double and expands per-channel constants.
+constexpr int GN_MAXQ = 3;   // quads (float4 columns) per thread: C <= 3*256*4 = 3072
 
+static int gn_rows_per_block(int N, int HW) {
+    long rows = (long)N * HW;
+    long rpb = (rows + 1023) / 1024;
+    if (rpb < 8) rpb = 8;
+    if (rpb > 256) rpb = 256;
+    return (int)rpb;
+}
 size_t gn_ws_floats(int N, int HW, int C, int G) {
-    (void)C;
-    return (size_t)N * cdiv(HW, GN_ROWS) * G * 2;
+    int nchunk = cdiv(HW, gn_rows_per_block(N, HW));
+    return (size_t)N * nchunk * G * 2 + (size_t)N * C * 4 + (size_t)N * C * 2 + 64;
 }
 
-__global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const float* __restrict__ x, int HW, int C,
-                                                          int G, int nchunk) {
-    __shared__ float chs[2560 * 2];
-    int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-    int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
-    int cpg = C / G;
-    const float* xn = x + (long)n * HW * C;
-    float s[GN_MAXC_PER_T], q[GN_MAXC_PER_T];
+// thread -> (quad slots, first row, row step) for a [rows][C] tile processed by 256 threads
+struct GnMap { int Q, rif, rr; int q[GN_MAXQ]; int nq; };
+__device__ __forceinline__ GnMap gn_map(int C) {
+    GnMap m; m.Q = C >> 2;
+    if (m.Q <= 256) {
+        m.rif = 256 / m.Q; m.rr = threadIdx.x / m.Q; m.nq = (m.rr < m.rif) ? 1 : 0; m.q[0] = threadIdx.x % m.Q; m.q[1] = m.q[2] = 0;
+    } else {
+        m.rif = 1; m.rr = 0; m.nq = 0;
 #pragma unroll
-    for (int j = 0; j < GN_MAXC_PER_T; ++j) { s[j] = 0.f; q[j] = 0.f; }
+        for (int s = 0; s < GN_MAXQ; ++s) { int q = threadIdx.x + s * 256; m.q[s] = q; if (q < m.Q) m.nq = s + 1; }
+    }
+    return m;
+}
+
+// deterministic block reduction: every (row-slot, channel) cell of the LDS tile is written by exactly one thread, then
+// one thread per group sums its cells in a fixed order and writes part[blockIdx.x][g][2]
+__device__ __forceinline__ void gn_block_reduce(float* __restrict__ part, float* chs, const GnMap& m, const float (*sa)[4],
+                                                const float (*sb)[4], int C, int G) {
 #pragma unroll
-    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
-        int c = threadIdx.x + j * 256;
-        if (c < C) {
-            float sh = xn[(c / cpg) * cpg];  // shift: row 0, first channel of the group
-            float a = 0.f, b = 0.f;
-            for (int r = r0; r < r1; ++r) {
-                float v = xn[(long)r * C + c] - sh;
-                a += v;
-                b += v * v;
-            }
-            s[j] = a; q[j] = b;
+    for (int s = 0; s < GN_MAXQ; ++s)
+        if (s < m.nq) {
+            float* cell = chs + ((long)m.rr * C + m.q[s] * 4) * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { cell[2 * j] = sa[s][j]; cell[2 * j + 1] = sb[s][j]; }
         }
-    }
-#pragma unroll
-    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
-        int c = threadIdx.x + j * 256;
-        if (c < C) { chs[c] = s[j]; chs[C + c] = q[j]; }
-    }
     __syncthreads();
+    int cpg = C / G;
     if (threadIdx.x < G) {
         int g = threadIdx.x;
         float a = 0.f, b = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; b += chs[C + c]; }
-        float* o = part + (((long)n * nchunk + chunk) * G + g) * 2;
+        for (int rr = 0; rr < m.rif; ++rr)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[((long)rr * C + c) * 2]; b += chs[((long)rr * C + c) * 2 + 1]; }
+        float* o = part + ((long)blockIdx.x * G + g) * 2;
         o[0] = a; o[1] = b;
     }
 }
-__global__ void gn_final_kernel(float* __restrict__ stats, const float* __restrict__ part, const float* __restrict__ x, int N,
-                                int HW, int C, int G, int nchunk, float eps) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * G) return;
-    int n = i / G, g = i % G;
+static size_t gn_lds_bytes(int C) { int Q = C / 4; int rif = Q <= 256 ? 256 / Q : 1; return (size_t)rif * C * 2 * sizeof(float); }
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const float* __restrict__ x, int HW, int C,
+                                                          int G, int nchunk, int rpb) {
+    extern __shared__ __attribute__((aligned(16))) float chs[];
+    int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
+    int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
     int cpg = C / G;
+    const float* xn = x + (long)n * HW * C;
+    GnMap m = gn_map(C);
+    float sa[GN_MAXQ][4], sb[GN_MAXQ][4], sh[GN_MAXQ][4];
+#pragma unroll
+    for (int s = 0; s < GN_MAXQ; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[s][j] = 0.f; sb[s][j] = 0.f; sh[s][j] = 0.f; }
+#pragma unroll
+    for (int s = 0; s < GN_MAXQ; ++s)
+        if (s < m.nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sh[s][j] = xn[((m.q[s] * 4 + j) / cpg) * cpg];   // shift: row 0, first channel of the group
+        }
+    for (int r = r0 + m.rr; r < r1; r += m.rif) {
+#pragma unroll
+        for (int s = 0; s < GN_MAXQ; ++s)
+            if (s < m.nq) {
+                float4 v = *reinterpret_cast<const float4*>(xn + (long)r * C + m.q[s] * 4);
+                float d0 = v.x - sh[s][0], d1 = v.y - sh[s][1], d2 = v.z - sh[s][2], d3 = v.w - sh[s][3];
+                sa[s][0] += d0; sa[s][1] += d1; sa[s][2] += d2; sa[s][3] += d3;
+                sb[s][0] += d0 * d0; sb[s][1] += d1 * d1; sb[s][2] += d2 * d2; sb[s][3] += d3 * d3;
+            }
+    }
+    gn_block_reduce(part, chs, m, sa, sb, C, G);
+}
+// one wave per (n, g): reduce chunk partials in double -> stats (mean, rstd) and per-channel {mean, rstd, gamma, beta}
+__global__ __launch_bounds__(256) void gn_final_kernel(float* __restrict__ stats, float* __restrict__ chn,
+                                                        const float* __restrict__ part, const float* __restrict__ x,
+                                                        const float* __restrict__ gamma, const float* __restrict__ beta, int N, int HW,
+                                                        int C, int G, int nchunk, float eps) {
+    int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= N * G) return;
+    int n = w / G, g = w % G, cpg = C / G;
     double a = 0, b = 0;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = lane; ch < nchunk; ch += 64) {
         const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
         a += o[0]; b += o[1];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     double cnt = (double)HW * cpg;
     double sh = x[(long)n * HW * C + g * cpg];
-    double m = a / cnt;
-    double var = b / cnt - m * m;
+    double mloc = a / cnt;
+    double var = b / cnt - mloc * mloc;
     if (var < 0) var = 0;
-    stats[i * 2 + 0] = (float)(m + sh);
-    stats[i * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    float mean = (float)(mloc + sh), rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) { stats[w * 2] = mean; stats[w * 2 + 1] = rstd; }
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64)
+        *reinterpret_cast<float4*>(chn + ((long)n * C + c) * 4) = make_float4(mean, rstd, gamma[c], beta[c]);
 }
-__global__ void gn_apply_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, const float* __restrict__ stats, long total, int HW, int C, int G,
-                                int silu) {
-    int cpg = C / G;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long n = i / ((long)HW * C);
-        const float* st = stats + (n * G + c / cpg) * 2;
-        float v = (x[i] - st[0]) * st[1] * gamma[c] + beta[c];
-        if (silu) v = v * sigmoidf_(v);
-        y[i] = v;
+// rebuild the per-channel constants from saved stats (backward entry through the ABI)
+__global__ void gn_expand_kernel(float* __restrict__ chn, const float* __restrict__ stats, const float* __restrict__ gamma,
+                                 const float* __restrict__ beta, int N, int C, int G) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N * C) return;
+    int n = i / C, c = i % C, g = c / (C / G);
+    *reinterpret_cast<float4*>(chn + (long)i * 4) = make_float4(stats[(n * G + g) * 2], stats[(n * G + g) * 2 + 1], gamma[c], beta[c]);
+}
+__global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ y, const float* __restrict__ x,
+                                                        const float* __restrict__ chn, long nquads, int HW, int C, int silu) {
+    const int Q = C >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
+        int q = (int)(i % Q);
+        long n = i / ((long)HW * Q);
+        float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
+        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 kk = k[j];
+            float t = (in[j] - kk.x) * kk.y * kk.z + kk.w;
+            o[j] = silu ? t * sigmoidf_(t) : t;
+        }
+        *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, float* ws,
                      int N, int HW, int C, int G, float eps, int silu) {
-    CB_CHECK(C % G == 0 && C <= 2560 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
-    int nchunk = cdiv(HW, GN_ROWS);
-    LAUNCH(gn_partial_kernel, dim3(N * nchunk), dim3(256), L, ws, x, HW, C, G, nchunk);
-    LAUNCH(gn_final_kernel, dim3(cdiv(N * G, 64)), dim3(64), L, stats, ws, x, N, HW, C, G, nchunk, eps);
-    long total = (long)N * HW * C;
-    LAUNCH(gn_apply_kernel, grid1d(total), dim3(256), L, y, x, gamma, beta, stats, total, HW, C, G, silu);
+    CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
+    int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
+    float* part = ws;
+    float* chn = ws + (size_t)N * nchunk * G * 2;
+    (void)L.count(3);
+    if (L.dry) return;
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, HW, C, G, nchunk, rpb);
+    hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, x, gamma, beta, N, HW, C, G, nchunk, eps);
+    long nquads = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(gn_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, y, x, chn, nquads, HW, C, silu);
+    CB_HIP(hipGetLastError());
 }
 
-// backward: t = x_hat*gamma+beta ; dt = dy * silu'(t) (or dy) ; s1 = sum dt*gamma ; s2 = sum dt*gamma*x_hat (per n,g)
-// dx = rstd * (dt*gamma - s1/m - x_hat*s2/m)
+// backward: t = x_hat*gamma+beta ; dt = dy * silu'(t) (or dy) ; s1 = mean(dt*gamma) ; s2 = mean(dt*gamma*x_hat) (per n,g)
+// dx = rstd * (dt*gamma - s1 - x_hat*s2)
 __device__ __forceinline__ float gn_dt(float xh, float gam, float bet, float dy, int silu) {
     if (!silu) return dy;
     float t = xh * gam + bet;
@@ -347,82 +410,104 @@ __device__ __forceinline__ float gn_dt(float xh, float gam, float bet, float dy,
     return dy * s * (1.f + t * (1.f - s));
 }
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const float* __restrict__ x,
-                                                              const float* __restrict__ dy, const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta, const float* __restrict__ stats,
-                                                              int HW, int C, int G, int nchunk, int silu) {
-    __shared__ float chs[2560 * 2];
+                                                              const float* __restrict__ dy, const float* __restrict__ chn, int HW,
+                                                              int C, int G, int nchunk, int rpb, int silu) {
+    extern __shared__ __attribute__((aligned(16))) float chs[];
     int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
-    int r0 = chunk * GN_ROWS, r1 = min(HW, r0 + GN_ROWS);
-    int cpg = C / G;
+    int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
     const float* xn = x + (long)n * HW * C;
     const float* dn = dy + (long)n * HW * C;
+    GnMap m = gn_map(C);
+    float sa[GN_MAXQ][4], sb[GN_MAXQ][4];
+    float4 kk[GN_MAXQ][4];
 #pragma unroll
-    for (int j = 0; j < GN_MAXC_PER_T; ++j) {
-        int c = threadIdx.x + j * 256;
-        if (c < C) {
-            const float* st = stats + ((long)n * G + c / cpg) * 2;
-            float mean = st[0], rstd = st[1], gam = gamma[c], bet = beta[c];
-            float a = 0.f, b = 0.f;
-            for (int r = r0; r < r1; ++r) {
-                float xh = (xn[(long)r * C + c] - mean) * rstd;
-                float dt = gn_dt(xh, gam, bet, dn[(long)r * C + c], silu) * gam;
-                a += dt;
-                b += dt * xh;
-            }
-            chs[c] = a; chs[C + c] = b;
+    for (int s = 0; s < GN_MAXQ; ++s)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { sa[s][j] = 0.f; sb[s][j] = 0.f; kk[s][j] = make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+    for (int s = 0; s < GN_MAXQ; ++s)
+        if (s < m.nq) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) kk[s][j] = *reinterpret_cast<const float4*>(chn + ((long)n * C + m.q[s] * 4 + j) * 4);
         }
+    for (int r = r0 + m.rr; r < r1; r += m.rif) {
+#pragma unroll
+        for (int s = 0; s < GN_MAXQ; ++s)
+            if (s < m.nq) {
+                float4 xv = *reinterpret_cast<const float4*>(xn + (long)r * C + m.q[s] * 4);
+                float4 dv = *reinterpret_cast<const float4*>(dn + (long)r * C + m.q[s] * 4);
+                float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float xh = (xi[j] - kk[s][j].x) * kk[s][j].y;
+                    float dt = gn_dt(xh, kk[s][j].z, kk[s][j].w, di[j], silu) * kk[s][j].z;
+                    sa[s][j] += dt; sb[s][j] += dt * xh;
+                }
+            }
     }
-    __syncthreads();
-    if (threadIdx.x < G) {
-        int g = threadIdx.x;
-        float a = 0.f, b = 0.f;
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[c]; b += chs[C + c]; }
-        float* o = part + (((long)n * nchunk + chunk) * G + g) * 2;
-        o[0] = a; o[1] = b;
-    }
+    gn_block_reduce(part, chs, m, sa, sb, C, G);
 }
-__global__ void gn_bwd_final_kernel(float* __restrict__ sums, const float* __restrict__ part, int N, int HW, int C, int G,
-                                    int nchunk) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= N * G) return;
-    int n = i / G, g = i % G;
+// one wave per (n, g): chunk partials -> per-channel {s1, s2} (already divided by the group size)
+__global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ gs, const float* __restrict__ part, int N, int HW,
+                                                            int C, int G, int nchunk) {
+    int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (w >= N * G) return;
+    int n = w / G, g = w % G, cpg = C / G;
     double a = 0, b = 0;
-    for (int ch = 0; ch < nchunk; ++ch) {
+    for (int ch = lane; ch < nchunk; ch += 64) {
         const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
         a += o[0]; b += o[1];
     }
-    double cnt = (double)HW * (C / G);
-    sums[i * 2 + 0] = (float)(a / cnt);
-    sums[i * 2 + 1] = (float)(b / cnt);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    double cnt = (double)HW * cpg;
+    float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) { gs[((long)n * C + c) * 2] = s1; gs[((long)n * C + c) * 2 + 1] = s2; }
 }
-__global__ void gn_bwd_apply_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy,
-                                    const float* __restrict__ gamma, const float* __restrict__ beta,
-                                    const float* __restrict__ stats, const float* __restrict__ sums, long total, int HW, int C,
-                                    int G, int silu, float acc_beta) {
-    int cpg = C / G;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long n = i / ((long)HW * C);
-        long sg = n * G + c / cpg;
-        float mean = stats[sg * 2], rstd = stats[sg * 2 + 1];
-        float gam = gamma[c];
-        float xh = (x[i] - mean) * rstd;
-        float dt = gn_dt(xh, gam, beta[c], dy[i], silu) * gam;
-        float v = rstd * (dt - sums[sg * 2] - xh * sums[sg * 2 + 1]);
-        if (acc_beta != 0.f) v += acc_beta * dx[i];
-        dx[i] = v;
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ dx, const float* __restrict__ x,
+                                                            const float* __restrict__ dy, const float* __restrict__ chn,
+                                                            const float* __restrict__ gs, long nquads, int HW, int C, int silu,
+                                                            float acc_beta) {
+    const int Q = C >> 2;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
+        int q = (int)(i % Q);
+        long n = i / ((long)HW * Q);
+        float4 xv = *reinterpret_cast<const float4*>(x + i * 4);
+        float4 dv = *reinterpret_cast<const float4*>(dy + i * 4);
+        const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
+        const float2* s = reinterpret_cast<const float2*>(gs + (n * C + q * 4) * 2);
+        float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float4 kk = k[j]; float2 ss = s[j];
+            float xh = (xi[j] - kk.x) * kk.y;
+            float dt = gn_dt(xh, kk.z, kk.w, di[j], silu) * kk.z;
+            o[j] = kk.y * (dt - ss.x - xh * ss.y);
+        }
+        if (acc_beta != 0.f) {
+            float4 old = *reinterpret_cast<const float4*>(dx + i * 4);
+            o[0] += acc_beta * old.x; o[1] += acc_beta * old.y; o[2] += acc_beta * old.z; o[3] += acc_beta * old.w;
+        }
+        *reinterpret_cast<float4*>(dx + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
                      const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta) {
-    CB_CHECK(C % G == 0 && C <= 2560 && G <= 256, CB_ERR_SHAPE, "groupnorm bwd: C=%d G=%d unsupported", C, G);
-    int nchunk = cdiv(HW, GN_ROWS);
+    CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm bwd: C=%d G=%d unsupported", C, G);
+    int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
     float* part = ws;
-    float* sums = ws + (size_t)N * nchunk * G * 2;  // caller provides gn_ws_floats + N*G*2
-    LAUNCH(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), L, part, x, dy, gamma, beta, stats, HW, C, G, nchunk, silu);
-    LAUNCH(gn_bwd_final_kernel, dim3(cdiv(N * G, 64)), dim3(64), L, sums, part, N, HW, C, G, nchunk);
-    long total = (long)N * HW * C;
-    LAUNCH(gn_bwd_apply_kernel, grid1d(total), dim3(256), L, dx, x, dy, gamma, beta, stats, sums, total, HW, C, G, silu, acc_beta);
+    float* chn = ws + (size_t)N * nchunk * G * 2;
+    float* gs = chn + (size_t)N * C * 4;
+    (void)L.count(4);
+    if (L.dry) return;
+    hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
+    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, dy, chn, HW, C, G,
+                       nchunk, rpb, silu);
+    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
+    long nquads = (long)N * HW * (C / 4);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, dx, x, dy, chn, gs, nquads, HW, C, silu,
+                       acc_beta);
+    CB_HIP(hipGetLastError());
 }
 
 // ------------------------------------------------------------------ LayerNorm: one wave per row, C <= 64*24
@@ -537,9 +622,66 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S,
         if (c < n) r[c] = v[j] * inv;
     }
 }
+// short rows (cross-attention ctx = 77, CLIP 77, 8x8 / 16x16 self-attention): one wave per row, 4 rows per block
+constexpr int SMW_PER_L = 8;   // n <= 512
+__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(float* __restrict__ S, long rows, int n, int ld, int causal,
+                                                                int rows_per_mat) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float* r = S + row * ld;
+    int lim = causal ? (int)(row % rows_per_mat) + 1 : n;
+    if (lim > n) lim = n;
+    float v[SMW_PER_L];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SMW_PER_L; ++j) {
+        int c = lane + j * 64;
+        v[j] = (c < lim) ? r[c] : -INFINITY;
+        mx = fmaxf(mx, v[j]);
+    }
+    mx = wave_max(mx);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMW_PER_L; ++j) {
+        int c = lane + j * 64;
+        v[j] = (c < lim) ? __expf(v[j] - mx) : 0.f;
+        s += v[j];
+    }
+    float inv = 1.f / wave_sum(s);
+#pragma unroll
+    for (int j = 0; j < SMW_PER_L; ++j) {
+        int c = lane + j * 64;
+        if (c < n) r[c] = v[j] * inv;
+    }
+}
+__global__ __launch_bounds__(256) void softmax_bwd_wave_kernel(float* __restrict__ dP, const float* __restrict__ P, long rows, int n,
+                                                                int ld, float scale) {
+    long row = blockIdx.x * 4L + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    int lane = threadIdx.x & 63;
+    float* d = dP + row * ld;
+    const float* p = P + row * ld;
+    float pv[SMW_PER_L], dv[SMW_PER_L];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < SMW_PER_L; ++j) {
+        int c = lane + j * 64;
+        pv[j] = (c < n) ? p[c] : 0.f;
+        dv[j] = (c < n) ? d[c] : 0.f;
+        s += pv[j] * dv[j];
+    }
+    s = wave_sum(s);
+#pragma unroll
+    for (int j = 0; j < SMW_PER_L; ++j) {
+        int c = lane + j * 64;
+        if (c < n) d[c] = scale * pv[j] * (dv[j] - s);
+    }
+}
 void k_softmax_fwd(const Launch& L, float* S, long rows, int n, int ld, int causal, int rows_per_mat) {
     CB_CHECK(n <= 256 * SM_PER_T, CB_ERR_SHAPE, "softmax: n=%d too large", n);
-    LAUNCH(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), L, S, n, ld, causal, rows_per_mat);
+    if (n <= 64 * SMW_PER_L) LAUNCH(softmax_fwd_wave_kernel, dim3(cdiv(rows, 4)), dim3(256), L, S, rows, n, ld, causal, rows_per_mat);
+    else LAUNCH(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), L, S, n, ld, causal, rows_per_mat);
 }
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dP, const float* __restrict__ P, int n, int ld,
                                                            float scale) {
@@ -565,7 +707,8 @@ __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dP
 }
 void k_softmax_bwd(const Launch& L, float* dP, const float* P, long rows, int n, int ld, float scale) {
     CB_CHECK(n <= 256 * SM_PER_T, CB_ERR_SHAPE, "softmax bwd: n=%d too large", n);
-    LAUNCH(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), L, dP, P, n, ld, scale);
+    if (n <= 64 * SMW_PER_L) LAUNCH(softmax_bwd_wave_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dP, P, rows, n, ld, scale);
+    else LAUNCH(softmax_bwd_kernel, dim3((unsigned)rows), dim3(256), L, dP, P, n, ld, scale);
 }
 
 // ------------------------------------------------------------------ diffusion glue

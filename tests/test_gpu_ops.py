@@ -324,8 +324,8 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     wref, sref = O.face_warp_resize(cat, 112)
     warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
     lib.check(L.cb_face_warp_resize(ctx.h, lib.ptr(dv(faces)), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
-    close("face.warp", warped.permute(0, 3, 1, 2), wref, 2e-5)
-    close("face.resize", small.permute(0, 3, 1, 2), sref, 2e-5)
+    close("face.warp", warped.permute(0, 3, 1, 2), wref, 1e-4)   # 4-tap bilinear, different association than ATen
+    close("face.resize", small.permute(0, 3, 1, 2), sref, 1e-4)
     # row surgery: bit-exact against the reference golden cases (copies only)
     for i, case in enumerate(torch.load(os.path.join(golden_dir, "shift_rows.pt"), weights_only=False)):
         toks = case["tokens"][None].contiguous().to(_dev())
