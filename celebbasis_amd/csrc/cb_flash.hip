@@ -36,17 +36,38 @@ template <int DT> struct FlCfg {
     static constexpr int NT = TK / 16;                          // 16-row sub-tiles of the streamed tile
 };
 
-// cooperative load of `rows` x d floats (row-major source, row stride ld) into T[rows][S2]; zero-fills rows >= limit and
-// columns in [d, DP)
+// Streamed tiles (TK rows x d floats, row-major source) go global -> registers -> LDS T[TK][S2]. The register stage is a
+// software prefetch: the loads of tile t+1 are issued before the MFMA work of tile t and land in LDS after it. Loads are
+// branch-free (out-of-range lanes read the base address; zeros are selected at the LDS store) so nothing forces an early wait.
+template <int DT> struct FlTile {
+    static constexpr int Q = FlCfg<DT>::DP / 4;                               // float4 per row
+    static constexpr int N = (FlCfg<DT>::TK * Q + 255) / 256;                 // float4 per thread
+};
 template <int DT>
-__device__ __forceinline__ void fl_load_tile(float* T, const float* __restrict__ src, long ld, int row0, int limit, int d, int rows) {
-    constexpr int DP = FlCfg<DT>::DP, S2 = FlCfg<DT>::S2, Q = DP / 4;
-    for (int i = threadIdx.x; i < rows * Q; i += 256) {
+__device__ __forceinline__ void fl_prefetch(float4 (&reg)[FlTile<DT>::N], const float* __restrict__ src, long ld, int row0, int limit,
+                                            int d) {
+    constexpr int Q = FlTile<DT>::Q;
+#pragma unroll
+    for (int j = 0; j < FlTile<DT>::N; ++j) {
+        int i = threadIdx.x + j * 256;
         int r = i / Q, c = (i - r * Q) * 4;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < limit && c < d) v = *reinterpret_cast<const float4*>(src + (long)(row0 + r) * ld + c);   // d % 4 == 0
-        float* t = T + r * S2 + c;
-        t[0] = v.x; t[1] = v.y; t[2] = v.z; t[3] = v.w;
+        bool ok = (i < FlCfg<DT>::TK * Q) && (row0 + r < limit) && (c < d);
+        reg[j] = *reinterpret_cast<const float4*>(ok ? src + (long)(row0 + r) * ld + c : src);   // d % 4 == 0
+    }
+}
+template <int DT>
+__device__ __forceinline__ void fl_store(float* T, const float4 (&reg)[FlTile<DT>::N], int row0, int limit, int d) {
+    constexpr int Q = FlTile<DT>::Q, S2 = FlCfg<DT>::S2;
+#pragma unroll
+    for (int j = 0; j < FlTile<DT>::N; ++j) {
+        int i = threadIdx.x + j * 256;
+        int r = i / Q, c = (i - r * Q) * 4;
+        if (i < FlCfg<DT>::TK * Q) {
+            bool ok = (row0 + r < limit) && (c < d);
+            float* t = T + r * S2 + c;                       // S2 is even: 8-byte aligned pairs
+            *reinterpret_cast<float2*>(t) = ok ? make_float2(reg[j].x, reg[j].y) : make_float2(0.f, 0.f);
+            *reinterpret_cast<float2*>(t + 2) = ok ? make_float2(reg[j].z, reg[j].w) : make_float2(0.f, 0.f);
+        }
     }
 }
 
@@ -85,11 +106,18 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
 
     int kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);      // keys beyond the last query of the block are fully masked
+    float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
+    fl_prefetch<DT>(pk, K, a.ldk, 0, a.Nk, a.d);
+    fl_prefetch<DT>(pv, V, a.ldk, 0, a.Nk, a.d);
     for (int k0 = 0; k0 < kend; k0 += C::TK) {
         __syncthreads();
-        fl_load_tile<DT>(Ks, K, a.ldk, k0, a.Nk, a.d, C::TK);
-        fl_load_tile<DT>(Vs, V, a.ldk, k0, a.Nk, a.d, C::TK);
+        fl_store<DT>(Ks, pk, k0, a.Nk, a.d);
+        fl_store<DT>(Vs, pv, k0, a.Nk, a.d);
         __syncthreads();
+        if (k0 + C::TK < kend) {
+            fl_prefetch<DT>(pk, K, a.ldk, k0 + C::TK, a.Nk, a.d);
+            fl_prefetch<DT>(pv, V, a.ldk, k0 + C::TK, a.Nk, a.d);
+        }
         f32x4 s[C::NT];
 #pragma unroll
         for (int kt = 0; kt < C::NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -194,11 +222,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
 
     int kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);
+    float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
+    fl_prefetch<DT>(pk, K, a.ldk, 0, a.Nk, a.d);
+    fl_prefetch<DT>(pv, V, a.ldk, 0, a.Nk, a.d);
     for (int k0 = 0; k0 < kend; k0 += C::TK) {
         __syncthreads();
-        fl_load_tile<DT>(Ks, K, a.ldk, k0, a.Nk, a.d, C::TK);
-        fl_load_tile<DT>(Vs, V, a.ldk, k0, a.Nk, a.d, C::TK);
+        fl_store<DT>(Ks, pk, k0, a.Nk, a.d);
+        fl_store<DT>(Vs, pv, k0, a.Nk, a.d);
         __syncthreads();
+        if (k0 + C::TK < kend) {
+            fl_prefetch<DT>(pk, K, a.ldk, k0 + C::TK, a.Nk, a.d);
+            fl_prefetch<DT>(pv, V, a.ldk, k0 + C::TK, a.Nk, a.d);
+        }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
         for (int kt = 0; kt < C::NT; ++kt) { s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
@@ -276,16 +311,23 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
 
     int qbeg = 0;
     if (a.causal) qbeg = (k0 / C::TK) * C::TK;        // queries before the first key of the block see none of its keys
+    float4 pq[FlTile<DT>::N], pd[FlTile<DT>::N];
+    fl_prefetch<DT>(pq, Q, a.ldq, qbeg, a.Nq, a.d);
+    fl_prefetch<DT>(pd, dO, a.ldo, qbeg, a.Nq, a.d);
     for (int q0 = qbeg; q0 < a.Nq; q0 += C::TK) {
         __syncthreads();
-        fl_load_tile<DT>(Qs, Q, a.ldq, q0, a.Nq, a.d, C::TK);
-        fl_load_tile<DT>(Ds, dO, a.ldo, q0, a.Nq, a.d, C::TK);
+        fl_store<DT>(Qs, pq, q0, a.Nq, a.d);
+        fl_store<DT>(Ds, pd, q0, a.Nq, a.d);
         if (threadIdx.x < C::TK) {
             int qi = q0 + threadIdx.x;
             Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
             Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
         }
         __syncthreads();
+        if (q0 + C::TK < a.Nq) {
+            fl_prefetch<DT>(pq, Q, a.ldq, q0 + C::TK, a.Nq, a.d);
+            fl_prefetch<DT>(pd, dO, a.ldo, q0 + C::TK, a.Nq, a.d);
+        }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
         for (int qt = 0; qt < C::NT; ++qt) { s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }

@@ -127,7 +127,8 @@ struct ConvRows {
     }
     __device__ __forceinline__ void advance(const ConvGeom& g) {
         ci += BK;
-        while (ci >= g.C) { ci -= g.C; ++tap; }
+        if (g.C >= BK) { bool w = ci >= g.C; ci -= w ? g.C : 0; tap += w ? 1 : 0; }   // wave-uniform, one wrap at most
+        else while (ci >= g.C) { ci -= g.C; ++tap; }
     }
 };
 
@@ -166,29 +167,93 @@ __device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float*
     }
 }
 
+// ---- branch-free 16-byte loaders (VEC kernels) -------------------------------------------------------------------------
+// Preconditions checked on the host: 16-byte aligned bases/strides, K % 4 == 0 (ROW/CONV) resp. rows % 4 == 0 (COL), so a
+// float4 is either fully inside or fully outside the operand. Out-of-range lanes read the (valid, aligned) base address and
+// the result is zeroed with selects: no divergent branch sits between the global loads and their consumers, which lets the
+// compiler issue the prefetch of tile t+1 before the MFMA block of tile t and wait for it only at the LDS stores.
+// NOTE the zeroing is deferred to the LDS store (mask bit per slot): a select right behind the load would make the compiler
+// wait for the data immediately (s_waitcnt vmcnt(0) in front of the MFMA block) instead of after it.
+__device__ __forceinline__ float4 ld4_safe(const float* __restrict__ q, const float* __restrict__ safe, bool ok) {
+    return *reinterpret_cast<const float4*>(ok ? q : safe);
+}
+template <int ROWS>
+__device__ __forceinline__ unsigned load_row_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R, int k0,
+                                               int Kend, int tid) {
+    const int k = k0 + ((tid & 3) << 2);
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int r = r0 + ((tid + i * 256) >> 2);
+        bool ok = (r < R) && (k < Kend);
+        reg[i] = ld4_safe(p + (long)r * ld + k, p, ok);
+        mask |= ok ? (1u << i) : 0u;
+    }
+    return mask;
+}
+template <int ROWS>
+__device__ __forceinline__ unsigned load_col_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R, int k0,
+                                               int Kend, int tid) {
+    constexpr int QPR = ROWS / 4;
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int k = k0 + idx / QPR;
+        int r = r0 + (idx % QPR) * 4;
+        bool ok = (k < Kend) && (r < R);
+        reg[i] = ld4_safe(p + (long)k * ld + r, p, ok);
+        mask |= ok ? (1u << i) : 0u;
+    }
+    return mask;
+}
+template <int ROWS>
+__device__ __forceinline__ unsigned load_conv_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, const ConvGeom& g,
+                                                const ConvRows<ROWS>& cr, int k0, int Kend, int tid) {
+    const int k = k0 + ((tid & 3) << 2);
+    const int sh = (g.up | g.tr);
+    const int Hv = g.H << sh, Wv = g.W << sh;
+    const int ky = (g.ks == 3) ? ((cr.tap * 11) >> 5) : 0;
+    const int kx = cr.tap - ky * g.ks;
+    const bool kok = k < Kend;
+    unsigned mask = 0;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int vy = cr.vy0[i] + ky, vx = cr.vx0[i] + kx;
+        bool ok = kok && (cr.nb[i] >= 0) && (vy >= 0) && (vx >= 0) && (vy < Hv) && (vx < Wv);
+        ok = ok && !(g.tr && ((vy | vx) & 1));
+        long off = ((long)(cr.nb[i] + (vy >> sh) * g.W + (vx >> sh))) * g.C + cr.ci;
+        reg[i] = ld4_safe(p + off, p, ok);
+        mask |= ok ? (1u << i) : 0u;
+    }
+    return mask;
+}
+
 // ---- registers -> LDS (k-major tile [BK][ROWS+4]) -----------------------------------------
 template <int ROWS>
-__device__ __forceinline__ void store_kcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid) {
+__device__ __forceinline__ void store_kcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid, unsigned mask) {
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
         int idx = tid + i * 256;
         int r = idx >> 2;
         int k = (idx & 3) << 2;
-        T[k + 0][r] = reg[i].x;
-        T[k + 1][r] = reg[i].y;
-        T[k + 2][r] = reg[i].z;
-        T[k + 3][r] = reg[i].w;
+        const bool ok = (mask >> i) & 1u;
+        T[k + 0][r] = ok ? reg[i].x : 0.f;
+        T[k + 1][r] = ok ? reg[i].y : 0.f;
+        T[k + 2][r] = ok ? reg[i].z : 0.f;
+        T[k + 3][r] = ok ? reg[i].w : 0.f;
     }
 }
 template <int ROWS>
-__device__ __forceinline__ void store_rcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid) {
+__device__ __forceinline__ void store_rcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid, unsigned mask) {
     constexpr int QPR = ROWS / 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
         int idx = tid + i * 256;
         int k = idx / QPR;
         int r = (idx % QPR) * 4;
-        *reinterpret_cast<float4*>(&T[k][r]) = reg[i];
+        const bool ok = (mask >> i) & 1u;
+        *reinterpret_cast<float4*>(&T[k][r]) = ok ? reg[i] : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 }
 
@@ -200,7 +265,7 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
     return base + j;
 }
 
-template <int BM, int BN, int AK, int BKIND>
+template <int BM, int BN, int AK, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
     constexpr int TM = BM / 64, TN = BN / 64;
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
@@ -236,22 +301,34 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
     ConvRows<BM> cr;
     if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
 
+    unsigned ma = ~0u, mb = ~0u;     // VEC: per-slot validity of the prefetched float4 (zeroed at the LDS store)
     auto loadA = [&](int k0) {
-        if constexpr (AK == LD_ROW) load_row<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
-        else if constexpr (AK == LD_COL) load_col<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
-        else { load_conv<BM>(ra, Ap, a.g, cr, k0, kend, p.a_vec, tid); cr.advance(a.g); }
+        if constexpr (VEC) {
+            if constexpr (AK == LD_ROW) ma = load_row_v<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, tid);
+            else if constexpr (AK == LD_COL) ma = load_col_v<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, tid);
+            else { ma = load_conv_v<BM>(ra, Ap, a.g, cr, k0, kend, tid); cr.advance(a.g); }
+        } else {
+            if constexpr (AK == LD_ROW) load_row<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
+            else if constexpr (AK == LD_COL) load_col<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
+            else { load_conv<BM>(ra, Ap, a.g, cr, k0, kend, p.a_vec, tid); cr.advance(a.g); }
+        }
     };
     auto loadB = [&](int k0) {
-        if constexpr (BKIND == LD_ROW) load_row<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
-        else load_col<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
+        if constexpr (VEC) {
+            if constexpr (BKIND == LD_ROW) mb = load_row_v<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, tid);
+            else mb = load_col_v<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, tid);
+        } else {
+            if constexpr (BKIND == LD_ROW) load_row<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
+            else load_col<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
+        }
     };
     auto storeA = [&](int buf) {
-        if constexpr (AK == LD_COL) store_rcontig<BM>(As[buf], ra, tid);
-        else store_kcontig<BM>(As[buf], ra, tid);
+        if constexpr (AK == LD_COL) store_rcontig<BM>(As[buf], ra, tid, ma);
+        else store_kcontig<BM>(As[buf], ra, tid, ma);
     };
     auto storeB = [&](int buf) {
-        if constexpr (BKIND == LD_COL) store_rcontig<BN>(Bs[buf], rb, tid);
-        else store_kcontig<BN>(Bs[buf], rb, tid);
+        if constexpr (BKIND == LD_COL) store_rcontig<BN>(Bs[buf], rb, tid, mb);
+        else store_kcontig<BN>(Bs[buf], rb, tid, mb);
     };
 
     if (kbeg < kend) {
@@ -266,19 +343,24 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
         const bool more = (k0 + BK) < kend;
         if (more) { loadA(k0 + BK); loadB(k0 + BK); }
 
+        // all MFMA fragments of the tile are requested from LDS up front; the compiler then waits with counted lgkmcnt(N)
+        // in front of each MFMA group instead of a full drain per k-step
+        float av[BK / 2][TM], bv[BK / 2][TN];
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            float av[TM], bv[TN];
+        for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[i] = As[cur][kk + kl][wm * (BM / 2) + i * 32 + ml];
+            for (int i = 0; i < TM; ++i) av[kk][i] = As[cur][2 * kk + kl][wm * (BM / 2) + i * 32 + ml];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[j] = Bs[cur][kk + kl][wn * (BN / 2) + j * 32 + ml];
+            for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[cur][2 * kk + kl][wn * (BN / 2) + j * 32 + ml];
+        }
+        __builtin_amdgcn_sched_barrier(0);      // keep the reads above: the scheduler otherwise sinks each pair next to its MFMAs
+#pragma unroll
+        for (int kk = 0; kk < BK / 2; ++kk)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i], bv[j], acc[i][j], 0, 0, 0);
-        }
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[kk][i], bv[kk][j], acc[i][j], 0, 0, 0);
 
         if (more) { storeA(cur ^ 1); storeB(cur ^ 1); }
         __syncthreads();
@@ -387,12 +469,16 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
     return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
 }
 
+template <int AK, int BKIND, bool VEC>
+static void launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<64, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+}
 template <int AK, int BKIND>
-static void launch_tiles(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
-    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND>), grid, dim3(256), 0, s, ka);
-    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND>), grid, dim3(256), 0, s, ka);
-    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<64, 128, AK, BKIND>), grid, dim3(256), 0, s, ka);
-    else hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKIND>), grid, dim3(256), 0, s, ka);
+static void launch_tiles(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka, bool vec) {
+    if (vec) launch_tiles2<AK, BKIND, true>(pl, grid, s, ka); else launch_tiles2<AK, BKIND, false>(pl, grid, s, ka);
 }
 
 void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
@@ -427,22 +513,26 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     else ka.a_vec = aligned16(a.A) && (a.lda % 4 == 0) && strides_ok(a.sAb, a.sAh);
     ka.b_vec = aligned16(a.B) && (a.ldb % 4 == 0) && strides_ok(a.sBb, a.sBh);
 
+    // branch-free 16-byte kernels need every float4 to be fully in or fully out of range
+    bool vec = ka.a_vec && ka.b_vec;
+    if (a.a_kind == LD_COL) vec = vec && (a.M % 4 == 0); else vec = vec && (a.K % 4 == 0);
+    if (a.b_kind == LD_COL) vec = vec && (a.N % 4 == 0); else vec = vec && (a.K % 4 == 0);
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
         static const char* kn[3] = {"ROW", "COL", "CONV"};
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s>%s", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], pl.splitk > 1 ? "+splitk" : "");
+        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s%s>%s", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], vec ? "" : ",generic", pl.splitk > 1 ? "+splitk" : "");
         rec.variant = L.prof->id_of(nm);
         rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
         CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
-    if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka);
-    else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka);
-    else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka);
-    else if (a.a_kind == LD_COL && a.b_kind == LD_ROW) launch_tiles<LD_COL, LD_ROW>(pl, grid, L.stream, ka);
-    else if (a.a_kind == LD_CONV) launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka);
+    if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka, vec);
+    else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka, vec);
+    else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka, vec);
+    else if (a.a_kind == LD_COL && a.b_kind == LD_ROW) launch_tiles<LD_COL, LD_ROW>(pl, grid, L.stream, ka, vec);
+    else if (a.a_kind == LD_CONV) launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka, vec);
     else fail(CB_ERR_ARG, "gemm: unsupported operand kinds %d/%d", a.a_kind, a.b_kind);
     CB_HIP(hipGetLastError());
     if (pl.splitk > 1) {
