@@ -167,66 +167,108 @@ __device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float*
     }
 }
 
-// ---- branch-free 16-byte loaders (VEC kernels) -------------------------------------------------------------------------
-// Preconditions checked on the host: 16-byte aligned bases/strides, K % 4 == 0 (ROW/CONV) resp. rows % 4 == 0 (COL), so a
-// float4 is either fully inside or fully outside the operand. Out-of-range lanes read the (valid, aligned) base address and
-// the result is zeroed with selects: no divergent branch sits between the global loads and their consumers, which lets the
-// compiler issue the prefetch of tile t+1 before the MFMA block of tile t and wait for it only at the LDS stores.
-// NOTE the zeroing is deferred to the LDS store (mask bit per slot): a select right behind the load would make the compiler
-// wait for the data immediately (s_waitcnt vmcnt(0) in front of the MFMA block) instead of after it.
-__device__ __forceinline__ float4 ld4_safe(const float* __restrict__ q, const float* __restrict__ safe, bool ok) {
-    return *reinterpret_cast<const float4*>(ok ? q : safe);
+// ---- branch-free 16-byte loaders (VEC kernels): buffer loads with hardware range checking -----------------------------
+// Preconditions checked on the host: 16-byte aligned bases/strides, every operand slice < 2 GiB, K % 4 == 0 (ROW/CONV) resp.
+// rows % 4 == 0 (COL), so a float4 is either fully inside or fully outside the operand. Each operand gets a raw buffer
+// descriptor (wave-uniform, num_records = 2 GiB); a lane whose element is out of range (row/k tail, conv padding, transposed
+// stride-2 holes) issues the load at byte offset 0xFFFFFFF0, which the hardware answers with zeros. Consequences:
+//  * no divergent branch and no select sits between the global loads and their consumers, so the prefetch of tile t+1 is
+//    issued before the MFMA block of tile t and waited for only at the LDS stores;
+//  * address math is 32-bit and the zero-fill costs no VALU (the fp32 MFMA shares issue with the vector ALU: every VALU
+//    instruction removed from the k loop is MFMA time won — PMC in profiles/r01_pmc_conv.md).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = -16;   // 0xFFFFFFF0 >= num_records -> zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t srd, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// ROW operand: element (r, k) at byte (r*ld + k)*4. Per-slot row offsets are loop invariant.
 template <int ROWS>
-__device__ __forceinline__ unsigned load_row_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R, int k0,
-                                               int Kend, int tid) {
-    const int k = k0 + ((tid & 3) << 2);
-    unsigned mask = 0;
+struct RowOffs {
+    int off[ROWS / 64];     // (r*ld + kq*4)*4 or OOB
+    __device__ __forceinline__ void init(long ld, int r0, int R, int tid) {
 #pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        int r = r0 + ((tid + i * 256) >> 2);
-        bool ok = (r < R) && (k < Kend);
-        reg[i] = ld4_safe(p + (long)r * ld + k, p, ok);
-        mask |= ok ? (1u << i) : 0u;
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            off[i] = (r < R) ? (int)(((long)r * ld + ((tid & 3) << 2)) * 4) : OOB;
+        }
     }
-    return mask;
-}
+};
 template <int ROWS>
-__device__ __forceinline__ unsigned load_col_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, long ld, int r0, int R, int k0,
-                                               int Kend, int tid) {
+__device__ __forceinline__ void offs_row(int (&off)[ROWS / 64], const RowOffs<ROWS>& ro, int k0, int Kend, int tid) {
+    const bool kok = (k0 + ((tid & 3) << 2)) < Kend;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) off[i] = (kok && ro.off[i] != OOB) ? ro.off[i] + k0 * 4 : OOB;
+}
+// COL operand: element (r, k) at byte (k*ld + r)*4; a thread's slots differ in k
+template <int ROWS>
+__device__ __forceinline__ void offs_col(int (&off)[ROWS / 64], long ld, int r0, int R, int k0, int Kend, int tid) {
     constexpr int QPR = ROWS / 4;
-    unsigned mask = 0;
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
         int idx = tid + i * 256;
         int k = k0 + idx / QPR;
         int r = r0 + (idx % QPR) * 4;
-        bool ok = (k < Kend) && (r < R);
-        reg[i] = ld4_safe(p + (long)k * ld + r, p, ok);
-        mask |= ok ? (1u << i) : 0u;
+        off[i] = ((k < Kend) && (r < R)) ? (int)(((long)k * ld + r) * 4) : OOB;
     }
-    return mask;
 }
 template <int ROWS>
-__device__ __forceinline__ unsigned load_conv_v(float4 (&reg)[ROWS / 64], const float* __restrict__ p, const ConvGeom& g,
-                                                const ConvRows<ROWS>& cr, int k0, int Kend, int tid) {
+__device__ __forceinline__ void offs_conv(int (&off)[ROWS / 64], const ConvGeom& g, const ConvRows<ROWS>& cr, int k0, int Kend, int tid) {
     const int k = k0 + ((tid & 3) << 2);
     const int sh = (g.up | g.tr);
     const int Hv = g.H << sh, Wv = g.W << sh;
     const int ky = (g.ks == 3) ? ((cr.tap * 11) >> 5) : 0;
     const int kx = cr.tap - ky * g.ks;
     const bool kok = k < Kend;
-    unsigned mask = 0;
+    const int c4 = g.C * 4, ci4 = cr.ci * 4;
 #pragma unroll
     for (int i = 0; i < ROWS / 64; ++i) {
         int vy = cr.vy0[i] + ky, vx = cr.vx0[i] + kx;
-        bool ok = kok && (cr.nb[i] >= 0) && (vy >= 0) && (vx >= 0) && (vy < Hv) && (vx < Wv);
+        bool ok = kok && (cr.nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
         ok = ok && !(g.tr && ((vy | vx) & 1));
-        long off = ((long)(cr.nb[i] + (vy >> sh) * g.W + (vx >> sh))) * g.C + cr.ci;
-        reg[i] = ld4_safe(p + off, p, ok);
-        mask |= ok ? (1u << i) : 0u;
+        int pix = cr.nb[i] + (vy >> sh) * g.W + (vx >> sh);
+        off[i] = ok ? pix * c4 + ci4 : OOB;
     }
-    return mask;
+}
+
+// Fast conv gather (plain 1x1 / 3x3, stride 1 or 2, no upsample / transposed holes, C % BK == 0): a k-tile then lies inside
+// ONE tap for the whole workgroup, so the tap decode lives in scalar registers (uniform k0) and each lane only needs
+//   byte offset = base_off[slot] + delta(tap, ci)     valid = bit `tap` of a per-slot 9-bit mask
+// i.e. 4 VALU per 16-byte load instead of ~25 (bounds compares, shifts, 2 multiplies).
+template <int ROWS>
+struct ConvFast {
+    int base[ROWS / 64];      // ((n*H + oy*stride - pad)*W + ox*stride - pad)*C*4 + kq*16   (may be "negative": only used when valid)
+    unsigned vmask[ROWS / 64];
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            unsigned m = 0; int b = 0;
+            if (r < R) {
+                int n = r / HWo;
+                int rem = r - n * HWo;
+                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                int vy0 = oy * g.stride - g.pad, vx0 = ox * g.stride - g.pad;
+                for (int ky = 0; ky < g.ks; ++ky)
+                    for (int kx = 0; kx < g.ks; ++kx)
+                        if ((unsigned)(vy0 + ky) < (unsigned)g.H && (unsigned)(vx0 + kx) < (unsigned)g.W) m |= 1u << (ky * g.ks + kx);
+                b = (((n * g.H + vy0) * g.W + vx0) * g.C + ((tid & 3) << 2)) * 4;
+            }
+            vmask[i] = m; base[i] = b;
+        }
+    }
+};
+template <int ROWS>
+__device__ __forceinline__ void offs_conv_fast(int (&off)[ROWS / 64], const ConvFast<ROWS>& cf, int tap_u, int delta_u) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        bool ok = (cf.vmask[i] >> tap_u) & 1u;
+        off[i] = ok ? cf.base[i] + delta_u : OOB;
+    }
 }
 
 // ---- registers -> LDS (k-major tile [BK][ROWS+4]) -----------------------------------------
@@ -299,25 +341,46 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
 
     float4 ra[BM / 64], rb[BN / 64];
     ConvRows<BM> cr;
-    if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
+    ConvFast<BM> cf;
+    const bool conv_fast = VEC && AK == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % BK == 0);    // wave-uniform
+    int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0
+    if constexpr (AK == LD_CONV) {
+        if (conv_fast) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
+        else cr.init(a.g, m0, a.M, kbeg, tid);
+    }
 
-    unsigned ma = ~0u, mb = ~0u;     // VEC: per-slot validity of the prefetched float4 (zeroed at the LDS store)
-    auto loadA = [&](int k0) {
+    const unsigned ma = ~0u, mb = ~0u;
+    __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    RowOffs<BM> roA; RowOffs<BN> roB;
+    if constexpr (VEC && AK == LD_ROW) roA.init(a.lda, m0, a.M, tid);
+    if constexpr (VEC && BKIND == LD_ROW) roB.init(a.ldb, n0, a.N, tid);
+    // VEC: all byte offsets are computed first, then the 16-byte buffer loads are issued back to back (pinned by a
+    // sched_barrier): interleaving offset math with the loads made the register allocator reuse a load destination as an
+    // address temporary, which costs an s_waitcnt vmcnt(0) in the middle of the prefetch.
+    auto loadAB = [&](int k0) {
         if constexpr (VEC) {
-            if constexpr (AK == LD_ROW) ma = load_row_v<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, tid);
-            else if constexpr (AK == LD_COL) ma = load_col_v<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, tid);
-            else { ma = load_conv_v<BM>(ra, Ap, a.g, cr, k0, kend, tid); cr.advance(a.g); }
+            int oa[BM / 64], ob[BN / 64];
+            if constexpr (AK == LD_ROW) offs_row<BM>(oa, roA, k0, kend, tid);
+            else if constexpr (AK == LD_COL) offs_col<BM>(oa, a.lda, m0, a.M, k0, kend, tid);
+            else if (conv_fast) {
+                const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
+                const int kx = tap_u - ky * a.g.ks;
+                offs_conv_fast<BM>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 4);
+                ci_u += BK;
+                if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
+            } else { offs_conv<BM>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
+            if constexpr (BKIND == LD_ROW) offs_row<BN>(ob, roB, k0, kend, tid);
+            else offs_col<BN>(ob, a.ldb, n0, a.N, k0, kend, tid);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < BM / 64; ++i) ra[i] = buf_ld4(srdA, oa[i]);
+#pragma unroll
+            for (int i = 0; i < BN / 64; ++i) rb[i] = buf_ld4(srdB, ob[i]);
+            __builtin_amdgcn_sched_barrier(0);
         } else {
             if constexpr (AK == LD_ROW) load_row<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
             else if constexpr (AK == LD_COL) load_col<BM>(ra, Ap, a.lda, m0, a.M, k0, kend, p.a_vec, tid);
             else { load_conv<BM>(ra, Ap, a.g, cr, k0, kend, p.a_vec, tid); cr.advance(a.g); }
-        }
-    };
-    auto loadB = [&](int k0) {
-        if constexpr (VEC) {
-            if constexpr (BKIND == LD_ROW) mb = load_row_v<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, tid);
-            else mb = load_col_v<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, tid);
-        } else {
             if constexpr (BKIND == LD_ROW) load_row<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
             else load_col<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
         }
@@ -332,7 +395,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
     };
 
     if (kbeg < kend) {
-        loadA(kbeg); loadB(kbeg);
+        loadAB(kbeg);
         storeA(0); storeB(0);
     }
     __syncthreads();
@@ -341,7 +404,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
     const int kl = lane >> 5, ml = lane & 31;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
-        if (more) { loadA(k0 + BK); loadB(k0 + BK); }
+        if (more) loadAB(k0 + BK);
 
         // all MFMA fragments of the tile are requested from LDS up front; the compiler then waits with counted lgkmcnt(N)
         // in front of each MFMA group instead of a full drain per k-step
@@ -515,6 +578,13 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
 
     // branch-free 16-byte kernels need every float4 to be fully in or fully out of range
     bool vec = ka.a_vec && ka.b_vec;
+    {   // 32-bit byte offsets inside one operand slice (buffer loads)
+        const long lim = (1L << 31) - 64;
+        long ea = a.a_kind == LD_CONV ? (long)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C
+                                      : (a.a_kind == LD_ROW ? (long)a.M * a.lda : (long)a.K * a.lda);
+        long eb = a.b_kind == LD_ROW ? (long)a.N * a.ldb : (long)a.K * a.ldb;
+        vec = vec && ea * 4 < lim && eb * 4 < lim;
+    }
     if (a.a_kind == LD_COL) vec = vec && (a.M % 4 == 0); else vec = vec && (a.K % 4 == 0);
     if (a.b_kind == LD_COL) vec = vec && (a.N % 4 == 0); else vec = vec && (a.K % 4 == 0);
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
