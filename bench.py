@@ -106,6 +106,8 @@ def main():
         run(0)
         prof = ctx.profile_end()
         st = ctx.stats()
+        hbm = [p for p in prof if p.get("bytes", 0) > 0]        # HBM-bound kernel groups (GroupNorm / LayerNorm): algorithmic bytes
+        prof = [p for p in prof if p["flops"] > 0]              # MFMA-bound launches (GEMM family + fused attention)
         tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
         dom = max(prof, key=lambda p: p["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
@@ -116,7 +118,11 @@ def main():
                         all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
                                               achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
                         by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
-                                   for p in sorted(prof, key=lambda p: -p["ms"])])
+                                   for p in sorted(prof, key=lambda p: -p["ms"])],
+                        hbm_bound=[dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1),
+                                        ms=round(p["ms"], 3), achieved_gbps=round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1),
+                                        frac_of_8tbps=round(p["bytes"] / (p["ms"] * 1e-3) / 8e12, 4))
+                                   for p in sorted(hbm, key=lambda p: -p["ms"])])
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
         out = {

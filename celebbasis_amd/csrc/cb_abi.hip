@@ -115,21 +115,21 @@ int cb_ctx_profile_end(cb_ctx* ctx, char* json, int64_t cap) {
     Profiler& P = ctx->c.prof;
     P.on = false;
     CB_HIP(hipStreamSynchronize(ctx->c.stream));
-    std::vector<double> ms(P.names.size(), 0.0), fl(P.names.size(), 0.0);
+    std::vector<double> ms(P.names.size(), 0.0), fl(P.names.size(), 0.0), by(P.names.size(), 0.0);
     std::vector<long> cnt(P.names.size(), 0);
     for (auto& r : P.recs) {
         float t = 0.f;
         CB_HIP(hipEventElapsedTime(&t, r.e0, r.e1));
-        ms[r.variant] += t; fl[r.variant] += r.flops; cnt[r.variant]++;
+        ms[r.variant] += t; fl[r.variant] += r.flops; by[r.variant] += r.bytes; cnt[r.variant]++;
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     P.recs.clear();
     std::string out = "[";
     for (size_t i = 0; i < P.names.size(); ++i) {
         if (!cnt[i]) continue;
-        char buf[256];
-        snprintf(buf, sizeof buf, "%s{\"kernel\":\"%s\",\"launches\":%ld,\"flops\":%.6e,\"ms\":%.6f}", out.size() > 1 ? "," : "",
-                 P.names[i].c_str(), cnt[i], fl[i], ms[i]);
+        char buf[320];
+        snprintf(buf, sizeof buf, "%s{\"kernel\":\"%s\",\"launches\":%ld,\"flops\":%.6e,\"bytes\":%.6e,\"ms\":%.6f}",
+                 out.size() > 1 ? "," : "", P.names[i].c_str(), cnt[i], fl[i], by[i], ms[i]);
         out += buf;
     }
     out += "]";

@@ -40,11 +40,20 @@ struct Stats {
     long   gemm_launches = 0;
 };
 // per-launch HIP-event timing of the GEMM-class kernels (bench.py's live roofline measurement)
-struct ProfRec { int variant; double flops; hipEvent_t e0, e1; };
+struct ProfRec { int variant; double flops; hipEvent_t e0, e1; double bytes = 0; };
 struct Profiler {
     bool on = false;
     std::vector<ProfRec> recs;
     std::vector<std::string> names;
+    // helpers for non-GEMM launch groups: begin() returns false when profiling is off
+    bool begin(ProfRec* r, const char* name, double flops, double bytes, hipStream_t s) {
+        if (!on) return false;
+        r->variant = id_of(name); r->flops = flops; r->bytes = bytes;
+        if (hipEventCreate(&r->e0) != hipSuccess || hipEventCreate(&r->e1) != hipSuccess) return false;
+        (void)hipEventRecord(r->e0, s);
+        return true;
+    }
+    void end(ProfRec* r, hipStream_t s) { (void)hipEventRecord(r->e1, s); recs.push_back(*r); }
     int id_of(const std::string& n) {
         for (size_t i = 0; i < names.size(); ++i) if (names[i] == n) return (int)i;
         names.push_back(n);
@@ -107,7 +116,9 @@ struct FlashArgs {
     float* dvec = nullptr;           // [B*H][Nq]  rowsum(dO * O)
     float* dq = nullptr; float beta_q = 0.f;                      // layout of q
     float* dk = nullptr; float* dv = nullptr; float beta_kv = 0.f; // layout of k / v
+    float* ws = nullptr; int nsplit = 1;   // dK/dV query-split partials [2][nsplit][B*H][Nk][d] (cross-attention: few keys, many queries)
 };
+size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
 bool flash_supported(int d, const FlashArgs& a);
 void flash_forward(const Launch& L, const FlashArgs& a, int B);
 void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv);

@@ -353,7 +353,11 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
                     if (qt->rg) gq = grad(qt, &bq);
                     if (kt->rg) { if (kt == qt) { gk = gq; bk = bq; } else gk = grad(kt, &bk); }
                     if (gq) { f.dq = gq + qoff; f.beta_q = bq; }
-                    if (gk) { f.dk = gk + koff; f.dv = gk + voff; f.beta_kv = bk; }
+                    if (gk) {
+                        f.dk = gk + koff; f.dv = gk + voff; f.beta_kv = bk;
+                        size_t wsf = flash_bwd_ws_floats(f, B, &f.nsplit);
+                        if (wsf) f.ws = ctx->arena.allocf(wsf);
+                    }
                     flash_backward(L, f, B, gq != nullptr, gk != nullptr);
                 });
             }

@@ -37,38 +37,56 @@ template <int DT> struct FlCfg {
 };
 
 // Streamed tiles (TK rows x d floats, row-major source) go global -> registers -> LDS T[TK][S2]. The register stage is a
-// software prefetch: the loads of tile t+1 are issued before the MFMA work of tile t and land in LDS after it. Loads are
-// branch-free (out-of-range lanes read the base address; zeros are selected at the LDS store) so nothing forces an early wait.
+// software prefetch: the buffer loads of tile t+1 are issued before the MFMA work of tile t and land in LDS after it.
+// Raw buffer loads zero-fill out-of-range lanes in hardware (rows beyond the tensor, head-dim padding columns), and the
+// per-thread (row, column) decode is loop invariant, so a tile costs ~3 VALU per 16-byte load (the fp32 MFMA shares issue
+// with the vector ALU: VALU in the loop is MFMA time lost).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int FL_OOB = -16;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t fl_srd(const float* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
 template <int DT> struct FlTile {
     static constexpr int Q = FlCfg<DT>::DP / 4;                               // float4 per row
     static constexpr int N = (FlCfg<DT>::TK * Q + 255) / 256;                 // float4 per thread
 };
+template <int DT> struct FlStream {
+    int goff[FlTile<DT>::N];      // (r*ld + c)*4 inside the source slice, FL_OOB for padding columns / unused slots
+    int loff[FlTile<DT>::N];      // r*S2 + c in the LDS tile, -1 for unused slots
+    int row[FlTile<DT>::N];
+    __device__ __forceinline__ void init(long ld, int d) {
+        constexpr int Q = FlTile<DT>::Q;
+#pragma unroll
+        for (int j = 0; j < FlTile<DT>::N; ++j) {
+            int i = threadIdx.x + j * 256;
+            int r = i / Q, c = (i - r * Q) * 4;
+            bool used = i < FlCfg<DT>::TK * Q;
+            row[j] = r;
+            loff[j] = used ? r * FlCfg<DT>::S2 + c : -1;
+            goff[j] = (used && c < d) ? (int)(((long)r * ld + c) * 4) : FL_OOB;           // d % 4 == 0
+        }
+    }
+};
 template <int DT>
-__device__ __forceinline__ void fl_prefetch(float4 (&reg)[FlTile<DT>::N], const float* __restrict__ src, long ld, int row0, int limit,
-                                            int d) {
-    constexpr int Q = FlTile<DT>::Q;
+__device__ __forceinline__ void fl_prefetch(float4 (&reg)[FlTile<DT>::N], __amdgpu_buffer_rsrc_t srd, const FlStream<DT>& st, int row0,
+                                            int limit, long ld) {
+    const int base = (int)((long)row0 * ld * 4);          // wave-uniform
 #pragma unroll
     for (int j = 0; j < FlTile<DT>::N; ++j) {
-        int i = threadIdx.x + j * 256;
-        int r = i / Q, c = (i - r * Q) * 4;
-        bool ok = (i < FlCfg<DT>::TK * Q) && (row0 + r < limit) && (c < d);
-        reg[j] = *reinterpret_cast<const float4*>(ok ? src + (long)(row0 + r) * ld + c : src);   // d % 4 == 0
+        bool ok = (st.goff[j] != FL_OOB) && (row0 + st.row[j] < limit);
+        u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, ok ? st.goff[j] + base : FL_OOB, 0, 0);
+        reg[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
     }
 }
 template <int DT>
-__device__ __forceinline__ void fl_store(float* T, const float4 (&reg)[FlTile<DT>::N], int row0, int limit, int d) {
-    constexpr int Q = FlTile<DT>::Q, S2 = FlCfg<DT>::S2;
+__device__ __forceinline__ void fl_store(float* T, const float4 (&reg)[FlTile<DT>::N], const FlStream<DT>& st) {
 #pragma unroll
-    for (int j = 0; j < FlTile<DT>::N; ++j) {
-        int i = threadIdx.x + j * 256;
-        int r = i / Q, c = (i - r * Q) * 4;
-        if (i < FlCfg<DT>::TK * Q) {
-            bool ok = (row0 + r < limit) && (c < d);
-            float* t = T + r * S2 + c;                       // S2 is even: 8-byte aligned pairs
-            *reinterpret_cast<float2*>(t) = ok ? make_float2(reg[j].x, reg[j].y) : make_float2(0.f, 0.f);
-            *reinterpret_cast<float2*>(t + 2) = ok ? make_float2(reg[j].z, reg[j].w) : make_float2(0.f, 0.f);
+    for (int j = 0; j < FlTile<DT>::N; ++j)
+        if (st.loff[j] >= 0) {
+            float* t = T + st.loff[j];                       // S2 is even: 8-byte aligned pairs
+            *reinterpret_cast<float2*>(t) = make_float2(reg[j].x, reg[j].y);
+            *reinterpret_cast<float2*>(t + 2) = make_float2(reg[j].z, reg[j].w);
         }
-    }
 }
 
 // per-lane register copy of row `row` (B operand of a transposed MFMA): reg[s] = src[row][4*s + quarter] * mul, 0 beyond d / limit
@@ -97,8 +115,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     const float* K = a.k + b * a.skb + h * a.skh;
     const float* V = a.v + b * a.skb + h * a.skh;
 
+    // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e) so that softmax needs a bare v_exp_f32
     float qreg[C::KS];
-    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale);
+    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale * 1.4426950408889634f);
     f32x4 o[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -106,17 +125,19 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
 
     int kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);      // keys beyond the last query of the block are fully masked
+    const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
+    FlStream<DT> st; st.init(a.ldk, a.d);
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, K, a.ldk, 0, a.Nk, a.d);
-    fl_prefetch<DT>(pv, V, a.ldk, 0, a.Nk, a.d);
+    fl_prefetch<DT>(pk, srdK, st, 0, a.Nk, a.ldk);
+    fl_prefetch<DT>(pv, srdV, st, 0, a.Nk, a.ldk);
     for (int k0 = 0; k0 < kend; k0 += C::TK) {
         __syncthreads();
-        fl_store<DT>(Ks, pk, k0, a.Nk, a.d);
-        fl_store<DT>(Vs, pv, k0, a.Nk, a.d);
+        fl_store<DT>(Ks, pk, st);
+        fl_store<DT>(Vs, pv, st);
         __syncthreads();
         if (k0 + C::TK < kend) {
-            fl_prefetch<DT>(pk, K, a.ldk, k0 + C::TK, a.Nk, a.d);
-            fl_prefetch<DT>(pv, V, a.ldk, k0 + C::TK, a.Nk, a.d);
+            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
         }
         f32x4 s[C::NT];
 #pragma unroll
@@ -128,28 +149,32 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
                 float av = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qreg[st], s[kt], 0, 0, 0);
             }
-        // mask + online softmax (per query = per lane quartet)
+        // mask (only on the ragged last tile / causal diagonal: wave-uniform branch) + online softmax per lane quartet
+        if (a.causal || k0 + C::TK > a.Nk) {
+#pragma unroll
+            for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int key = k0 + kt * 16 + quarter * 4 + r;
+                    bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                }
+        }
         float mx = -INFINITY;
 #pragma unroll
         for (int kt = 0; kt < C::NT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int key = k0 + kt * 16 + quarter * 4 + r;
-                bool ok = key < a.Nk && (!a.causal || key <= qrow);
-                float v = ok ? s[kt][r] : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
         mx = quad_max(mx);
         float mnew = fmaxf(m, mx);
         float muse = (mnew == -INFINITY) ? 0.f : mnew;
-        float alpha = __expf(m - muse);            // m = -inf -> 0
+        float alpha = __builtin_amdgcn_exp2f(m - muse);            // m = -inf -> 0
         float ps = 0.f;
 #pragma unroll
         for (int kt = 0; kt < C::NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                float p = __expf(s[kt][r] - muse);
+                float p = __builtin_amdgcn_exp2f(s[kt][r] - muse);
                 s[kt][r] = p;
                 ps += p;
             }
@@ -176,7 +201,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
             int c = t * 16 + quarter * 4;
             if (c < a.d) *reinterpret_cast<float4*>(O + c) = make_float4(o[t][0] * inv, o[t][1] * inv, o[t][2] * inv, o[t][3] * inv);
         }
-        if (quarter == 0 && a.lse) a.lse[(long)bh * a.Nq + qrow] = m + __logf(l);
+        if (quarter == 0 && a.lse) a.lse[(long)bh * a.Nq + qrow] = m + __builtin_amdgcn_logf(l);   // log2 domain
     }
 }
 
@@ -212,7 +237,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     const float* dO = a.dout + b * a.sob + h * a.soh;
 
     float qreg[C::KS], dreg[C::KS];
-    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale);
+    fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale * 1.4426950408889634f);
     fl_load_rowregs<DT>(dreg, dO, a.ldo, qrow, a.Nq, a.d, quarter, 1.f);
     const float lse = qrow < a.Nq ? a.lse[(long)bh * a.Nq + qrow] : 0.f;
     const float Dq = qrow < a.Nq ? a.dvec[(long)bh * a.Nq + qrow] : 0.f;
@@ -222,17 +247,19 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
 
     int kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);
+    const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
+    FlStream<DT> st; st.init(a.ldk, a.d);
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, K, a.ldk, 0, a.Nk, a.d);
-    fl_prefetch<DT>(pv, V, a.ldk, 0, a.Nk, a.d);
+    fl_prefetch<DT>(pk, srdK, st, 0, a.Nk, a.ldk);
+    fl_prefetch<DT>(pv, srdV, st, 0, a.Nk, a.ldk);
     for (int k0 = 0; k0 < kend; k0 += C::TK) {
         __syncthreads();
-        fl_store<DT>(Ks, pk, k0, a.Nk, a.d);
-        fl_store<DT>(Vs, pv, k0, a.Nk, a.d);
+        fl_store<DT>(Ks, pk, st);
+        fl_store<DT>(Vs, pv, st);
         __syncthreads();
         if (k0 + C::TK < kend) {
-            fl_prefetch<DT>(pk, K, a.ldk, k0 + C::TK, a.Nk, a.d);
-            fl_prefetch<DT>(pv, V, a.ldk, k0 + C::TK, a.Nk, a.d);
+            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
         }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
@@ -246,13 +273,17 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
                 s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qreg[st], s[kt], 0, 0, 0);      // S^T  = K Q^T
                 dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dreg[st], dp[kt], 0, 0, 0);    // dP^T = V dO^T
             }
+        const bool need_mask = a.causal || k0 + C::TK > a.Nk;          // wave-uniform
 #pragma unroll
         for (int kt = 0; kt < C::NT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                int key = k0 + kt * 16 + quarter * 4 + r;
-                bool ok = key < a.Nk && (!a.causal || key <= qrow);
-                float p = ok ? __expf(s[kt][r] - lse) : 0.f;
+                float p = __builtin_amdgcn_exp2f(s[kt][r] - lse);
+                if (need_mask) {
+                    int key = k0 + kt * 16 + quarter * 4 + r;
+                    bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                    p = ok ? p : 0.f;
+                }
                 s[kt][r] = p * (dp[kt][r] - Dq) * a.scale;                                        // d(q.k)
             }
         // dQ^T += K^T dS^T
@@ -309,24 +340,30 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
 #pragma unroll
     for (int t = 0; t < DT; ++t) { gk[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; gv[t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 
-    int qbeg = 0;
-    if (a.causal) qbeg = (k0 / C::TK) * C::TK;        // queries before the first key of the block see none of its keys
+    // cross-attention has few keys and many queries: blockIdx.z splits the query range, partial dK/dV go to a workspace
+    const int qchunk = ((a.Nq + a.nsplit - 1) / a.nsplit + C::TK - 1) / C::TK * C::TK;
+    int qbeg = blockIdx.z * qchunk;
+    const int qlim = min(a.Nq, qbeg + qchunk);
+    if (a.causal) qbeg = max(qbeg, (k0 / C::TK) * C::TK);   // queries before the first key of the block see none of its keys
+    const __amdgpu_buffer_rsrc_t srdQ = fl_srd(Q), srdD = fl_srd(dO);
+    FlStream<DT> stq, sto; stq.init(a.ldq, a.d); sto.init(a.ldo, a.d);
+    const float scale2 = a.scale * 1.4426950408889634f;
     float4 pq[FlTile<DT>::N], pd[FlTile<DT>::N];
-    fl_prefetch<DT>(pq, Q, a.ldq, qbeg, a.Nq, a.d);
-    fl_prefetch<DT>(pd, dO, a.ldo, qbeg, a.Nq, a.d);
-    for (int q0 = qbeg; q0 < a.Nq; q0 += C::TK) {
+    fl_prefetch<DT>(pq, srdQ, stq, qbeg, a.Nq, a.ldq);
+    fl_prefetch<DT>(pd, srdD, sto, qbeg, a.Nq, a.ldo);
+    for (int q0 = qbeg; q0 < qlim; q0 += C::TK) {
         __syncthreads();
-        fl_store<DT>(Qs, pq, q0, a.Nq, a.d);
-        fl_store<DT>(Ds, pd, q0, a.Nq, a.d);
+        fl_store<DT>(Qs, pq, stq);
+        fl_store<DT>(Ds, pd, sto);
         if (threadIdx.x < C::TK) {
             int qi = q0 + threadIdx.x;
             Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
             Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
         }
         __syncthreads();
-        if (q0 + C::TK < a.Nq) {
-            fl_prefetch<DT>(pq, Q, a.ldq, q0 + C::TK, a.Nq, a.d);
-            fl_prefetch<DT>(pd, dO, a.ldo, q0 + C::TK, a.Nq, a.d);
+        if (q0 + C::TK < qlim) {
+            fl_prefetch<DT>(pq, srdQ, stq, q0 + C::TK, a.Nq, a.ldq);
+            fl_prefetch<DT>(pd, srdD, sto, q0 + C::TK, a.Nq, a.ldo);
         }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
@@ -341,13 +378,17 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
                 dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, vreg[st], dp[qt], 0, 0, 0);
             }
         // rows of the C layout are queries 4*quarter + r of sub-tile qt, the column is this lane's key
+        const bool need_mask = a.causal || q0 + C::TK > a.Nq || k0 + FL_ROWS > a.Nk;   // wave-uniform
 #pragma unroll
         for (int qt = 0; qt < C::NT; ++qt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 int ql = qt * 16 + quarter * 4 + r, qi = q0 + ql;
-                bool ok = qi < a.Nq && krow < a.Nk && (!a.causal || krow <= qi);
-                float p = ok ? __expf(s[qt][r] * a.scale - Ls[ql]) : 0.f;
+                float p = __builtin_amdgcn_exp2f(s[qt][r] * scale2 - Ls[ql]);
+                if (need_mask) {
+                    bool ok = qi < a.Nq && krow < a.Nk && (!a.causal || krow <= qi);
+                    p = ok ? p : 0.f;
+                }
                 float ds = p * (dp[qt][r] - Ls[C::TK + ql]) * a.scale;
                 s[qt][r] = p;
                 dp[qt][r] = ds;
@@ -363,6 +404,22 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
                     gv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s[qt][r], gv[t], 0, 0, 0);
                     gk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dp[qt][r], gk[t], 0, 0, 0);
                 }
+    }
+    if (a.nsplit > 1) {
+        if (krow < a.Nk) {
+            const long slab = (long)gridDim.y * a.Nk * a.d;
+            float* WK = a.ws + ((long)blockIdx.z * gridDim.y + bh) * a.Nk * a.d + (long)krow * a.d;
+            float* WV = WK + (long)a.nsplit * slab;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                int c = t * 16 + quarter * 4;
+                if (c < a.d) {
+                    *reinterpret_cast<float4*>(WK + c) = make_float4(gk[t][0], gk[t][1], gk[t][2], gk[t][3]);
+                    *reinterpret_cast<float4*>(WV + c) = make_float4(gv[t][0], gv[t][1], gv[t][2], gv[t][3]);
+                }
+            }
+        }
+        return;
     }
     if (krow < a.Nk) {
         float* GK = a.dk + b * a.skb + h * a.skh + (long)krow * a.ldk;
@@ -385,12 +442,58 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     }
 }
 
+// sum the query-split partials: one thread per (bh, key, 4 head-dim columns), dK and dV
+__global__ __launch_bounds__(256) void flash_dkv_reduce_kernel(const FlashArgs a, int BH) {
+    const int dq4 = a.d / 4;
+    long total = (long)BH * a.Nk * dq4;
+    const long slab = (long)BH * a.Nk * a.d;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        int c = (int)(i % dq4) * 4;
+        long r = i / dq4;
+        int key = (int)(r % a.Nk);
+        int bh = (int)(r / a.Nk), b = bh / a.H, h = bh - b * a.H;
+        const float* wk = a.ws + ((long)bh * a.Nk + key) * a.d + c;
+        const float* wv = wk + (long)a.nsplit * slab;
+        float4 sk = make_float4(0.f, 0.f, 0.f, 0.f), sv = sk;
+        for (int sp = 0; sp < a.nsplit; ++sp) {
+            float4 x = *reinterpret_cast<const float4*>(wk + sp * slab), y = *reinterpret_cast<const float4*>(wv + sp * slab);
+            sk.x += x.x; sk.y += x.y; sk.z += x.z; sk.w += x.w;
+            sv.x += y.x; sv.y += y.y; sv.z += y.z; sv.w += y.w;
+        }
+        float* GK = a.dk + b * a.skb + h * a.skh + (long)key * a.ldk + c;
+        float* GV = a.dv + b * a.skb + h * a.skh + (long)key * a.ldk + c;
+        if (a.beta_kv != 0.f) {
+            float4 ok = *reinterpret_cast<float4*>(GK), ov = *reinterpret_cast<float4*>(GV);
+            sk.x += ok.x; sk.y += ok.y; sk.z += ok.z; sk.w += ok.w;
+            sv.x += ov.x; sv.y += ov.y; sv.z += ov.z; sv.w += ov.w;
+        }
+        *reinterpret_cast<float4*>(GK) = sk;
+        *reinterpret_cast<float4*>(GV) = sv;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host
+size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit) {
+    const int BH = B * a.H;
+    long blocks0 = (long)cdiv(a.Nk, FL_ROWS) * BH;
+    int ns = 1;
+    if (blocks0 < 128 && a.Nq >= 512 && !a.causal) {
+        ns = (int)((256 + blocks0 - 1) / blocks0);
+        int maxs = a.Nq / 128;                      // at least two 64-query tiles per split
+        if (ns > maxs) ns = maxs;
+        if (ns < 1) ns = 1;
+    }
+    *nsplit = ns;
+    return ns > 1 ? (size_t)2 * ns * BH * a.Nk * a.d : 0;
+}
+
 bool flash_supported(int d, const FlashArgs& a) {
     auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
     bool strides = (a.ldq % 4 == 0) && (a.ldk % 4 == 0) && (a.ldo % 4 == 0) && (a.sqb % 4 == 0) && (a.sqh % 4 == 0) &&
                    (a.skb % 4 == 0) && (a.skh % 4 == 0) && (a.sob % 4 == 0) && (a.soh % 4 == 0);
-    return d >= 4 && d <= 160 && d % 4 == 0 && strides && al(a.q) && al(a.k) && al(a.v) && al(a.o);
+    const long lim = (1L << 31) - 64;
+    bool small = (long)a.Nq * a.ldq * 4 < lim && (long)a.Nk * a.ldk * 4 < lim && (long)a.Nq * a.ldo * 4 < lim;   // 32-bit buffer offsets
+    return d >= 4 && d <= 160 && d % 4 == 0 && strides && small && al(a.q) && al(a.k) && al(a.v) && al(a.o);
 }
 
 template <int DT> static size_t fl_lds_bytes(bool dkv) {
@@ -441,7 +544,7 @@ void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bo
     // algorithmic (reference-equivalent) work: dP, dQ | dK, dV — the recomputation of S inside both kernels is not counted
     double fl = 2.0 + (need_dq ? 2.0 : 0.0) + (need_dkv ? 4.0 : 0.0);
     if (L.stats) { L.stats->gemm_flops += fl * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count(1 + (need_dq ? 1 : 0) + (need_dkv ? 1 : 0));
+    L.count(1 + (need_dq ? 1 : 0) + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
     if (L.dry) return;
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
@@ -454,9 +557,14 @@ void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bo
         FL_DISPATCH(dt, flash_bwd_dq_kernel, grid, LDSF, a)
     }
     if (need_dkv) {
-        dim3 grid(cdiv(a.Nk, FL_ROWS), BH);
+        CB_CHECK(a.nsplit == 1 || a.ws, CB_ERR_STATE, "flash backward: query-split workspace missing");
+        dim3 grid(cdiv(a.Nk, FL_ROWS), BH, a.nsplit);
 #define LDSK(x) lds_dkv(x)
         FL_DISPATCH(dt, flash_bwd_dkv_kernel, grid, LDSK, a)
+        if (a.nsplit > 1) {
+            long total = (long)BH * a.Nk * (a.d / 4);
+            hipLaunchKernelGGL(flash_dkv_reduce_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, L.stream, a, BH);
+        }
     }
     CB_HIP(hipGetLastError());
     if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }

@@ -394,10 +394,12 @@ void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gam
     float* chn = ws + (size_t)N * nchunk * G * 2;
     (void)L.count(3);
     if (L.dry) return;
+    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? "groupnorm_silu_fwd" : "groupnorm_fwd", 0.0, 3.0 * N * HW * (double)C * 4, L.stream);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, HW, C, G, nchunk, rpb);
     hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, x, gamma, beta, N, HW, C, G, nchunk, eps);
     long nquads = (long)N * HW * (C / 4);
     hipLaunchKernelGGL(gn_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, y, x, chn, nquads, HW, C, silu);
+    if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
 }
 
@@ -500,6 +502,7 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
     float* gs = chn + (size_t)N * C * 4;
     (void)L.count(4);
     if (L.dry) return;
+    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? "groupnorm_silu_bwd" : "groupnorm_bwd", 0.0, 5.0 * N * HW * (double)C * 4, L.stream);
     hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, dy, chn, HW, C, G,
                        nchunk, rpb, silu);
@@ -507,6 +510,7 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
     long nquads = (long)N * HW * (C / 4);
     hipLaunchKernelGGL(gn_bwd_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, dx, x, dy, chn, gs, nquads, HW, C, silu,
                        acc_beta);
+    if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
 }
 
@@ -547,7 +551,9 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
 void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, long rows,
                      int C, float eps) {
     CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm: C=%d too large", C);
+    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_fwd", 0.0, 2.0 * rows * (double)C * 4, L.stream);
     LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, y, x, gamma, beta, stats, rows, C, eps);
+    if (prof) L.prof->end(&rec, L.stream);
 }
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x,
                                                              const float* __restrict__ dy, const float* __restrict__ gamma,
@@ -586,7 +592,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
 void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* stats,
                      long rows, int C, float acc_beta) {
     CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm bwd: C=%d too large", C);
+    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_bwd", 0.0, 3.0 * rows * (double)C * 4, L.stream);
     LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, x, dy, gamma, stats, rows, C, acc_beta);
+    if (prof) L.prof->end(&rec, L.stream);
 }
 
 // ------------------------------------------------------------------ row softmax (materialised attention path)
