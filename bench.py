@@ -106,6 +106,8 @@ def main():
         run(0)
         prof = ctx.profile_end()
         st = ctx.stats()
+        phases = {p["kernel"][6:]: round(p["ms"], 3) for p in prof if p["kernel"].startswith("phase:")}
+        prof = [p for p in prof if not p["kernel"].startswith("phase:")]
         hbm = [p for p in prof if p.get("bytes", 0) > 0]        # HBM-bound kernel groups (GroupNorm / LayerNorm): algorithmic bytes
         prof = [p for p in prof if p["flops"] > 0]              # MFMA-bound launches (GEMM family + fused attention)
         tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
@@ -138,6 +140,7 @@ def main():
             "step_tflop": round(st["gemm_flops"] / 1e12, 4),
             "step_tflops_per_gpu": round(st["gemm_flops"] / 1e12 / (ms_per_step * 1e-3), 2),
             "loss": loss,
+            "phase_ms": phases,
             "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()),
             "roofline": roofline,
         }

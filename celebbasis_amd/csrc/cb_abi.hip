@@ -48,6 +48,9 @@ int cb_ctx_create(int device, void* hip_stream, cb_ctx** out) {
         CB_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, CB_ERR_HIP,
                  "libcelebbasis_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
         c.stream = static_cast<hipStream_t>(hip_stream);
+        CB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+        CB_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
+        CB_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
     }
     *out = h.release();
     CB_END

@@ -59,6 +59,8 @@ struct WTab {
 struct Ctx {
     int device = -1;             // -1: dry (no GPU): shape checks and accounting only
     hipStream_t stream = nullptr;
+    hipStream_t aux = nullptr;           // library-owned side stream: independent branches of the step (FR-net || VAE encode)
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     bool dry = true;
     Arena arena;                 // per-step activations
     Pool pool;                   // persistent

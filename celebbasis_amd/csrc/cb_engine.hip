@@ -42,6 +42,9 @@ void Ctx::ensure_arena(size_t bytes) {
 Ctx::~Ctx() {
     if (!dry) {
         (void)hipStreamSynchronize(stream);
+        if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (arena.base) (void)hipFree(arena.base);
         pool.release();
     }
@@ -177,6 +180,13 @@ static void accumulate(Graph* G, Ten* t, const float* src) {
     float* g = G->grad(t, &beta);
     k_axpby(G->L, g, src, t->numel(), 1.f, beta);
 }
+// y = f(...) + residual: d residual = dy. When nothing has been written to residual.g yet, the residual simply ADOPTS
+// y.g as its gradient buffer (no copy): y.g is dead after y's own backward closure — the tape runs each closure once, in
+// reverse order, and only the closure of the op that produced y reads y.g.
+static void pass_grad_to_residual(Graph* G, Ten* residual, Ten* y) {
+    if (!residual->g && !residual->ginit) { residual->g = y->g; residual->ginit = true; return; }
+    accumulate(G, residual, y->g);
+}
 
 // ---------------------------------------------------------------- conv
 void conv_out_dims(const Conv& cv, ConvMode mode, int H, int W, int* Ho, int* Wo, ConvGeom* g) {
@@ -247,7 +257,7 @@ Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* resid
         Conv cvc = cv;
         tape.push_back([this, x, y, residual, cvc, mode]() {
             if (!y->ginit) return;
-            if (residual && residual->rg) accumulate(this, residual, y->g);
+            if (residual && residual->rg) pass_grad_to_residual(this, residual, y);
             if (!x->rg) return;
             float beta; float* gx = grad(x, &beta);
             conv_dgrad(this, y->g, cvc, mode, x->n, x->h, x->w, gx, beta);
@@ -276,7 +286,7 @@ Ten* Graph::linear(Ten* x, const Lin& l, Ten* residual) {
         Lin lc = l;
         tape.push_back([this, x, y, residual, lc, rows]() {
             if (!y->ginit) return;
-            if (residual && residual->rg) accumulate(this, residual, y->g);
+            if (residual && residual->rg) pass_grad_to_residual(this, residual, y);
             if (!x->rg) return;
             GemmArgs d;   // dx[rows,in] = dy[rows,out] . W[out,in]
             d.A = y->g; d.lda = lc.out; d.a_kind = LD_ROW;

@@ -240,7 +240,18 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale * 1.4426950408889634f);
     fl_load_rowregs<DT>(dreg, dO, a.ldo, qrow, a.Nq, a.d, quarter, 1.f);
     const float lse = qrow < a.Nq ? a.lse[(long)bh * a.Nq + qrow] : 0.f;
-    const float Dq = qrow < a.Nq ? a.dvec[(long)bh * a.Nq + qrow] : 0.f;
+    float Dq = 0.f;     // D = rowsum(dO * O), computed here and published for the dK/dV kernel that runs next
+    {
+        const float* O = a.o + b * a.sob + h * a.soh;
+#pragma unroll
+        for (int s_ = 0; s_ < C::KS; ++s_) {
+            int c = 4 * s_ + quarter;
+            float ov = (qrow < a.Nq && c < a.d) ? O[(long)qrow * a.ldo + c] : 0.f;
+            Dq += ov * dreg[s_];
+        }
+        Dq = quad_sum(Dq);
+        if (quarter == 0 && qrow < a.Nq) a.dvec[(long)bh * a.Nq + qrow] = Dq;
+    }
     f32x4 g[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) g[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -544,14 +555,14 @@ void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bo
     // algorithmic (reference-equivalent) work: dP, dQ | dK, dV — the recomputation of S inside both kernels is not counted
     double fl = 2.0 + (need_dq ? 2.0 : 0.0) + (need_dkv ? 4.0 : 0.0);
     if (L.stats) { L.stats->gemm_flops += fl * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count(1 + (need_dq ? 1 : 0) + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
+    L.count(1 + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
     if (L.dry) return;
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
         rec.variant = L.prof->id_of("flash_bwd_kernels"); rec.flops = fl * BH * (double)a.Nq * a.Nk * a.d;
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
-    hipLaunchKernelGGL(flash_dvec_kernel, dim3(cdiv((long)BH * a.Nq, 4)), dim3(256), 0, L.stream, a, BH);
+    if (!need_dq) hipLaunchKernelGGL(flash_dvec_kernel, dim3(cdiv((long)BH * a.Nq, 4)), dim3(256), 0, L.stream, a, BH);
     if (need_dq) {
         dim3 grid(cdiv(a.Nq, FL_ROWS), BH);
         FL_DISPATCH(dt, flash_bwd_dq_kernel, grid, LDSF, a)

@@ -514,84 +514,96 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
     CB_HIP(hipGetLastError());
 }
 
-// ------------------------------------------------------------------ LayerNorm: one wave per row, C <= 64*24
-constexpr int LN_MAX_PER_LANE = 24;
+// ------------------------------------------------------------------ LayerNorm: one wave per row, row held in registers
+// attention.py:203-205 norm1..3, HF CLIP layer norms. HBM-bound: 16-byte accesses (C % 4 == 0), C <= 64*4*LN_MAXQ.
+constexpr int LN_MAXQ = 6;
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, const float* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ stats, long rows, int C, float eps) {
     long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= rows) return;
-    int lane = threadIdx.x & 63;
-    const float* xr = x + row * C;
-    float v[LN_MAX_PER_LANE];
+    const int lane = threadIdx.x & 63, Q = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    float4 v[LN_MAXQ];
     float s = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
-        int c = lane + j * 64;
-        v[j] = (c < C) ? xr[c] : 0.f;
-        s += v[j];
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        int q = lane + j * 64;
+        v[j] = (q < Q) ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
-    float mean = wave_sum(s) / C;
-    float q = 0.f;
+    const float mean = wave_sum(s) / C;
+    float qd = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
-        int c = lane + j * 64;
-        float d = (c < C) ? v[j] - mean : 0.f;
-        q += d * d;
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        if (lane + j * 64 < Q) {
+            float a = v[j].x - mean, b = v[j].y - mean, c = v[j].z - mean, d = v[j].w - mean;
+            qd += (a * a + b * b) + (c * c + d * d);
+        }
     }
-    float rstd = 1.f / sqrtf(wave_sum(q) / C + eps);
+    const float rstd = 1.f / sqrtf(wave_sum(qd) / C + eps);
     if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
-    float* yr = y + row * C;
+    float4* yr = reinterpret_cast<float4*>(y + row * C);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
-        int c = lane + j * 64;
-        if (c < C) yr[c] = (v[j] - mean) * rstd * gamma[c] + beta[c];
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        int q = lane + j * 64;
+        if (q < Q) {
+            float4 g = g4[q], b = b4[q];
+            yr[q] = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                                (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+        }
     }
 }
 void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, long rows,
                      int C, float eps) {
-    CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm: C=%d too large", C);
+    CB_CHECK(C % 4 == 0 && C <= 256 * LN_MAXQ, CB_ERR_SHAPE, "layernorm: C=%d unsupported", C);
     ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_fwd", 0.0, 2.0 * rows * (double)C * 4, L.stream);
     LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, y, x, gamma, beta, stats, rows, C, eps);
     if (prof) L.prof->end(&rec, L.stream);
 }
+// dx = rstd * (dy*gamma - mean(dy*gamma) - x_hat * mean(dy*gamma*x_hat))
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x,
                                                              const float* __restrict__ dy, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, long rows, int C, float acc_beta) {
     long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= rows) return;
-    int lane = threadIdx.x & 63;
-    const float* xr = x + row * C;
-    const float* dr = dy + row * C;
-    float mean = stats[row * 2], rstd = stats[row * 2 + 1];
-    float xh[LN_MAX_PER_LANE], dg[LN_MAX_PER_LANE];
+    const int lane = threadIdx.x & 63, Q = C >> 2;
+    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+    const float4* g4 = reinterpret_cast<const float4*>(gamma);
+    const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
+    float4 xh[LN_MAXQ], dg[LN_MAXQ];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
-        int c = lane + j * 64;
-        if (c < C) {
-            xh[j] = (xr[c] - mean) * rstd;
-            dg[j] = dr[c] * gamma[c];
-        } else { xh[j] = 0.f; dg[j] = 0.f; }
-        s1 += dg[j];
-        s2 += dg[j] * xh[j];
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        int q = lane + j * 64;
+        if (q < Q) {
+            float4 xv = xr[q], dv = dr[q], g = g4[q];
+            xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
+            dg[j] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
+        } else { xh[j] = make_float4(0.f, 0.f, 0.f, 0.f); dg[j] = xh[j]; }
+        s1 += (dg[j].x + dg[j].y) + (dg[j].z + dg[j].w);
+        s2 += (dg[j].x * xh[j].x + dg[j].y * xh[j].y) + (dg[j].z * xh[j].z + dg[j].w * xh[j].w);
     }
     s1 = wave_sum(s1) / C;
     s2 = wave_sum(s2) / C;
-    float* o = dx + row * C;
+    float4* o = reinterpret_cast<float4*>(dx + row * C);
 #pragma unroll
-    for (int j = 0; j < LN_MAX_PER_LANE; ++j) {
-        int c = lane + j * 64;
-        if (c < C) {
-            float v = rstd * (dg[j] - s1 - xh[j] * s2);
-            if (acc_beta != 0.f) v += acc_beta * o[c];
-            o[c] = v;
+    for (int j = 0; j < LN_MAXQ; ++j) {
+        int q = lane + j * 64;
+        if (q < Q) {
+            float4 r = make_float4(rstd * (dg[j].x - s1 - xh[j].x * s2), rstd * (dg[j].y - s1 - xh[j].y * s2),
+                                   rstd * (dg[j].z - s1 - xh[j].z * s2), rstd * (dg[j].w - s1 - xh[j].w * s2));
+            if (acc_beta != 0.f) { float4 old = o[q]; r.x += acc_beta * old.x; r.y += acc_beta * old.y; r.z += acc_beta * old.z; r.w += acc_beta * old.w; }
+            o[q] = r;
         }
     }
 }
 void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* stats,
                      long rows, int C, float acc_beta) {
-    CB_CHECK(C <= 64 * LN_MAX_PER_LANE, CB_ERR_SHAPE, "layernorm bwd: C=%d too large", C);
+    CB_CHECK(C % 4 == 0 && C <= 256 * LN_MAXQ, CB_ERR_SHAPE, "layernorm bwd: C=%d unsupported", C);
     ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_bwd", 0.0, 3.0 * rows * (double)C * 4, L.stream);
     LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, x, dy, gamma, stats, rows, C, acc_beta);
     if (prof) L.prof->end(&rec, L.stream);

@@ -402,6 +402,13 @@ void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
 static const float kTheta[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f,     // meta_net.py:131-142 trans_matrix
                                 0.03625215f, 1.07695457f, -5.32134629f / 512.f};
 
+// phase boundaries for the live profiler (cb_ctx_profile_begin/end): one HIP-event pair per phase of the step
+struct Phase {
+    const Launch& L; ProfRec rec; bool on;
+    Phase(const Launch& l, const char* name) : L(l) { on = !L.dry && L.prof && L.prof->begin(&rec, name, 0.0, 0.0, L.stream); }
+    ~Phase() { if (on) L.prof->end(&rec, L.stream); }
+};
+
 static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ctx* ctx = T->ctx;
     const TrainerCfg& c = T->cfg;
@@ -410,15 +417,18 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     const int B = bt.B, S_ = c.image_size, w = c.clip.width, es = c.es, K = c.inner_dim, T77 = c.clip.ctx_len;
     const int zc = c.vae.z_channels;
 
-    // (1) first stage: VAE encode -> posterior sample * scale_factor   (ddpm.py:702-759, 590-597) — no grad
-    Ten* img = G.wrap(const_cast<float*>(bt.image), B, S_, S_, c.vae.in_channels);
-    Ten* mom = vae_encode_moments(G, T->vae, img);
-    Ten* z0 = G.make(B, mom->h, mom->w, zc);
-    k_vae_sample(L, z0->p, mom->p, bt.post_noise, B, mom->h * mom->w, zc, c.scale_factor);
-    G.tap("z0", z0);
-
     // (2) identity branch: warp + resize + iresnet (no grad) -> MLP -> L2-norm -> basis   (meta_net.py:250-289)
+    // It is independent of the VAE encode, so it is enqueued on the library's side stream and overlaps with (1): the ~250 small
+    // FR-net launches fill the tails of the big VAE convolutions instead of serialising 3 ms behind them.
     const int NF = 2 * B;
+    const bool fork = !ctx->dry && ctx->aux != nullptr;
+    hipStream_t main_stream = G.L.stream;
+    if (fork) {
+        CB_HIP(hipEventRecord(ctx->ev_fork, main_stream));        // everything enqueued so far (incl. the previous step) ...
+        CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));    // ... happens before the side branch
+        G.L.stream = ctx->aux;
+    }
+    std::unique_ptr<Phase> ph_id(new Phase(L, "phase:frnet_head"));
     Ten* warped = G.make(NF, S_, S_, 3);
     k_affine_warp(L, warped->p, bt.faces, B, S_, 2, kTheta);
     Ten* small = G.make(NF, c.fr_in, c.fr_in, 3);
@@ -439,25 +449,48 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     G.tap("coef", xn); G.tap("zz", zz);
     // momentum dictionaries (embedding_manager.py:484-489) use the first face chunk (meta1 / cef1)
     k_ema_update(L, T->id_emb, T->id_coef, zz->p, xn->p, bt.ids, 2, B, es * w, es * K, c.max_ids, c.momentum);
+    ph_id.reset();
+    if (fork) { CB_HIP(hipEventRecord(ctx->ev_join, ctx->aux)); G.L.stream = main_stream; }
+
+    // (1) first stage: VAE encode -> posterior sample * scale_factor   (ddpm.py:702-759, 590-597) — no grad, main stream
+    Ten* z0;
+    {
+        Phase ph(L, "phase:vae_encode");
+        Ten* img = G.wrap(const_cast<float*>(bt.image), B, S_, S_, c.vae.in_channels);
+        Ten* mom = vae_encode_moments(G, T->vae, img);
+        z0 = G.make(B, mom->h, mom->w, zc);
+        k_vae_sample(L, z0->p, mom->p, bt.post_noise, B, mom->h * mom->w, zc, c.scale_factor);
+        G.tap("z0", z0);
+    }
+
+    if (fork) CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));   // join: the conditioning needs the identity embedding
 
     // (3) conditioning: token embedding -> manager hook (row surgery) -> CLIP   (modules.py:176-298, 345-404)
+    std::unique_ptr<Phase> ph_clip(new Phase(L, "phase:clip_fwd"));
     Ten* emb0 = G.make(B, T77, 1, w);
     k_gather_rows(L, emb0->p, T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
     Ten* emb1 = G.make(B, T77, 1, w, true);
     int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
     k_row_surgery_fwd(L, emb1->p, emb0->p, zz->p, bt.tokens, map, B, T77, w, es, c.placeholder_token);
     Ten* cond = clip_encode(G, T->clip, emb1);
+    ph_clip.reset();
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
+    std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));
     Ten* xt = G.make(B, z0->h, z0->w, zc);
     k_qsample(L, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
     Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond);
     float beta;
     float* deps = G.grad(eps_hat, &beta);
     k_mse_loss(L, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);
+    ph_uf.reset();
 
     // (7) backward: UNet dgrad -> context -> CLIP dgrad -> rows p, p+1 -> basis^T -> norm -> LeakyReLU -> dW, db
-    G.backward();
+    {
+        Phase ph(L, "phase:backward_unet_clip");
+        G.backward();
+    }
+    Phase ph_tail(L, "phase:head_bwd_adamw");
     CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");
     if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());
     float* dzz = ctx->arena.allocf((size_t)NF * es * w);

@@ -133,3 +133,31 @@ def test_adamw_matches_torch():
         opt.step()
         p, m, v = O.adamw_step(p, grad, m, v, step, 1e-2)
         assert torch.allclose(p, ref.detach(), atol=1e-6, rtol=1e-5)
+
+
+def test_config1_cpu_plumbing_ten_steps():
+    """BASELINE config 1 (plumbing, no GPU): 10 personalization steps of the CPU restatement on a single identity at reduced
+    width; the loss stays finite, the EMA coefficient block moves towards the (unit-norm) prediction and only the 2 x inner
+    coefficients of the trained identity change."""
+    unet = dict(in_channels=4, out_channels=4, model_channels=32, num_res_blocks=1, channel_mult=(1, 2), attention_resolutions=(1, 2),
+                num_heads=2, context_dim=64)
+    vae = dict(ch=32, ch_mult=(1, 2), num_res_blocks=1, in_channels=3, z_channels=4)
+    clip = dict(vocab=100, width=64, layers=2, heads=2, ctx_len=77, mlp=128)
+    fr = dict(layers=(1, 1, 1, 1), width=16, in_size=32, feat=512)
+    W = O.init_weights(O.trainer_param_shapes(unet, vae, clip, fr, es=2, inner=16, max_ids=3), seed=1)
+    st = O.TrainState(W)
+    coef0 = st.id_coef.clone()
+    g = torch.Generator().manual_seed(5)
+    losses = []
+    for step in range(10):
+        tokens = torch.randint(0, 90, (1, 77), generator=g); tokens[:, 5] = 99
+        batch = dict(image=torch.rand(1, 32, 32, 3, generator=g) * 2 - 1, faces=torch.rand(1, 32, 32, 6, generator=g) * 2 - 1,
+                     ids=torch.tensor([[1, 1]]), tokens=tokens, t=torch.randint(0, 1000, (1,), generator=g),
+                     noise=torch.randn(1, 4, 16, 16, generator=g), post_noise=torch.randn(1, 4, 16, 16, generator=g))
+        losses.append(float(O.train_step(W, st, batch, 5e-3, unet, vae, clip, fr, es=2, inner=16, placeholder=99)))
+    assert all(torch.isfinite(torch.tensor(losses))) and st.step == 10
+    assert torch.equal(st.id_coef[0], coef0[0]) and torch.equal(st.id_coef[2], coef0[2])      # other identities untouched
+    assert not torch.equal(st.id_coef[1], coef0[1])
+    # EMA with momentum 0.99 of a unit-norm prediction: the norm of each (e) block contracts by 0.99^10 plus the drift
+    blk = st.id_coef[1].reshape(2, 16)
+    assert (blk.norm(dim=1) < coef0[1].reshape(2, 16).norm(dim=1) + 0.2).all()
