@@ -30,6 +30,32 @@ PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_m
 STEPS_PER_IDENTITY = 800           # aigc_id.yaml:135 max_steps
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
+    separate passes and cannot be collected inside this process): profiles/*_pmc_hbm_traffic.json, written by
+    tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Returns (bytes | None, detail)."""
+    import glob
+    import re
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.json")))
+    if not files:
+        return None, None
+    m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+),(\w+)(,generic)?>", kernel)
+    if not m:
+        return None, None
+    kinds = {"ROW": 0, "COL": 1, "CONV": 2}
+    sym = f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
+    d = json.load(open(files[-1]))
+    e = d.get("per_symbol", {}).get(sym)
+    if not e or e["fetch_bytes_per_launch"] is None or e["write_bytes_per_launch"] is None:
+        return None, None
+    raw = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
+    detail = dict(source=os.path.basename(files[-1]), symbol=sym, launches=e["launches"],
+                  fetch_bytes_per_launch=round(e["fetch_bytes_per_launch"]), write_bytes_per_launch=round(e["write_bytes_per_launch"]),
+                  fetch_x2_bytes_per_launch=round(2 * e["fetch_bytes_per_launch"]),
+                  note="FETCH_SIZE as reported (lower bound); x2 = the guide's gfx950 correction for wide coalesced reads (upper bound)")
+    return round(raw), detail
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -108,15 +134,17 @@ def main():
         st = ctx.stats()
         phases = {p["kernel"][6:]: round(p["ms"], 3) for p in prof if p["kernel"].startswith("phase:")}
         prof = [p for p in prof if not p["kernel"].startswith("phase:")]
-        hbm = [p for p in prof if p.get("bytes", 0) > 0]        # HBM-bound kernel groups (GroupNorm / LayerNorm): algorithmic bytes
+        hbm = [p for p in prof if p.get("bytes", 0) > 0 and p["flops"] == 0]   # HBM-bound groups (GroupNorm / LayerNorm / split-K reduce): algorithmic bytes
         prof = [p for p in prof if p["flops"] > 0]              # MFMA-bound launches (GEMM family + fused attention)
         tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
         dom = max(prof, key=lambda p: p["ms"])
         ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+        traffic, traffic_detail = pmc_traffic(dom["kernel"])
         roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=None,
+                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_detail=traffic_detail,
                         launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 5),
                         algorithmic_gflop_per_step=round(dom["flops"] / 1e9, 1),
+                        algorithmic_bytes_per_launch=round(dom.get("bytes", 0) / dom["launches"]),
                         all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
                                               achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
                         by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))

@@ -18,6 +18,7 @@ struct cb_ctx { Ctx c; };
 struct cb_wtab { WTab t; };
 struct cb_unet { Ctx* ctx; UNet U; std::unique_ptr<Graph> G; Ten* out = nullptr; Ten* context = nullptr; int B = 0, H = 0, W = 0, L = 0; };
 struct cb_vae { Ctx* ctx; VaeEnc V; };
+struct cb_vae_dec { Ctx* ctx; VaeDec V; };
 struct cb_clip { Ctx* ctx; Clip C; std::unique_ptr<Graph> G; Ten* out = nullptr; Ten* in = nullptr; };
 struct cb_frnet { Ctx* ctx; FrNet F; };
 struct cb_trainer { Ctx* ctx; Trainer T; };
@@ -418,6 +419,85 @@ int cb_unet_backward_context(cb_unet* u, const float* deps_nchw, float* dcontext
     CB_END
 }
 
+// DDIM (ddim.py:113-204). The scalar coefficients follow the reference's fp32 tensor arithmetic: a_t.sqrt(),
+// (1 - a_prev - sigma_t**2).sqrt(), a_prev.sqrt() on torch.full(..., float32) tensors.
+namespace {
+struct DdimCoef { float sqrt_at, sqrt_aprev, dir; };
+DdimCoef ddim_coef(float a_t, float a_prev, float sigma) {
+    DdimCoef c;
+    c.sqrt_at = sqrtf(a_t);
+    c.sqrt_aprev = sqrtf(a_prev);
+    float s2 = sigma * sigma;
+    float one_m = 1.0f - a_prev;
+    c.dir = sqrtf(one_m - s2);
+    return c;
+}
+}  // namespace
+int cb_ddim_update(cb_ctx* ctx, float* x_nchw, const float* eps_nchw, const float* noise_nchw, int n, int C, int HW, int cfg_rows,
+                   float guidance_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, float* pred_x0_nchw) {
+    CB_TRY
+    require(ctx, "ctx"); require(x_nchw, "x"); require(eps_nchw, "eps");
+    CB_CHECK(sigma_t == 0.f || noise_nchw, CB_ERR_ARG, "ddim update with sigma != 0 needs a noise tensor");
+    Launch L = ctx->c.launch();
+    DdimCoef k = ddim_coef(a_t, a_prev, sigma_t);
+    // elementwise, so the NCHW buffers can be walked linearly (C=1 decode keeps the noise index identical)
+    k_ddim_update(L, x_nchw, pred_x0_nchw, eps_nchw, noise_nchw, n, 1, C * HW, cfg_rows != 0, guidance_scale, sqrt_one_minus_at,
+                  k.sqrt_at, k.sqrt_aprev, k.dir, sigma_t);
+    CB_END
+}
+int cb_unet_ddim_sample(cb_unet* u, float* x_nchw, const float* cond, const float* uncond, int n, int H, int W, int L, int S,
+                        const int64_t* timesteps, const float* alphas, const float* alphas_prev, const float* sigmas,
+                        const float* sqrt_one_minus_alphas, float guidance_scale, const float* noise_nchw, float* pred_x0_nchw) {
+    CB_TRY
+    require(u, "unet"); require(timesteps, "timesteps");
+    if (!u->ctx->dry) { require(x_nchw, "x"); require(cond, "cond"); }
+    require(alphas, "alphas"); require(alphas_prev, "alphas_prev"); require(sigmas, "sigmas"); require(sqrt_one_minus_alphas, "sqrt_one_minus_alphas");
+    CB_CHECK(n > 0 && S > 0, CB_ERR_ARG, "ddim: n and S must be positive");
+    for (int i = 0; i < S; ++i) CB_CHECK(sigmas[i] == 0.f || noise_nchw, CB_ERR_ARG, "ddim: eta != 0 needs a noise tensor [S][n,C,H,W]");
+    Ctx* c = u->ctx;
+    const bool cfg = (uncond != nullptr || c->dry) && guidance_scale != 1.0f;   // ddim.py:172 (a dry context plans the guided shape)
+    const int Cx = u->U.cfg.in_channels, D = u->U.cfg.context_dim;
+    CB_CHECK(Cx == u->U.cfg.out_channels, CB_ERR_ARG, "ddim: eps-parameterisation needs out_channels == in_channels");
+    const int Bn = cfg ? 2 * n : n;
+    const long per = (long)n * H * W * Cx;
+    // loop-carried buffers live at the bottom of the step arena; every iteration rewinds the arena to `mark`
+    Ten X, XIN, CIN, P0;
+    Ten *x = &X, *xin = &XIN, *cin = &CIN, *p0 = &P0;
+    auto shape = [](Ten* t, int n_, int h_, int w_, int c_) { t->n = n_; t->h = h_; t->w = w_; t->c = c_; };
+    shape(x, n, H, W, Cx); shape(xin, Bn, H, W, Cx); shape(p0, n, H, W, Cx); shape(cin, Bn, L, 1, D);
+    int64_t* tin = nullptr;
+    size_t mark = 0;
+    auto iteration = [&](int i) {
+        const int index = S - 1 - i;                                       // ddim.py:141
+        Graph G(c);
+        k_fill_i64(G.L, tin, Bn, timesteps[index]);
+        k_axpby(G.L, xin->p, x->p, per, 1.f, 0.f);
+        if (cfg) k_axpby(G.L, xin->p + per, x->p, per, 1.f, 0.f);
+        Ten* e = unet_forward(G, u->U, xin, tin, cin);
+        DdimCoef k = ddim_coef(alphas[index], alphas_prev[index], sigmas[index]);
+        const float* nz = (noise_nchw && sigmas[index] != 0.f) ? noise_nchw + (long)i * per : nullptr;
+        k_ddim_update(G.L, x->p, (pred_x0_nchw && i == S - 1) ? p0->p : nullptr, e->p, nz, n, Cx, H * W, cfg, guidance_scale,
+                      sqrt_one_minus_alphas[index], k.sqrt_at, k.sqrt_aprev, k.dir, sigmas[index]);
+    };
+    plan_and_run(c, [&]() {
+        Launch L0 = c->launch();
+        x->p = c->arena.allocf((size_t)x->numel()); xin->p = c->arena.allocf((size_t)xin->numel());
+        p0->p = c->arena.allocf((size_t)p0->numel()); cin->p = c->arena.allocf((size_t)cin->numel());
+        tin = static_cast<int64_t*>(c->arena.alloc(sizeof(int64_t) * (size_t)Bn));
+        k_nchw_to_nhwc(L0, x->p, x_nchw, n, Cx, H, W);
+        const long cn = (long)n * L * D;
+        if (cfg) { k_axpby(L0, cin->p, uncond, cn, 1.f, 0.f); k_axpby(L0, cin->p + cn, cond, cn, 1.f, 0.f); }   // cat([uc, c])
+        else k_axpby(L0, cin->p, cond, cn, 1.f, 0.f);
+        mark = c->arena.off;
+        iteration(0);
+    });
+    for (int i = 1; i < S; ++i) { c->arena.off = mark; iteration(i); }
+    Launch Lx = c->launch();
+    k_nhwc_to_nchw(Lx, x_nchw, x->p, n, Cx, H, W);
+    if (pred_x0_nchw) k_nhwc_to_nchw(Lx, pred_x0_nchw, p0->p, n, Cx, H, W);
+    CB_END
+}
+
 // ------------------------------------------------------------------ VAE
 int cb_vae_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_vae_cfg* cfg, cb_vae** out) {
     CB_TRY
@@ -449,6 +529,38 @@ int cb_vae_encode(cb_vae* v, const float* image, const float* post_noise, int B,
             k_vae_sample(G.L, z->p, mom->p, post_noise, B, mom->h * mom->w, zc, scale);
             k_nhwc_to_nchw(G.L, z_nchw, z->p, B, zc, mom->h, mom->w);
         }
+    });
+    CB_END
+}
+
+int cb_vae_decoder_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_vae_cfg* cfg, cb_vae_dec** out) {
+    CB_TRY
+    require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    std::unique_ptr<cb_vae_dec> v(new cb_vae_dec());
+    v->ctx = &ctx->c;
+    vae_dec_load(&ctx->c, wt->t, prefix ? prefix : "", to_cfg(cfg), &v->V);
+    *out = v.release();
+    CB_END
+}
+int cb_vae_decoder_destroy(cb_vae_dec* v) {
+    CB_TRY
+    delete v;
+    CB_END
+}
+int cb_vae_decode(cb_vae_dec* v, const float* z_nchw, int B, int h, int w, float scale_factor, int to01, float* image_nchw) {
+    CB_TRY
+    require(v, "vae decoder");
+    if (!v->ctx->dry) { require(z_nchw, "z"); require(image_nchw, "image"); }
+    CB_CHECK(scale_factor != 0.f, CB_ERR_ARG, "scale_factor must not be 0");
+    Ctx* c = v->ctx;
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        const int zc = v->V.cfg.z_channels;
+        Ten* z = G.make(B, h, w, zc);
+        k_nchw_to_nhwc(G.L, z->p, z_nchw, B, zc, h, w);
+        k_axpby(G.L, z->p, z->p, z->numel(), 1.f / scale_factor, 0.f);        // ddpm.py:772 z = 1/scale_factor * z
+        Ten* img = vae_decode(G, v->V, z);
+        k_image_out(G.L, image_nchw, img->p, B, img->c, img->h * img->w, to01);
     });
     CB_END
 }

@@ -163,6 +163,10 @@ void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nch
                const float* sqrt_ac, const float* sqrt_1mac, int B, int C, int HW);
 void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw,
                 int B, int C, int HW);
+void k_ddim_update(const Launch& L, float* x, float* pred_x0, const float* eps, const float* noise_nchw, int n, int C, int HW,
+                   int cfg, float scale, float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma);
+void k_fill_i64(const Launch& L, int64_t* p, long n, int64_t v);
+void k_image_out(const Launch& L, float* dst_nchw, const float* src_nhwc, int N, int C, int HW, int to01);
 void k_vae_sample(const Launch& L, float* z, const float* moments, const float* noise_nchw, int B, int HW, int Cz, float scale);
 void k_gather_rows(const Launch& L, float* out, const float* table, const int64_t* idx, long rows, int C, long table_rows);
 void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* pos, long rows, int period, int C);

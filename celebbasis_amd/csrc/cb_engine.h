@@ -135,5 +135,7 @@ Lin load_conv1x1_as_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, 
 Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, int out_each, bool bias,
                     bool conv1x1 = false);
 Norm load_norm(Ctx* ctx, const WTab& wt, const std::string& prefix, int c, float eps);
+// concatenate bias-free [out_i, in] projections of different widths into one [sum(out_i), in] weight
+Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs);
 
 }  // namespace cb

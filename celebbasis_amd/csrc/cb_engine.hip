@@ -134,6 +134,20 @@ Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& pr
     }
     return l;
 }
+Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs) {
+    CB_CHECK(prefixes.size() == outs.size(), CB_ERR_ARG, "load_linear_cat_var: size mismatch");
+    Lin l; l.in = in; l.out = 0;
+    for (int o : outs) l.out += o;
+    l.w = ctx->pool.allocf((size_t)l.out * in);
+    Launch L = ctx->launch();
+    size_t row = 0;
+    for (size_t i = 0; i < prefixes.size(); ++i) {
+        float* w = ctx->upload(wt, prefixes[i] + ".weight", {outs[i], in});
+        k_axpby(L, l.w + row * in, w, (long)outs[i] * in, 1.f, 0.f);
+        row += outs[i];
+    }
+    return l;
+}
 Norm load_norm(Ctx* ctx, const WTab& wt, const std::string& prefix, int c, float eps) {
     Norm n; n.c = c; n.eps = eps;
     n.g = ctx->upload(wt, prefix + ".weight", {c});

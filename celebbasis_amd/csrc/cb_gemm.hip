@@ -406,15 +406,18 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
         const bool more = (k0 + BK) < kend;
         if (more) loadAB(k0 + BK);
 
+        // MFMA step kk contracts the k-pair (kk, kk + BK/2) — any pairing of the tile's k indices is valid as long as A and B
+        // agree. With the row pitch BM+4 (== 4 mod 8) the two half-waves then sit 8*pitch == 32 banks apart, so a fragment read
+        // is conflict-free (the adjacent pairing (2kk, 2kk+1) cost one conflict cycle per dword: PMC SQ_LDS_BANK_CONFLICT).
         // all MFMA fragments of the tile are requested from LDS up front; the compiler then waits with counted lgkmcnt(N)
         // in front of each MFMA group instead of a full drain per k-step
         float av[BK / 2][TM], bv[BK / 2][TN];
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[kk][i] = As[cur][2 * kk + kl][wm * (BM / 2) + i * 32 + ml];
+            for (int i = 0; i < TM; ++i) av[kk][i] = As[cur][kk + (BK / 2) * kl][wm * (BM / 2) + i * 32 + ml];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[cur][2 * kk + kl][wn * (BN / 2) + j * 32 + ml];
+            for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[cur][kk + (BK / 2) * kl][wn * (BN / 2) + j * 32 + ml];
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the reads above: the scheduler otherwise sinks each pair next to its MFMAs
 #pragma unroll
@@ -592,9 +595,13 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     if (prof) {
         static const char* kn[3] = {"ROW", "COL", "CONV"};
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s%s>%s", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], vec ? "" : ",generic", pl.splitk > 1 ? "+splitk" : "");
+        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s%s>", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], vec ? "" : ",generic");
         rec.variant = L.prof->id_of(nm);
         rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+        // algorithmic HBM bytes: each operand once + the output once (conv A = the input image, not its im2col expansion)
+        double ea_ = a.a_kind == LD_CONV ? (double)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (double)a.M * a.K * a.batch;
+        double eb_ = (double)a.N * a.K * (a.sBb || a.sBh ? a.batch : 1);
+        rec.bytes = 4.0 * (ea_ + eb_ + (double)a.M * a.N * a.batch);
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
         CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
@@ -605,13 +612,24 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     else if (a.a_kind == LD_CONV) launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka, vec);
     else fail(CB_ERR_ARG, "gemm: unsupported operand kinds %d/%d", a.a_kind, a.b_kind);
     CB_HIP(hipGetLastError());
+    // the event pair brackets the GEMM kernel alone, so a variant's average matches the rocprofv3 per-symbol average;
+    // the split-K reduce is its own (HBM-bound) record: split partial reads + one output write (+ residual/accumulate read)
+    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
     if (pl.splitk > 1) {
         long total = (long)a.M * a.N * a.batch;
         unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+        ProfRec r2;
+        if (prof) {
+            r2.variant = L.prof->id_of("splitk_reduce_kernel");
+            r2.flops = 0;
+            r2.bytes = 4.0 * total * (pl.splitk + 1 + (a.R ? 1 : 0) + (a.beta != 0.f ? 1 : 0));
+            CB_HIP(hipEventCreate(&r2.e0)); CB_HIP(hipEventCreate(&r2.e1));
+            CB_HIP(hipEventRecord(r2.e0, L.stream));
+        }
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, L.stream, ka);
         CB_HIP(hipGetLastError());
+        if (prof) { CB_HIP(hipEventRecord(r2.e1, L.stream)); L.prof->recs.push_back(r2); }
     }
-    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
 }
 
 }  // namespace cb

@@ -768,6 +768,62 @@ void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nch
     LAUNCH(qsample_kernel, grid1d((long)B * C * HW), dim3(256), L, xt, x0, eps_nchw, t, sqrt_ac, sqrt_1mac, B, C, HW);
 }
 
+// ddim.py:166-204 p_sample_ddim, eps-parameterisation. x (NHWC [n,HW,C]) is updated in place; eps holds the UNet output:
+// [n] rows when cfg == 0, or [2n] rows (unconditional half first, ddim.py:175-179) when cfg != 0:
+//   e      = e_u + s (e_c - e_u)
+//   pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t)                       (:189)
+//   x_prev  = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise     (:193-198)
+// The scalar coefficients are evaluated on the host in fp32 exactly as the reference's torch.full(...) tensors are.
+__global__ void ddim_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const float* __restrict__ eps,
+                                   const float* __restrict__ noise_nchw, long half, int C, int HW, int cfg, float scale,
+                                   float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < half; i += (long)gridDim.x * blockDim.x) {
+        float e = eps[cfg ? half + i : i];
+        if (cfg) { float eu = eps[i]; e = eu + scale * (e - eu); }
+        float xv = x[i];
+        float p0 = __fdiv_rn(xv - sqrt_1m_at * e, sqrt_at);
+        float dir = dir_coef * e;
+        float nz = 0.f;
+        if (noise_nchw) {
+            int c = (int)(i % C);
+            long r = i / C;
+            long hw = r % HW, b = r / HW;
+            nz = sigma * noise_nchw[(b * C + c) * HW + hw];
+        }
+        x[i] = sqrt_aprev * p0 + dir + nz;
+        if (pred_x0) pred_x0[i] = p0;
+    }
+}
+void k_ddim_update(const Launch& L, float* x, float* pred_x0, const float* eps, const float* noise_nchw, int n, int C, int HW,
+                   int cfg, float scale, float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma) {
+    long half = (long)n * C * HW;
+    LAUNCH(ddim_update_kernel, grid1d(half), dim3(256), L, x, pred_x0, eps, noise_nchw, half, C, HW, cfg, scale, sqrt_1m_at,
+           sqrt_at, sqrt_aprev, dir_coef, sigma);
+}
+__global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
+    long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+void k_fill_i64(const Launch& L, int64_t* p, long n, int64_t v) {
+    LAUNCH(fill_i64_kernel, dim3(cdiv(n, 256)), dim3(256), L, p, n, v);
+}
+// stable_txt2img.py:343: clamp((x + 1) / 2, 0, 1), NHWC -> NCHW
+__global__ void image_out_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int HW, int to01) {
+    long total = (long)N * C * HW;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long hw = i % HW;
+        long r = i / HW;
+        int c = (int)(r % C);
+        long b = r / C;
+        float v = src[(b * HW + hw) * C + c];
+        if (to01) v = fminf(fmaxf((v + 1.0f) / 2.0f, 0.f), 1.f);
+        dst[i] = v;
+    }
+}
+void k_image_out(const Launch& L, float* dst_nchw, const float* src_nhwc, int N, int C, int HW, int to01) {
+    LAUNCH(image_out_kernel, grid1d((long)N * C * HW), dim3(256), L, dst_nchw, src_nhwc, N, C, HW, to01);
+}
+
 // ddpm.py:1069-1116 with l2 / eps-parameterisation / logvar==0: loss = mean((pred - eps)^2); dpred = 2 (pred-eps)/numel
 __global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss, float* __restrict__ dpred,
                                                         const float* __restrict__ pred, const float* __restrict__ target, int B,

@@ -14,7 +14,8 @@ struct UNetCfg {
     int context_dim = 768;
 };
 struct ResBlockW { Norm n1; Conv c1; Lin emb; Norm n2; Conv c2; bool has_skip = false; Lin skip; int cin = 0, cout = 0; };
-struct XfmrW { Norm norm; Lin proj_in; Norm ln1, ln2, ln3; Lin qkv1, out1, q2, kv2, out2, ff1, ff2, proj_out; int ch = 0, heads = 0; };
+struct XfmrW { Norm norm; Lin proj_in; Norm ln1, ln2, ln3; Lin qkv1, out1, q2, out2, ff1, ff2, proj_out; int ch = 0, heads = 0;
+               int kv_col = 0; /* column of this layer's K block inside UNet::kv_all (V follows at kv_col + ch) */ };
 struct UBlock { bool has_res = false; ResBlockW res; bool has_xf = false; XfmrW xf; bool has_down = false; Conv down;
                 bool has_up = false; Conv up; };
 struct UNet {
@@ -25,6 +26,7 @@ struct UNet {
     ResBlockW mid1, mid2; XfmrW midx;
     std::vector<UBlock> out_blocks;
     Norm out_norm; Conv out_conv;
+    Lin kv_all;          // every cross-attention to_k / to_v of the UNet stacked: [sum 2*ch, context_dim]
 };
 void unet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const UNetCfg& cfg, UNet* U);
 // x: [B,H,W,Cin] NHWC, t: device int64[B], context: [B,L,ctx_dim]; returns eps_hat [B,H,W,Cout]
@@ -43,6 +45,19 @@ struct VaeEnc {
 };
 void vae_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const VaeCfg& cfg, VaeEnc* V);
 Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img /*[B,H,W,3]*/);   // -> [B,H/8,W/8,2*z]
+
+// ---------------------------------------------------------------- VAE decoder (model.py:462-568, autoencoder.py:330-333) — sampling path
+struct VaeDec {
+    VaeCfg cfg;
+    Lin post_quant;
+    Conv conv_in;
+    VResW mid1, mid2; Norm attn_norm; Lin attn_qkv, attn_proj;
+    std::vector<std::vector<VResW>> up;      // indexed by level like the reference's self.up (level 0 = full resolution)
+    std::vector<Conv> upsample; std::vector<bool> has_up;
+    Norm norm_out; Conv conv_out;
+};
+void vae_dec_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const VaeCfg& cfg, VaeDec* V);
+Ten* vae_decode(Graph& G, const VaeDec& V, Ten* z /*[B,h,w,z_channels], already divided by scale_factor*/);   // -> [B,8h,8w,3]
 
 // ---------------------------------------------------------------- CLIP text transformer (modules.py:345-404 + HF 4.18 modeling_clip)
 struct ClipCfg { int vocab = 49408, width = 768, layers = 12, heads = 12, ctx_len = 77, mlp = 3072; };

@@ -18,7 +18,10 @@ static ResBlockW load_resblock(Ctx* ctx, const WTab& wt, const std::string& p, i
     if (cin != cout) { r.has_skip = true; r.skip = load_conv1x1_as_linear(ctx, wt, p + ".skip_connection", cin, cout); }
     return r;
 }
-static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, int heads, int ctx_dim) {
+// The 32 cross-attention K/V projections depend only on the conditioning: they are stacked into ONE weight at load time and
+// evaluated by one GEMM per step (and one dgrad GEMM back to the context) instead of 16 + 16 tiny M=77 launches.
+struct KvCollect { std::vector<std::string> prefixes; std::vector<int> outs; int cols = 0; };
+static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, int heads, int ctx_dim, KvCollect* kvc) {
     XfmrW x; x.ch = ch; x.heads = heads;
     x.norm = load_norm(ctx, wt, p + ".norm", ch, 1e-6f);                    // attention.py:76-77 Normalize eps 1e-6
     x.proj_in = load_conv1x1_as_linear(ctx, wt, p + ".proj_in", ch, ch);
@@ -29,7 +32,10 @@ static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, i
     x.qkv1 = load_linear_cat(ctx, wt, {tb + ".attn1.to_q", tb + ".attn1.to_k", tb + ".attn1.to_v"}, ch, ch, false);
     x.out1 = load_linear(ctx, wt, tb + ".attn1.to_out.0", ch, ch);
     x.q2 = load_linear(ctx, wt, tb + ".attn2.to_q", ch, ch, false);
-    x.kv2 = load_linear_cat(ctx, wt, {tb + ".attn2.to_k", tb + ".attn2.to_v"}, ctx_dim, ch, false);
+    x.kv_col = kvc->cols;
+    kvc->prefixes.push_back(tb + ".attn2.to_k"); kvc->outs.push_back(ch);
+    kvc->prefixes.push_back(tb + ".attn2.to_v"); kvc->outs.push_back(ch);
+    kvc->cols += 2 * ch;
     x.out2 = load_linear(ctx, wt, tb + ".attn2.to_out.0", ch, ch);
     x.ff1 = load_linear(ctx, wt, tb + ".ff.net.0.proj", ch, 8 * ch);
     x.ff2 = load_linear(ctx, wt, tb + ".ff.net.2", 4 * ch, ch);
@@ -45,6 +51,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
     U->te2 = load_linear(ctx, wt, pre + "time_embed.2", ted, ted);
     U->conv_in = load_conv(ctx, wt, pre + "input_blocks.0.0", cfg.in_channels, mc, 3, false);
     std::vector<int> chans{mc};
+    KvCollect kvc;
     int ch = mc, ds = 1, idx = 1;
     for (int level = 0; level < cfg.n_mult; ++level) {
         int mult = cfg.channel_mult[level];
@@ -53,7 +60,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
             b.has_res = true;
             b.res = load_resblock(ctx, wt, pre + S("input_blocks.", idx) + ".0", ch, mult * mc, ted);
             ch = mult * mc;
-            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, pre + S("input_blocks.", idx) + ".1", ch, cfg.num_heads, cfg.context_dim); }
+            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, pre + S("input_blocks.", idx) + ".1", ch, cfg.num_heads, cfg.context_dim, &kvc); }
             U->in_blocks.push_back(b);
             chans.push_back(ch); ++idx;
         }
@@ -66,7 +73,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
         }
     }
     U->mid1 = load_resblock(ctx, wt, pre + "middle_block.0", ch, ch, ted);
-    U->midx = load_xfmr(ctx, wt, pre + "middle_block.1", ch, cfg.num_heads, cfg.context_dim);
+    U->midx = load_xfmr(ctx, wt, pre + "middle_block.1", ch, cfg.num_heads, cfg.context_dim, &kvc);
     U->mid2 = load_resblock(ctx, wt, pre + "middle_block.2", ch, ch, ted);
     int oidx = 0;
     for (int level = cfg.n_mult - 1; level >= 0; --level) {
@@ -79,7 +86,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
             b.res = load_resblock(ctx, wt, bp + ".0", ch + ich, mc * mult, ted);
             ch = mc * mult;
             int sub = 1;
-            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, bp + ".1", ch, cfg.num_heads, cfg.context_dim); sub = 2; }
+            if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, bp + ".1", ch, cfg.num_heads, cfg.context_dim, &kvc); sub = 2; }
             if (level && i == cfg.num_res_blocks) {
                 b.has_up = true;
                 b.up = load_conv(ctx, wt, bp + "." + std::to_string(sub) + ".conv", ch, ch, 3, true);
@@ -91,6 +98,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
     }
     U->out_norm = load_norm(ctx, wt, pre + "out.0", ch, 1e-5f);
     U->out_conv = load_conv(ctx, wt, pre + "out.2", mc, cfg.out_channels, 3, true);
+    U->kv_all = load_linear_cat_var(ctx, wt, kvc.prefixes, cfg.context_dim, kvc.outs);
 }
 
 // openaimodel.py:255-275 ResBlock._forward (use_scale_shift_norm=False, no up/down, dropout 0)
@@ -103,7 +111,7 @@ static Ten* resblock(Graph& G, const ResBlockW& r, Ten* x, Ten* semb) {
     return G.conv(h, r.c2, CONV_SAME, nullptr, skip);  // skip_connection(x) + h fused as a residual epilogue
 }
 // attention.py:250-261 SpatialTransformer + 211-215 BasicTransformerBlock
-static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* context) {
+static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* kv_all) {
     const int ch = w.ch, d = ch / w.heads;
     const float scale = 1.f / sqrtf((float)d);
     Ten* h = G.groupnorm(x, w.norm, false);
@@ -114,8 +122,7 @@ static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* context) {
     h = G.linear(a, w.out1, h);
     Ten* n2 = G.layernorm(h, w.ln2);
     Ten* q = G.linear(n2, w.q2);
-    Ten* kv = G.linear(context, w.kv2);
-    a = G.attention(q, 0, kv, 0, ch, ch, w.heads, scale, false);
+    a = G.attention(q, 0, kv_all, w.kv_col, w.kv_col + ch, ch, w.heads, scale, false);
     h = G.linear(a, w.out2, h);
     Ten* n3 = G.layernorm(h, w.ln3);
     Ten* f = G.linear(n3, w.ff1);
@@ -134,19 +141,26 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     e = G.silu(e);
     Ten* emb = G.linear(e, U.te2);
     Ten* semb = G.silu(emb);
+    // all cross-attention keys/values of the step in one GEMM; the layers read column views of it. Its gradient buffer is
+    // zero-filled up front because the 16 layers each accumulate into their own disjoint column block.
+    Ten* kv_all = G.linear(context, U.kv_all);
+    if (kv_all->rg) {
+        float beta; float* g = G.grad(kv_all, &beta);
+        k_fill(G.L, g, kv_all->numel(), 0.f);
+    }
     std::vector<Ten*> hs;
     Ten* h = G.conv(x, U.conv_in, CONV_SAME);
     hs.push_back(h);
     int bi = 1;
     for (const UBlock& b : U.in_blocks) {
         if (b.has_res) h = resblock(G, b.res, h, semb);
-        if (b.has_xf) h = xfmr(G, b.xf, h, context);
+        if (b.has_xf) h = xfmr(G, b.xf, h, kv_all);
         if (b.has_down) h = G.conv(h, b.down, CONV_DOWN);
         hs.push_back(h);
         G.tap("unet.input_blocks." + std::to_string(bi++), h);
     }
     h = resblock(G, U.mid1, h, semb);
-    h = xfmr(G, U.midx, h, context);
+    h = xfmr(G, U.midx, h, kv_all);
     h = resblock(G, U.mid2, h, semb);
     G.tap("unet.middle_block", h);
     bi = 0;
@@ -154,7 +168,7 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
         Ten* skip = hs.back(); hs.pop_back();
         h = G.concat(h, skip);
         h = resblock(G, b.res, h, semb);
-        if (b.has_xf) h = xfmr(G, b.xf, h, context);
+        if (b.has_xf) h = xfmr(G, b.xf, h, kv_all);
         if (b.has_up) h = G.conv(h, b.up, CONV_UP);
         G.tap("unet.output_blocks." + std::to_string(bi++), h);
     }
@@ -229,6 +243,52 @@ Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img) {
     h = G.linear(h, V.quant);
     G.tap("vae.moments", h);
     return h;
+}
+
+// ================================================================= VAE decoder (sampling path)
+void vae_dec_load(Ctx* ctx, const WTab& wt, const std::string& pre, const VaeCfg& cfg, VaeDec* V) {
+    V->cfg = cfg;
+    const std::string d = pre + "decoder.";
+    V->post_quant = load_conv1x1_as_linear(ctx, wt, pre + "post_quant_conv", cfg.z_channels, cfg.z_channels);
+    int block_in = cfg.ch * cfg.ch_mult[cfg.n_mult - 1];
+    V->conv_in = load_conv(ctx, wt, d + "conv_in", cfg.z_channels, block_in, 3, false);
+    V->mid1 = load_vres(ctx, wt, d + "mid.block_1", block_in, block_in);
+    V->attn_norm = load_norm(ctx, wt, d + "mid.attn_1.norm", block_in, 1e-6f);
+    V->attn_qkv = load_linear_cat(ctx, wt, {d + "mid.attn_1.q", d + "mid.attn_1.k", d + "mid.attn_1.v"}, block_in, block_in, true, true);
+    V->attn_proj = load_conv1x1_as_linear(ctx, wt, d + "mid.attn_1.proj_out", block_in, block_in);
+    V->mid2 = load_vres(ctx, wt, d + "mid.block_2", block_in, block_in);
+    V->up.resize(cfg.n_mult); V->upsample.resize(cfg.n_mult); V->has_up.assign(cfg.n_mult, false);
+    for (int l = cfg.n_mult - 1; l >= 0; --l) {            // model.py:507-526: built from the coarsest level down, num_res_blocks+1 each
+        int block_out = cfg.ch * cfg.ch_mult[l];
+        for (int b = 0; b < cfg.num_res_blocks + 1; ++b) {
+            V->up[l].push_back(load_vres(ctx, wt, d + S("up.", l) + S(".block.", b), block_in, block_out));
+            block_in = block_out;
+        }
+        if (l != 0) { V->has_up[l] = true; V->upsample[l] = load_conv(ctx, wt, d + S("up.", l) + ".upsample.conv", block_in, block_in, 3, false); }
+    }
+    V->norm_out = load_norm(ctx, wt, d + "norm_out", block_in, 1e-6f);
+    V->conv_out = load_conv(ctx, wt, d + "conv_out", block_in, cfg.in_channels, 3, false);
+}
+Ten* vae_decode(Graph& G, const VaeDec& V, Ten* z) {
+    Ten* h = G.linear(z, V.post_quant);                    // autoencoder.py:331
+    h = G.conv(h, V.conv_in, CONV_SAME);
+    h = vres(G, V.mid1, h);
+    {   // AttnBlock model.py:176-202
+        const int C = h->c;
+        Ten* n = G.groupnorm(h, V.attn_norm, false);
+        Ten* qkv = G.linear(n, V.attn_qkv);
+        Ten* a = G.attention(qkv, 0, qkv, C, 2 * C, C, 1, 1.f / sqrtf((float)C), false);
+        h = G.linear(a, V.attn_proj, h);
+    }
+    h = vres(G, V.mid2, h);
+    G.tap("vaedec.mid", h);
+    for (int l = V.cfg.n_mult - 1; l >= 0; --l) {
+        for (const VResW& r : V.up[l]) h = vres(G, r, h);
+        if (V.has_up[l]) h = G.conv(h, V.upsample[l], CONV_UP);   // nearest x2 + conv3x3, model.py:42-57
+        G.tap("vaedec.up." + std::to_string(l), h);
+    }
+    h = G.groupnorm(h, V.norm_out, true);
+    return G.conv(h, V.conv_out, CONV_SAME);
 }
 
 // ================================================================= CLIP text transformer

@@ -1,5 +1,6 @@
-"""Host-side mirror of ldm/models/autoencoder.py `AutoencoderKL` (reference :285-424), encoder half only: the CelebBasis
-training step uses `encode` every step (ddpm.py:881-919); the decoder belongs to sampling (SURVEY §8 f, next)."""
+"""Host-side mirror of ldm/models/autoencoder.py `AutoencoderKL` (reference :285-424): `encode` is used by every training
+step (ddpm.py:881-919), `decode` by sampling (ddpm.py:761-819, stable_txt2img.py:342). The two halves are separate native
+objects (cb_vae / cb_vae_dec); a checkpoint that only carries one half still serves that half."""
 import torch
 
 from ... import lib as _lib
@@ -65,15 +66,47 @@ class AutoencoderKL(FrozenModule):
         res("encoder.mid.block_2", width, width)
         affine("encoder.norm_out", width); conv("encoder.conv_out", width, 2 * cfg["z_channels"], 3)
         conv("quant_conv", 2 * cfg["z_channels"], 2 * cfg["z_channels"], 1)
+        # decoder half (model.py:462-568) + post_quant_conv (autoencoder.py:303)
+        conv("post_quant_conv", cfg["z_channels"], cfg["z_channels"], 1)
+        width = cfg["ch"] * cfg["ch_mult"][-1]
+        conv("decoder.conv_in", cfg["z_channels"], width, 3)
+        res("decoder.mid.block_1", width, width)
+        affine("decoder.mid.attn_1.norm", width)
+        for name in ("q", "k", "v", "proj_out"):
+            conv(f"decoder.mid.attn_1.{name}", width, width, 1)
+        res("decoder.mid.block_2", width, width)
+        for level in reversed(range(len(cfg["ch_mult"]))):
+            out = cfg["ch"] * cfg["ch_mult"][level]
+            for b in range(cfg["num_res_blocks"] + 1):
+                res(f"decoder.up.{level}.block.{b}", width, out); width = out
+            if level != 0:
+                conv(f"decoder.up.{level}.upsample.conv", width, width, 3)
+        affine("decoder.norm_out", width); conv("decoder.conv_out", width, cfg["in_channels"], 3)
         return S
 
+    ENC_KEYS = ("encoder.", "quant_conv.")
+    DEC_KEYS = ("decoder.", "post_quant_conv.")
+
     def load_state_dict(self, sd, strict=True, prefix=""):
-        # decoder.* / post_quant_conv.* / loss.* keys of a full SD checkpoint are not part of the training step
-        sd = {k: v for k, v in sd.items() if k.startswith(prefix + "encoder.") or k.startswith(prefix + "quant_conv.")}
+        # loss.* (LPIPS / discriminator) keys of a full first-stage checkpoint never run
+        keep = tuple(prefix + k for k in self.ENC_KEYS + self.DEC_KEYS)
+        sd = {k: v for k, v in sd.items() if k.startswith(keep)}
+        self._dec = None
         return super().load_state_dict(sd, strict=strict, prefix=prefix)
 
     def _build(self, ctx):
-        return _lib.VAE(ctx, _lib.WeightTable(self.state_dict()), _lib.vae_cfg(**self.cfg))
+        return _lib.VAE(ctx, _lib.WeightTable(self.state_dict(only=self.ENC_KEYS)), _lib.vae_cfg(**self.cfg))
+
+    def native_decoder(self, device):
+        if getattr(self, "_dec", None) is None:
+            from ..modules.frozen import context_for
+            self._dec = _lib.VAEDecoder(context_for(device), _lib.WeightTable(self.state_dict(only=self.DEC_KEYS)),
+                                        _lib.vae_cfg(**self.cfg))
+        return self._dec
+
+    def decode(self, z, scale_factor=1.0, to01=False):
+        """autoencoder.py:330-333: post_quant_conv -> Decoder; z NCHW [B,zc,h,w] -> image NCHW [B,3,8h,8w]"""
+        return self.native_decoder(z.device).decode(z.float().contiguous(), scale_factor, to01)
 
     def encode(self, x):
         """x: NCHW (reference layout) or NHWC image batch in [-1,1]; returns the posterior"""

@@ -73,6 +73,40 @@ class LatentDiffusion:
         self._trainer = None
         return missing, []
 
+    # ---- inference surface used by DDIMSampler / stable_txt2img.py
+    @property
+    def device(self):
+        return torch.device("cuda", torch.cuda.current_device())
+
+    def ema_scope(self, context=None):
+        """ddpm.py:180-193; use_ema is False in aigc_id.yaml, so the scope is a no-op"""
+        import contextlib
+        return contextlib.nullcontext()
+
+    def get_learned_conditioning(self, c, face_img=None, image_ori=None):
+        """ddpm.py:599-611: cond_stage_model.encode(c, embedding_manager=..., face_img=..., image_ori=...)"""
+        return self.cond_stage_model.encode(c, embedding_manager=self.embedding_manager, face_img=face_img, image_ori=image_ori)
+
+    def apply_model(self, x_noisy, t, cond, return_ids=False):
+        """ddpm.py:948-1049 with conditioning_key 'crossattn': UNet(x, t, context=cond)"""
+        if isinstance(cond, dict):
+            cond = cond["c_crossattn"][0] if isinstance(cond["c_crossattn"], (list, tuple)) else cond["c_crossattn"]
+        if isinstance(cond, (list, tuple)):
+            cond = cond[0]
+        unet = self.model.diffusion_model.native(x_noisy.device)
+        return unet.forward(x_noisy.float().contiguous(), t.to(torch.int64).contiguous(), cond.float().contiguous())
+
+    def decode_first_stage(self, z, predict_cids=False, force_not_quantize=False):
+        """ddpm.py:761-819: z = 1/scale_factor * z; first_stage_model.decode(z)"""
+        return self.first_stage_model.decode(z, scale_factor=self.scale_factor)
+
+    def q_sample(self, x_start, t, noise=None):
+        """ddpm.py:289-292 (host-side convenience for masks in DDIMSampler; elementwise on the caller's device)"""
+        noise = torch.randn_like(x_start) if noise is None else noise
+        a = self.sqrt_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)
+        b = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)
+        return a * x_start + b * noise
+
     def train(self, mode=True):
         self.training = mode
         if self.embedding_manager is not None:

@@ -31,11 +31,13 @@ class FrozenModule:
         self.training = False
 
     # -- torch.nn.Module-like surface used by the reference's callers
-    def state_dict(self, prefix=""):
-        missing = [k for k in self._shapes if k not in self._params]
+    def state_dict(self, prefix="", only=None):
+        """`only`: tuple of key prefixes restricting the dict to one half of the module (e.g. the VAE encoder)"""
+        keys = [k for k in self._shapes if only is None or k.startswith(tuple(only))]
+        missing = [k for k in keys if k not in self._params]
         if missing:
             raise RuntimeError(f"{type(self).__name__}: {len(missing)} parameters were never loaded (e.g. {missing[0]})")
-        return {prefix + k: v for k, v in self._params.items()}
+        return {prefix + k: self._params[k] for k in keys}
 
     def load_state_dict(self, sd, strict=True, prefix=""):
         unexpected, loaded = [], 0

@@ -81,6 +81,7 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
+    "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
@@ -118,6 +119,10 @@ _ARGTYPES = {
     "cb_trainer_cfg_default": [_P], "cb_trainer_create": [_P, _P, _P, _P], "cb_trainer_destroy": [_P],
     "cb_trainer_step": [_P, _P, _F], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
     "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
+    "cb_unet_ddim_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P],
+    "cb_ddim_update": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
+    "cb_vae_decoder_create": [_P, _P, C.c_char_p, _P, _P], "cb_vae_decoder_destroy": [_P],
+    "cb_vae_decode": [_P, _P, _I, _I, _I, _F, _I, _P],
 }
 
 
@@ -334,6 +339,28 @@ class UNet(_Handle):
         check(load().cb_unet_backward_context(self.h, None if dry else ptr(deps), None if dry else ptr(dc)))
         return dc
 
+    def ddim_sample(self, x_T, cond, uncond, timesteps, alphas, alphas_prev, sigmas, sqrt_one_minus_alphas, scale=1.0,
+                    noise=None, want_pred_x0=False):
+        """the whole DDIM loop (ddim.py:113-204) on the device. x_T [n,C,H,W]; cond/uncond [n,L,D]; the five tables are the
+        S-entry buffers of DDIMSampler.make_schedule (host, any array-like). Returns (x_0 sample, last pred_x0 | None)."""
+        import numpy as np
+        n, _, H, W = x_T.shape
+        L = cond.shape[1]
+        S = len(timesteps)
+        ts = np.ascontiguousarray(np.asarray(timesteps, dtype=np.int64))
+        tabs = [np.ascontiguousarray(np.asarray(torch.as_tensor(v).cpu() if isinstance(v, torch.Tensor) else v, dtype=np.float32))
+                for v in (alphas, alphas_prev, sigmas, sqrt_one_minus_alphas)]
+        assert all(t.shape == (S,) for t in tabs), "DDIM tables must have one entry per DDIM step"
+        x = x_T.detach().to(torch.float32).contiguous().clone()
+        p0 = torch.empty_like(x) if want_pred_x0 else None
+        dry = self.ctx.dry
+        hp = lambda a: C.c_void_p(a.ctypes.data)
+        check(load().cb_unet_ddim_sample(self.h, None if dry else ptr(x), None if dry else ptr(cond),
+                                         None if (dry or uncond is None) else ptr(uncond), n, H, W, L, S, hp(ts), hp(tabs[0]),
+                                         hp(tabs[1]), hp(tabs[2]), hp(tabs[3]), C.c_float(scale),
+                                         None if (dry or noise is None) else ptr(noise), None if (dry or p0 is None) else ptr(p0)))
+        return x, p0
+
 
 class VAE(_Handle):
     _destroy = "cb_vae_destroy"
@@ -354,6 +381,36 @@ class VAE(_Handle):
         check(load().cb_vae_encode(self.h, None if dry else ptr(image_hwc), None if dry else ptr(post_noise), B, H, W,
                                    C.c_float(scale), None if dry else ptr(mom), None if dry else ptr(z)))
         return mom, z
+
+
+class VAEDecoder(_Handle):
+    _destroy = "cb_vae_decoder_destroy"
+
+    def __init__(self, ctx, wtab, cfg, prefix=""):
+        self.ctx, self.cfg = ctx, cfg
+        self.h = C.c_void_p()
+        check(load().cb_vae_decoder_create(ctx.h, wtab.h, prefix.encode(), C.byref(cfg), C.byref(self.h)))
+
+    def decode(self, z, scale_factor=1.0, to01=False):
+        """z [B,zc,h,w] NCHW -> image [B,3,8h,8w] NCHW: decode_first_stage (ddpm.py:761-819) = decode(z / scale_factor)"""
+        B, _, h, w = z.shape
+        f = 2 ** (self.cfg.n_mult - 1)
+        out = torch.empty((B, self.cfg.in_channels, h * f, w * f), dtype=torch.float32, device=z.device)
+        dry = self.ctx.dry
+        check(load().cb_vae_decode(self.h, None if dry else ptr(z), B, h, w, C.c_float(scale_factor), C.c_int(1 if to01 else 0),
+                                   None if dry else ptr(out)))
+        return out
+
+
+def ddim_update(ctx, x, eps, a_t, a_prev, sigma_t, sqrt_one_minus_at, scale=1.0, noise=None, want_pred_x0=True):
+    """one p_sample_ddim update (ddim.py:181-199) in place on x [n,C,H,W]; eps is [n,...] or, with guidance, [2n,...] (uncond first)"""
+    n, Cc, H, W = x.shape
+    cfg_rows = 1 if eps.shape[0] == 2 * n else 0
+    p0 = torch.empty_like(x) if want_pred_x0 else None
+    check(load().cb_ddim_update(ctx.h, ptr(x), ptr(eps), None if noise is None else ptr(noise), n, Cc, H * W, cfg_rows,
+                                C.c_float(scale), C.c_float(a_t), C.c_float(a_prev), C.c_float(sigma_t), C.c_float(sqrt_one_minus_at),
+                                None if p0 is None else ptr(p0)))
+    return x, p0
 
 
 class Clip(_Handle):

@@ -22,7 +22,8 @@ def trainer_shapes(unet=UNET_SD14, vae=VAE_SD14, clip=CLIP_L14, fr_layers=(3, 13
                    max_ids=10):
     S = {}
     S.update({"model.diffusion_model." + k: v for k, v in UNetModel.param_shapes(unet).items()})
-    S.update({"first_stage_model." + k: v for k, v in AutoencoderKL.param_shapes(vae).items()})
+    S.update({"first_stage_model." + k: v for k, v in AutoencoderKL.param_shapes(vae).items()
+              if k.startswith(AutoencoderKL.ENC_KEYS)})          # the training step never touches the decoder half
     S.update({"cond_stage_model.transformer.text_model." + k: v for k, v in FrozenCLIPEmbedder.param_shapes(clip).items()})
     S.update({"embedding_manager.meta_id_net.id_model." + k: v for k, v in IResNet.param_shapes(fr_layers, 512, fr_width, fr_in).items()})
     S["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"] = (es * inner, 512)
@@ -31,6 +32,11 @@ def trainer_shapes(unet=UNET_SD14, vae=VAE_SD14, clip=CLIP_L14, fr_layers=(3, 13
     S["id_embeddings"] = (max_ids, es * clip["width"])
     S["id_coefficients"] = (max_ids, es * inner)
     return S
+
+
+def decoder_shapes(vae=VAE_SD14):
+    """first_stage_model.decoder.* + post_quant_conv.* (sampling path only)"""
+    return {"first_stage_model." + k: v for k, v in AutoencoderKL.param_shapes(vae).items() if k.startswith(AutoencoderKL.DEC_KEYS)}
 
 
 def synthetic_state(shapes, seed=0, device="cpu"):

@@ -35,6 +35,7 @@ typedef struct cb_ctx cb_ctx;
 typedef struct cb_wtab cb_wtab;
 typedef struct cb_unet cb_unet;
 typedef struct cb_vae cb_vae;
+typedef struct cb_vae_dec cb_vae_dec;
 typedef struct cb_clip cb_clip;
 typedef struct cb_frnet cb_frnet;
 typedef struct cb_trainer cb_trainer;
@@ -152,6 +153,19 @@ int cb_unet_forward(cb_unet* u, const float* x_nchw, const int64_t* t, const flo
                     float* eps_nchw, int need_grad);
 /* d(sum(eps * deps)) / d context : the input-gradient-only backward the reference gets from autograd */
 int cb_unet_backward_context(cb_unet* u, const float* deps_nchw, float* dcontext);
+/* DDIMSampler.ddim_sampling + p_sample_ddim (ddim.py:113-204), eps-parameterisation, whole loop on the device.
+ * x_nchw [n,C,H,W]: x_T on entry, the sample on return. cond [n,L,ctx]; uncond [n,L,ctx] or NULL (no guidance, ddim.py:172-173).
+ * The S-entry HOST tables are the buffers DDIMSampler.make_schedule registers (ddim.py:25-54): timesteps = ddim_timesteps
+ * (ascending; the loop runs them flipped, ddim.py:133), alphas = ddim_alphas, alphas_prev = ddim_alphas_prev,
+ * sigmas = ddim_sigmas, sqrt_one_minus_alphas = ddim_sqrt_one_minus_alphas. noise_nchw: [S][n,C,H,W] device noise used when
+ * sigmas != 0 (iteration order; NULL requires eta == 0). pred_x0_nchw (optional): the last step's pred_x0.
+ * Classifier-free guidance runs as one batch-2n UNet pass per step (torch.cat([x]*2), ddim.py:175-179). */
+int cb_unet_ddim_sample(cb_unet* u, float* x_nchw, const float* cond, const float* uncond, int n, int H, int W, int L, int S,
+                        const int64_t* timesteps, const float* alphas, const float* alphas_prev, const float* sigmas,
+                        const float* sqrt_one_minus_alphas, float guidance_scale, const float* noise_nchw, float* pred_x0_nchw);
+/* one p_sample_ddim update given the (guided or 2n-row unguided) UNet output, in place on x_nchw (ddim.py:181-199) */
+int cb_ddim_update(cb_ctx* ctx, float* x_nchw, const float* eps_nchw, const float* noise_nchw, int n, int C, int HW, int cfg_rows,
+                   float guidance_scale, float a_t, float a_prev, float sigma_t, float sqrt_one_minus_at, float* pred_x0_nchw);
 
 typedef struct { int ch; int ch_mult[8]; int n_mult; int num_res_blocks; int in_channels; int z_channels; } cb_vae_cfg;
 /* AutoencoderKL.encode (autoencoder.py:324-328) + DiagonalGaussianDistribution.sample * scale (ddpm.py:590-597).
@@ -178,6 +192,13 @@ int cb_frnet_forward(cb_frnet* f, const float* img_nhwc, int N, float* features)
 
 /* ---- the whole personalization training step (LatentDiffusion.training_step, ddpm.py:357-370 -> shared_step ->
  *      get_input -> forward -> p_losses, loss.backward(), AdamW.step(); SURVEY §3.1 hot loop) ------------- */
+/* AutoencoderKL.decode (autoencoder.py:330-333: post_quant_conv -> Decoder.forward model.py:535-568) behind
+ * LatentDiffusion.decode_first_stage (ddpm.py:761-819: z / scale_factor first). z_nchw [B,z,h,w] -> image_nchw [B,3,8h,8w].
+ * to01 != 0 additionally applies clamp((x+1)/2, 0, 1) (stable_txt2img.py:343). */
+int cb_vae_decoder_create(cb_ctx* ctx, const cb_wtab* wt, const char* prefix, const cb_vae_cfg* cfg, cb_vae_dec** out);
+int cb_vae_decoder_destroy(cb_vae_dec* v);
+int cb_vae_decode(cb_vae_dec* v, const float* z_nchw, int B, int h, int w, float scale_factor, int to01, float* image_nchw);
+
 typedef struct {
     cb_unet_cfg unet; cb_vae_cfg vae; cb_clip_cfg clip;
     int fr_layers[4]; int fr_width; int fr_in;

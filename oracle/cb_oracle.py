@@ -130,6 +130,41 @@ def vae_encoder_param_shapes(cfg, prefix=""):
     return S
 
 
+def vae_decoder_param_shapes(cfg, prefix=""):
+    """AutoencoderKL decoder half (model.py:462-533, autoencoder.py:303)"""
+    S = {}
+
+    def conv(p, i, o, k):
+        S[p + ".weight"] = (o, i, k, k); S[p + ".bias"] = (o,)
+
+    def norm(p, c):
+        S[p + ".weight"] = (c,); S[p + ".bias"] = (c,)
+
+    def res(p, ci, co):
+        norm(p + ".norm1", ci); conv(p + ".conv1", ci, co, 3); norm(p + ".norm2", co); conv(p + ".conv2", co, co, 3)
+        if ci != co:
+            conv(p + ".nin_shortcut", ci, co, 1)
+
+    d = prefix + "decoder."
+    n = len(cfg["ch_mult"])
+    bi = cfg["ch"] * cfg["ch_mult"][-1]
+    conv(prefix + "post_quant_conv", cfg["z_channels"], cfg["z_channels"], 1)
+    conv(d + "conv_in", cfg["z_channels"], bi, 3)
+    res(d + "mid.block_1", bi, bi)
+    norm(d + "mid.attn_1.norm", bi)
+    for q in ("q", "k", "v", "proj_out"):
+        conv(f"{d}mid.attn_1.{q}", bi, bi, 1)
+    res(d + "mid.block_2", bi, bi)
+    for l in reversed(range(n)):
+        bo = cfg["ch"] * cfg["ch_mult"][l]
+        for b in range(cfg["num_res_blocks"] + 1):
+            res(f"{d}up.{l}.block.{b}", bi, bo); bi = bo
+        if l != 0:
+            conv(f"{d}up.{l}.upsample.conv", bi, bi, 3)
+    norm(d + "norm_out", bi); conv(d + "conv_out", bi, cfg["in_channels"], 3)
+    return S
+
+
 def clip_param_shapes(cfg, prefix=""):
     """HF CLIPTextModel.text_model state-dict (transformers 4.18 modeling_clip)"""
     w = cfg["width"]; S = {}
@@ -383,6 +418,83 @@ def vae_sample(moments, noise, scale=0.18215):
     mean, logvar = torch.chunk(moments, 2, dim=1)
     logvar = torch.clamp(logvar, -30.0, 20.0)
     return scale * (mean + torch.exp(0.5 * logvar) * noise)
+
+
+def _vattn(W, a, h):
+    """AttnBlock.forward model.py:176-202 (single head, scale C^-0.5)"""
+    hn = _gn(W, a + ".norm", h, 1e-6)
+    q = _conv(W, a + ".q", hn, padding=0); k = _conv(W, a + ".k", hn, padding=0); v = _conv(W, a + ".v", hn, padding=0)
+    b, c, hh, ww = q.shape
+    w_ = F.softmax(torch.bmm(q.reshape(b, c, hh * ww).permute(0, 2, 1), k.reshape(b, c, hh * ww)) * (int(c) ** (-0.5)), dim=2)
+    h_ = torch.bmm(v.reshape(b, c, hh * ww), w_.permute(0, 2, 1)).reshape(b, c, hh, ww)
+    return h + _conv(W, a + ".proj_out", h_, padding=0)
+
+
+def vae_decode(W, cfg, z, prefix=""):
+    """AutoencoderKL.decode autoencoder.py:330-333 (post_quant_conv) + Decoder.forward model.py:535-568. z NCHW, unscaled."""
+    d = prefix + "decoder."
+    h = _conv(W, prefix + "post_quant_conv", z, padding=0)
+    h = _conv(W, d + "conv_in", h)
+    h = _vres(W, d + "mid.block_1", h)
+    h = _vattn(W, d + "mid.attn_1", h)
+    h = _vres(W, d + "mid.block_2", h)
+    for l in reversed(range(len(cfg["ch_mult"]))):
+        for b in range(cfg["num_res_blocks"] + 1):
+            h = _vres(W, f"{d}up.{l}.block.{b}", h)
+        if l != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")                            # Upsample model.py:52-56
+            h = _conv(W, f"{d}up.{l}.upsample.conv", h)
+    return _conv(W, d + "conv_out", F.silu(_gn(W, d + "norm_out", h, 1e-6)))
+
+
+def decode_first_stage(W, cfg, z, scale_factor=0.18215, prefix=""):
+    """ddpm.py:761-819: z = 1/scale_factor * z -> decode"""
+    return vae_decode(W, cfg, 1.0 / scale_factor * z, prefix)
+
+
+def ddim_schedule(alphas_cumprod, S, eta=0.0, T=1000, method="uniform"):
+    """make_ddim_timesteps util.py:46-60 + make_ddim_sampling_parameters util.py:63-74 + ddim.py:51 — fp32 tables as the
+    reference's p_sample_ddim sees them through torch.full (ddim.py:186-189)"""
+    if method == "uniform":
+        steps = np.asarray(list(range(0, T, T // S))) + 1
+    else:
+        steps = ((np.linspace(0, np.sqrt(T * .8), S)) ** 2).astype(int) + 1
+    ac = alphas_cumprod.float()
+    a = ac[steps]
+    a_prev = np.asarray([float(ac[0])] + ac[steps[:-1]].tolist())
+    # `ndarray / fp32-tensor` dispatches to Tensor.__rtruediv__ = reciprocal() * other: the reciprocal is rounded to fp32 first
+    recip32 = (np.float32(1.0) / (1 - a.numpy())).astype(np.float32)
+    sig = eta * np.sqrt((1 - a_prev) * recip32 * (1 - a.numpy() / a_prev))
+    return dict(timesteps=steps, alphas=a.clone(), alphas_prev=torch.tensor(a_prev, dtype=torch.float32),
+                sigmas=torch.tensor(sig, dtype=torch.float32), sqrt_one_minus_alphas=torch.sqrt(1. - a))
+
+
+def ddim_step(x, e_t, a_t, a_prev, sigma_t, sqrt_one_minus_at, noise=None):
+    """ddim.py:186-199 on fp32 0-dim tensors"""
+    pred_x0 = (x - sqrt_one_minus_at * e_t) / a_t.sqrt()
+    dir_xt = (1. - a_prev - sigma_t ** 2).sqrt() * e_t
+    x_prev = a_prev.sqrt() * pred_x0 + dir_xt + (sigma_t * noise if noise is not None else 0.)
+    return x_prev, pred_x0
+
+
+def ddim_sample(W, cfg, x_T, cond, uncond, sched, scale=1.0, noise=None, prefix=""):
+    """DDIMSampler.ddim_sampling + p_sample_ddim (ddim.py:113-204) over unet_forward, eps-parameterisation.
+    noise: [S, *x.shape] in iteration order when sigmas != 0."""
+    x = x_T
+    S = len(sched["timesteps"])
+    pred = None
+    for i in range(S):
+        index = S - 1 - i
+        t = torch.full((x.shape[0],), int(sched["timesteps"][index]), dtype=torch.long)
+        if uncond is None or scale == 1.0:
+            e = unet_forward(W, cfg, x, t, cond, prefix)
+        else:
+            e_u, e_c = unet_forward(W, cfg, torch.cat([x] * 2), torch.cat([t] * 2), torch.cat([uncond, cond]), prefix).chunk(2)
+            e = e_u + scale * (e_c - e_u)
+        nz = noise[i] if (noise is not None and float(sched["sigmas"][index]) != 0.0) else None
+        x, pred = ddim_step(x, e, sched["alphas"][index], sched["alphas_prev"][index], sched["sigmas"][index],
+                            sched["sqrt_one_minus_alphas"][index], nz)
+    return x, pred
 
 
 # ----------------------------------------------------------------------------- CLIP text transformer

@@ -203,6 +203,101 @@ def gen_vae(manifest):
     return keys_digest(fs)
 
 
+def gen_vae_decoder(manifest):
+    """reference Decoder + post_quant_conv on a seeded latent (sampling path)"""
+    from ldm.modules.diffusionmodules.model import Decoder
+    cfg = MINI_VAE
+    dec = Decoder(ch=cfg["ch"], out_ch=3, ch_mult=cfg["ch_mult"], num_res_blocks=cfg["num_res_blocks"], attn_resolutions=[],
+                  dropout=0.0, in_channels=3, resolution=64, z_channels=cfg["z_channels"]).eval()
+    pq = nn.Conv2d(cfg["z_channels"], cfg["z_channels"], 1)                                       # autoencoder.py:303
+    shapes = O.vae_decoder_param_shapes(cfg)
+    ref_shapes = sd_shapes(dec, "decoder."); ref_shapes.update(sd_shapes(pq, "post_quant_conv."))
+    assert keys_digest(shapes) == keys_digest(ref_shapes), "mini VAE decoder key table mismatch"
+    W = O.init_weights(shapes, seed=19)
+    load_into(dec, W, "decoder."); load_into(pq, W, "post_quant_conv.")
+    g = torch.Generator().manual_seed(41)
+    f = 2 ** (len(cfg["ch_mult"]) - 1)
+    z = torch.randn(2, cfg["z_channels"], 64 // f, 64 // f, generator=g) * 0.18215 * 4.0
+    with torch.no_grad():
+        img = dec(pq(1.0 / 0.18215 * z))                                                         # ddpm.py:772 + autoencoder.py:330-333
+        img01 = torch.clamp((img + 1.0) / 2.0, min=0.0, max=1.0)                                  # stable_txt2img.py:343
+    torch.save(dict(cfg=cfg, weight_seed=19, z=z, scale_factor=0.18215, image=img, image01=img01), os.path.join(OUT, "vae_dec_mini.pt"))
+    manifest["vae_dec_mini.pt"] = ("ldm/modules/diffusionmodules/model.py Decoder.forward:535-568, autoencoder.py:330-333, ddpm.py:772, "
+                                   "scripts/stable_txt2img.py:343")
+    with torch.device("meta"):
+        full = Decoder(ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, attn_resolutions=[], dropout=0.0, in_channels=3,
+                       resolution=512, z_channels=4)
+        fq = nn.Conv2d(4, 4, 1)
+    fs = sd_shapes(full, "decoder."); fs.update(sd_shapes(fq, "post_quant_conv."))
+    return keys_digest(fs)
+
+
+def gen_ddim(manifest):
+    """reference DDIMSampler (ddim.py) driving the reference mini UNetModel: schedules, one p_sample_ddim update, and short
+    guided sampling runs at eta 0 and eta 0.5"""
+    from ldm.models.diffusion.ddim import DDIMSampler
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.modules.diffusionmodules.util import make_ddim_timesteps, make_ddim_sampling_parameters
+    cfg = MINI_UNET
+    unet = UNetModel(image_size=32, in_channels=cfg["in_channels"], model_channels=cfg["model_channels"], out_channels=cfg["out_channels"],
+                     num_res_blocks=cfg["num_res_blocks"], attention_resolutions=list(cfg["attention_resolutions"]),
+                     channel_mult=list(cfg["channel_mult"]), num_heads=cfg["num_heads"], use_spatial_transformer=True,
+                     transformer_depth=1, context_dim=cfg["context_dim"], use_checkpoint=True, legacy=False).eval()
+    W = O.init_weights(O.unet_param_shapes(cfg), seed=7)
+    load_into(unet, W)
+    sch = O.make_schedule()
+
+    class Model:                      # the surface DDIMSampler touches on LatentDiffusion (ddim.py:16,28-34,120,172-179)
+        num_timesteps = 1000
+        parameterization = "eps"
+        device = torch.device("cpu")
+        betas = sch["betas"]
+        alphas_cumprod = sch["alphas_cumprod"]
+        alphas_cumprod_prev = torch.cat([torch.ones(1), sch["alphas_cumprod"][:-1]])
+
+        def apply_model(self, x, t, c):
+            return unet(x, t, context=c)
+
+    DDIMSampler.register_buffer = lambda self, name, attr: setattr(self, name, attr)          # harness side: no .to("cuda") on a CPU box
+    out = dict(cfg=cfg, weight_seed=7)
+    # (a) schedule tables for the shipped setting (50 uniform steps) and the short ones used below
+    for S, eta in ((50, 0.0), (5, 0.0), (4, 0.5)):
+        ts = make_ddim_timesteps("uniform", S, 1000, verbose=False)
+        sig, a, ap = make_ddim_sampling_parameters(sch["alphas_cumprod"], ts, eta, verbose=False)
+        out[f"sched_{S}_{eta}"] = dict(timesteps=torch.tensor(ts), sigmas=torch.tensor(np.asarray(sig)), alphas=torch.as_tensor(a).clone(),
+                                       alphas_prev=torch.tensor(np.asarray(ap)), sqrt_one_minus_alphas=torch.as_tensor(np.sqrt(1. - a)).clone())
+    out["quad_10"] = torch.tensor(make_ddim_timesteps("quad", 10, 1000, verbose=False))
+    g = torch.Generator().manual_seed(51)
+    n = 2
+    x_T = torch.randn(n, 4, 16, 16, generator=g)
+    cond = torch.randn(n, 77, cfg["context_dim"], generator=g); uncond = torch.randn(n, 77, cfg["context_dim"], generator=g)
+    out.update(x_T=x_T, cond=cond, uncond=uncond)
+    sampler = DDIMSampler(Model())
+    with torch.no_grad():
+        # (b) a single guided update in the middle of a 5-step schedule
+        sampler.make_schedule(5, ddim_eta=0.0, verbose=False)
+        ts = torch.full((n,), int(sampler.ddim_timesteps[2]), dtype=torch.long)
+        x1, p0 = sampler.p_sample_ddim(x_T, cond, ts, index=2, unconditional_guidance_scale=7.5, unconditional_conditioning=uncond)
+        out["step_index2"] = dict(x_prev=x1, pred_x0=p0)
+        # (c) full guided runs
+        s0, inter0 = sampler.sample(S=5, batch_size=n, shape=[4, 16, 16], conditioning=cond, verbose=False, unconditional_guidance_scale=7.5,
+                                    unconditional_conditioning=uncond, eta=0.0, x_T=x_T)
+        out["run_5_eta0_cfg7.5"] = dict(samples=s0, pred_x0=inter0["pred_x0"][-1])
+        s1, _ = sampler.sample(S=5, batch_size=n, shape=[4, 16, 16], conditioning=cond, verbose=False, unconditional_guidance_scale=1.0,
+                               unconditional_conditioning=None, eta=0.0, x_T=x_T)
+        out["run_5_eta0_nocfg"] = dict(samples=s1)
+        torch.manual_seed(5)
+        s2, _ = sampler.sample(S=4, batch_size=n, shape=[4, 16, 16], conditioning=cond, verbose=False, unconditional_guidance_scale=3.0,
+                               unconditional_conditioning=uncond, eta=0.5, x_T=x_T)
+        torch.manual_seed(5)
+        noise = torch.stack([torch.randn(n, 4, 16, 16) for _ in range(4)])       # the stream noise_like drew, ddim.py:194
+        out["run_4_eta0.5_cfg3"] = dict(samples=s2, noise=noise)
+    torch.save(out, os.path.join(OUT, "ddim_mini.pt"))
+    manifest["ddim_mini.pt"] = ("ldm/models/diffusion/ddim.py DDIMSampler.make_schedule:25-54, sample:56-111, ddim_sampling:113-163, "
+                                "p_sample_ddim:166-204; util.py make_ddim_timesteps:46-60, make_ddim_sampling_parameters:63-74 — over the "
+                                "reference UNetModel (mini config)")
+
+
 def _fr_reinit(net, seed):
     """the reference initialises convs with N(0, 0.1) which overflows at depth with random BN stats; re-seed small"""
     g = torch.Generator().manual_seed(seed)
@@ -344,15 +439,33 @@ def main():
     from transformers import CLIPTokenizer, CLIPTextModel  # noqa: F401
     install_shims()
     torch.set_num_threads(8)
-    manifest = {}
-    gen_schedule(manifest)
-    gen_shift_rows(manifest)
-    digests = {}
-    digests["unet_sd14"] = gen_unet(manifest)
-    digests["vae_encoder_sd14"] = gen_vae(manifest)
-    digests["iresnet100"] = gen_frnet(manifest)
-    gen_manager(manifest)
-    digests["clip_l14_text"] = gen_clip(manifest)
+    only = None
+    for a in sys.argv[1:]:
+        if a.startswith("--only="):          # e.g. --only=vae_dec,ddim : regenerate some fixtures, keep the other entries
+            only = set(a[len("--only="):].split(","))
+    manifest, digests = {}, {}
+    if only is not None:
+        manifest = json.load(open(os.path.join(OUT, "MANIFEST.json")))
+        digests = json.load(open(os.path.join(OUT, "state_dict_digests.json")))
+    want = lambda name: only is None or name in only
+    if want("schedule"):
+        gen_schedule(manifest)
+    if want("shift_rows"):
+        gen_shift_rows(manifest)
+    if want("unet"):
+        digests["unet_sd14"] = gen_unet(manifest)
+    if want("vae"):
+        digests["vae_encoder_sd14"] = gen_vae(manifest)
+    if want("vae_dec"):
+        digests["vae_decoder_sd14"] = gen_vae_decoder(manifest)
+    if want("ddim"):
+        gen_ddim(manifest)
+    if want("frnet"):
+        digests["iresnet100"] = gen_frnet(manifest)
+    if want("manager"):
+        gen_manager(manifest)
+    if want("clip"):
+        digests["clip_l14_text"] = gen_clip(manifest)
     with open(os.path.join(OUT, "state_dict_digests.json"), "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
     manifest["state_dict_digests.json"] = "sha256 over sorted 'key:shape' lines of the reference modules' float state_dict at SD v1-4 sizes"

@@ -228,3 +228,128 @@ def test_train_step_sd14_vs_oracle(cb):
                 placeholder=O.PLACEHOLDER_SKS)
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     run_steps(lib, ctx, full, B=1, steps=1, lr=5e-3, seed=5, check_aux=True)
+
+
+# ------------------------------------------------------------------ sampling path: DDIM + VAE decoder
+def test_vae_decoder_mini_vs_reference_golden(cb, golden_dir):
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    fx = load(golden_dir, "vae_dec_mini.pt")
+    W = O.init_weights(O.vae_decoder_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
+    d = lib.VAEDecoder(ctx, lib.WeightTable(W), lib.vae_cfg(**fx["cfg"]))
+    img = d.decode(dv(fx["z"]), fx["scale_factor"])
+    img01 = d.decode(dv(fx["z"]), fx["scale_factor"], to01=True)
+    ctx.sync()
+    close("vae_dec_mini.image", img, fx["image"], 5e-5)
+    close("vae_dec_mini.image01", img01, fx["image01"], 5e-5)
+    d.close()
+
+
+def test_ddim_mini_vs_reference_golden(cb, golden_dir):
+    """the reference's DDIMSampler over its own mini UNetModel: one guided update, then whole-loop runs (cfg / no cfg / eta>0)"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    fx = load(golden_dir, "ddim_mini.pt")
+    cfg = fx["cfg"]
+    u = lib.UNet(ctx, lib.WeightTable(O.init_weights(O.unet_param_shapes(cfg), seed=fx["weight_seed"])), lib.unet_cfg(**cfg))
+    x_T, cond, uncond = dv(fx["x_T"]), dv(fx["cond"]), dv(fx["uncond"])
+    ac = O.make_schedule()["alphas_cumprod"]
+    s5 = O.ddim_schedule(ac, 5, 0.0)
+    tabs = lambda s: (s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"], s["sqrt_one_minus_alphas"])
+    # one p_sample_ddim update at index 2 with guidance 7.5: batch-2n UNet pass + cb_ddim_update
+    t = torch.full((4,), int(s5["timesteps"][2]), dtype=torch.int64)
+    eps = u.forward(torch.cat([x_T, x_T]).contiguous(), dv(t), torch.cat([uncond, cond]).contiguous())
+    x1, p0 = lib.ddim_update(ctx, x_T.clone(), eps, float(s5["alphas"][2]), float(s5["alphas_prev"][2]), float(s5["sigmas"][2]),
+                             float(s5["sqrt_one_minus_alphas"][2]), scale=7.5)
+    ctx.sync()
+    close("ddim_mini.step.x_prev", x1, fx["step_index2"]["x_prev"], 1e-4)
+    close("ddim_mini.step.pred_x0", p0, fx["step_index2"]["pred_x0"], 1e-4)
+    # whole loops on the device
+    x, p0 = u.ddim_sample(x_T, cond, uncond, *tabs(s5), scale=7.5, want_pred_x0=True)
+    ctx.sync()
+    close("ddim_mini.run_cfg.samples", x, fx["run_5_eta0_cfg7.5"]["samples"], 5e-4)
+    close("ddim_mini.run_cfg.pred_x0", p0, fx["run_5_eta0_cfg7.5"]["pred_x0"], 5e-4)
+    x, _ = u.ddim_sample(x_T, cond, None, *tabs(s5), scale=1.0)
+    ctx.sync()
+    close("ddim_mini.run_nocfg.samples", x, fx["run_5_eta0_nocfg"]["samples"], 5e-4)
+    r = fx["run_4_eta0.5_cfg3"]
+    x, _ = u.ddim_sample(x_T, cond, uncond, *tabs(O.ddim_schedule(ac, 4, 0.5)), scale=3.0, noise=dv(r["noise"]))
+    ctx.sync()
+    close("ddim_mini.run_eta.samples", x, r["samples"], 5e-4)
+    # eta != 0 without a noise tensor is an argument error, not a silent eta = 0
+    with pytest.raises(lib.CBError):
+        u.ddim_sample(x_T, cond, uncond, *tabs(O.ddim_schedule(ac, 4, 0.5)), scale=3.0, noise=None)
+    assert torch.equal(x_T.cpu(), fx["x_T"]), "x_T must not be modified by the sampler"
+    u.close()
+
+
+def test_host_sampler_mini_vs_oracle(cb):
+    """the reference-facing classes (LatentDiffusion + DDIMSampler + AutoencoderKL.decode, same call sequence as
+    scripts/stable_txt2img.py:320-343) at mini sizes against the oracle: fused loop and the hook (step-by-step) loop"""
+    import celebbasis_amd
+    from celebbasis_amd.ldm.models.diffusion.ddim import DDIMSampler
+    from celebbasis_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    ucfg = dict(in_channels=4, out_channels=4, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2), attention_resolutions=(1, 2),
+                num_heads=2, context_dim=48)
+    vcfg = dict(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, in_channels=3, z_channels=4)
+    T = lambda t, p: dict(target=t, params=p)
+    m = LatentDiffusion(
+        first_stage_config=T("celebbasis_amd.ldm.models.autoencoder.AutoencoderKL",
+                             dict(embed_dim=4, ddconfig=dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32,
+                                                             ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0))),
+        cond_stage_config=T("celebbasis_amd.ldm.modules.encoders.modules.FrozenCLIPEmbedder", dict(vocab=120, width=48, layers=1, heads=4, mlp=96)),
+        unet_config=T("celebbasis_amd.ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                      dict(image_size=16, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[1, 2], num_res_blocks=1,
+                           channel_mult=[1, 2, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1, context_dim=48)),
+        linear_start=0.00085, linear_end=0.012, timesteps=1000, scale_factor=0.18215, image_size=16, channels=4)
+    Wu = O.init_weights(O.unet_param_shapes(ucfg), seed=11)
+    Wd = O.init_weights(O.vae_decoder_param_shapes(vcfg), seed=12)
+    m.model.diffusion_model.load_state_dict(Wu)
+    m.first_stage_model.load_state_dict(Wd, strict=False)
+    g = torch.Generator().manual_seed(13)
+    n = 2
+    x_T = torch.randn(n, 4, 16, 16, generator=g); c = torch.randn(n, 77, 48, generator=g); uc = torch.randn(n, 77, 48, generator=g)
+    sampler = DDIMSampler(m)
+    samples, inter = sampler.sample(S=4, conditioning=dv(c), batch_size=n, shape=[4, 16, 16], verbose=False, unconditional_guidance_scale=5.0,
+                                    unconditional_conditioning=dv(uc), eta=0.0, x_T=dv(x_T))
+    img = torch.clamp((m.decode_first_stage(samples) + 1.0) / 2.0, min=0.0, max=1.0)
+    seen = []
+    samples2, _ = sampler.sample(S=4, conditioning=dv(c), batch_size=n, shape=[4, 16, 16], verbose=False, unconditional_guidance_scale=5.0,
+                                 unconditional_conditioning=dv(uc), eta=0.0, x_T=dv(x_T), callback=seen.append)
+    ctx.sync()
+    with torch.no_grad():
+        ref, ref_p0 = O.ddim_sample(Wu, ucfg, x_T, c, uc, O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 4, 0.0), scale=5.0)
+        ref_img = torch.clamp((O.decode_first_stage(Wd, vcfg, ref, 0.18215) + 1.0) / 2.0, 0.0, 1.0)
+    close("host_sampler.samples", samples, ref, 5e-4)
+    close("host_sampler.pred_x0", inter["pred_x0"][-1], ref_p0, 5e-4)
+    close("host_sampler.samples_stepwise", samples2, ref, 5e-4)
+    close("host_sampler.image", img, ref_img, 1e-3)
+    assert seen == [0, 1, 2, 3]
+
+
+def test_sampler_sd14_vs_oracle(cb):
+    """SD v1-4 sizes: 2 guided DDIM steps (batch-2 UNet passes at 64x64) + decode to 512x512 against the CPU oracle"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    cfg = O.UNET_SD14
+    W = O.init_weights(O.unet_param_shapes(cfg), seed=3)
+    u = lib.UNet(ctx, lib.WeightTable(W), lib.unet_cfg(**cfg))
+    g = torch.Generator().manual_seed(6)
+    x_T = torch.randn(1, 4, 64, 64, generator=g); c = torch.randn(1, 77, 768, generator=g); uc = torch.randn(1, 77, 768, generator=g)
+    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 2, 0.0)
+    x, _ = u.ddim_sample(dv(x_T), dv(c), dv(uc), s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"], s["sqrt_one_minus_alphas"], scale=10.0)
+    ctx.sync()
+    u.close()
+    Wd = O.init_weights(O.vae_decoder_param_shapes(O.VAE_SD14), seed=8)
+    d = lib.VAEDecoder(ctx, lib.WeightTable(Wd), lib.vae_cfg(**O.VAE_SD14))
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    with torch.no_grad():
+        ref, _ = O.ddim_sample(W, cfg, x_T, c, uc, s, scale=10.0)
+        ref_img = O.decode_first_stage(Wd, O.VAE_SD14, ref, 0.18215)
+    img = d.decode(dv(ref), 0.18215)            # decode the oracle's latent so the two checks are independent
+    ctx.sync()
+    close("sampler_sd14.samples", x, ref, 1e-3)
+    close("sampler_sd14.image", img, ref_img, 5e-4)
+    d.close()

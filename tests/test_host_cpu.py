@@ -70,6 +70,33 @@ def test_dry_training_step_accounting(built_lib):
     assert ctx.stats()["gemm_flops"] / 1e9 > 4 * 2800        # scales with the batch
 
 
+def test_dry_sampler_accounting(built_lib):
+    """sampling path at SD v1-4 shapes on a dry context: DDIM-50 with guidance = 50 batch-2 UNet passes (SURVEY §8 A10:
+    50 x 2 x 803 GF), and the native VAE decoder graph does exactly the FLOPs torch's FlopCounter sees in the oracle"""
+    from torch.utils.flop_counter import FlopCounterMode
+    from celebbasis_amd import lib, synthetic
+    from oracle import cb_oracle as O
+    ctx = lib.Context(device=-1)
+    shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
+    wt = lib.WeightTable(shapes)
+    gf = lambda: ctx.stats()["gemm_flops"] / 1e9
+    u = lib.UNet(ctx, wt, lib.unet_cfg(), prefix="model.diffusion_model.")
+    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 50, 0.0)
+    z = torch.zeros(1, 4, 64, 64); c = torch.zeros(1, 77, 768)
+    tabs = (s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"], s["sqrt_one_minus_alphas"])
+    ctx.reset_stats(); u.ddim_sample(z, c, c, *tabs, scale=10.0)
+    assert abs(gf() - 50 * 2 * 803.27) < 5.0, gf()
+    ctx.reset_stats(); u.ddim_sample(z, c, None, *tabs, scale=1.0)
+    assert abs(gf() - 50 * 803.27) < 5.0, gf()
+    d = lib.VAEDecoder(ctx, wt, lib.vae_cfg(), prefix="first_stage_model.")
+    ctx.reset_stats(); img = d.decode(z, 0.18215)
+    assert tuple(img.shape) == (1, 3, 512, 512)
+    W = {k: torch.empty(v, device="meta") for k, v in O.vae_decoder_param_shapes(O.VAE_SD14).items()}
+    with FlopCounterMode(display=False) as fc:
+        O.vae_decode(W, O.VAE_SD14, torch.empty(1, 4, 64, 64, device="meta"))
+    assert abs(gf() - fc.get_total_flops() / 1e9) < 0.5, (gf(), fc.get_total_flops() / 1e9)
+
+
 def test_product_tables_match_oracle_and_reference_digests(golden_dir):
     import json
     from celebbasis_amd import synthetic

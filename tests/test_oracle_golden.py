@@ -161,3 +161,69 @@ def test_config1_cpu_plumbing_ten_steps():
     # EMA with momentum 0.99 of a unit-norm prediction: the norm of each (e) block contracts by 0.99^10 plus the drift
     blk = st.id_coef[1].reshape(2, 16)
     assert (blk.norm(dim=1) < coef0[1].reshape(2, 16).norm(dim=1) + 0.2).all()
+
+
+def test_vae_decoder_vs_reference(golden_dir):
+    """sampling path: post_quant_conv + Decoder, decode_first_stage scaling, [0,1] image map"""
+    fx = _load(golden_dir, "vae_dec_mini.pt")
+    with open(os.path.join(golden_dir, "state_dict_digests.json")) as f:
+        assert keys_digest(O.vae_decoder_param_shapes(O.VAE_SD14)) == json.load(f)["vae_decoder_sd14"]
+    W = O.init_weights(O.vae_decoder_param_shapes(fx["cfg"]), seed=fx["weight_seed"])
+    with torch.no_grad():
+        img = O.decode_first_stage(W, fx["cfg"], fx["z"], fx["scale_factor"])
+    assert torch.allclose(img, fx["image"], atol=2e-5, rtol=1e-4)
+    assert torch.allclose(torch.clamp((img + 1.0) / 2.0, 0.0, 1.0), fx["image01"], atol=2e-5, rtol=0)
+
+
+def test_ddim_schedule_and_sampling_vs_reference(golden_dir):
+    """DDIM tables bit-exact; one p_sample_ddim update and short guided runs (eta 0 and eta 0.5) over the mini UNet"""
+    fx = _load(golden_dir, "ddim_mini.pt")
+    ac = O.make_schedule()["alphas_cumprod"]
+    for S, eta in ((50, 0.0), (5, 0.0), (4, 0.5)):
+        ref, got = fx[f"sched_{S}_{eta}"], O.ddim_schedule(ac, S, eta)
+        assert torch.equal(torch.as_tensor(got["timesteps"]), ref["timesteps"])
+        assert torch.equal(got["alphas"], ref["alphas"]) and torch.equal(got["sqrt_one_minus_alphas"], ref["sqrt_one_minus_alphas"])
+        assert torch.equal(got["alphas_prev"], ref["alphas_prev"].float()) and torch.equal(got["sigmas"], ref["sigmas"].float())
+    assert fx["sched_50_0.0"]["timesteps"][:3].tolist() == [1, 21, 41]           # range(0,1000,20)+1, SURVEY §8 A10
+    assert torch.equal(torch.as_tensor(O.ddim_schedule(ac, 10, 0.0, method="quad")["timesteps"]), fx["quad_10"])
+    cfg = fx["cfg"]
+    W = O.init_weights(O.unet_param_shapes(cfg), seed=fx["weight_seed"])
+    with torch.no_grad():
+        s5 = O.ddim_schedule(ac, 5, 0.0)
+        t = torch.full((2,), int(s5["timesteps"][2]), dtype=torch.long)
+        e_u, e_c = O.unet_forward(W, cfg, torch.cat([fx["x_T"]] * 2), torch.cat([t] * 2), torch.cat([fx["uncond"], fx["cond"]])).chunk(2)
+        x1, p0 = O.ddim_step(fx["x_T"], e_u + 7.5 * (e_c - e_u), s5["alphas"][2], s5["alphas_prev"][2], s5["sigmas"][2],
+                             s5["sqrt_one_minus_alphas"][2])
+        assert torch.allclose(x1, fx["step_index2"]["x_prev"], atol=3e-5, rtol=1e-4)
+        assert torch.allclose(p0, fx["step_index2"]["pred_x0"], atol=3e-5, rtol=1e-4)
+        x, pred = O.ddim_sample(W, cfg, fx["x_T"], fx["cond"], fx["uncond"], s5, scale=7.5)
+        assert torch.allclose(x, fx["run_5_eta0_cfg7.5"]["samples"], atol=2e-4, rtol=1e-3)
+        assert torch.allclose(pred, fx["run_5_eta0_cfg7.5"]["pred_x0"], atol=2e-4, rtol=1e-3)
+        x, _ = O.ddim_sample(W, cfg, fx["x_T"], fx["cond"], None, s5, scale=1.0)
+        assert torch.allclose(x, fx["run_5_eta0_nocfg"]["samples"], atol=1e-4, rtol=1e-3)
+        r = fx["run_4_eta0.5_cfg3"]
+        x, _ = O.ddim_sample(W, cfg, fx["x_T"], fx["cond"], fx["uncond"], O.ddim_schedule(ac, 4, 0.5), scale=3.0, noise=r["noise"])
+        assert torch.allclose(x, r["samples"], atol=2e-4, rtol=1e-3)
+
+
+def test_host_ddim_schedule_matches_reference(golden_dir):
+    """the host mirror's make_schedule buffers (celebbasis_amd.ldm.models.diffusion.ddim) against the reference's tables"""
+    from celebbasis_amd.ldm.models.diffusion.ddim import DDIMSampler, ddim_timesteps
+    fx = _load(golden_dir, "ddim_mini.pt")
+    sch = O.make_schedule()
+
+    class M:
+        num_timesteps = 1000
+        betas, alphas_cumprod = sch["betas"], sch["alphas_cumprod"]
+        alphas_cumprod_prev = torch.cat([torch.ones(1), sch["alphas_cumprod"][:-1]])
+
+    s = DDIMSampler(M())
+    for S, eta in ((50, 0.0), (5, 0.0), (4, 0.5)):
+        s.make_schedule(S, ddim_eta=eta, verbose=False)
+        ref = fx[f"sched_{S}_{eta}"]
+        assert torch.equal(torch.as_tensor(s.ddim_timesteps), ref["timesteps"])
+        a, ap, sg, s1m = s._tables()
+        assert torch.equal(torch.as_tensor(a), ref["alphas"]) and torch.equal(torch.as_tensor(ap), ref["alphas_prev"].float())
+        assert torch.equal(torch.as_tensor(sg), ref["sigmas"].float()) and torch.equal(torch.as_tensor(s1m), ref["sqrt_one_minus_alphas"])
+        assert torch.equal(torch.as_tensor(s.ddim_sigmas), ref["sigmas"])            # float64, as the reference keeps it
+    assert torch.equal(torch.as_tensor(ddim_timesteps("quad", 10, 1000)), fx["quad_10"])

@@ -1,0 +1,59 @@
+#!/usr/bin/env python
+"""HBM traffic of the hot path's kernels from two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE cannot share a pass on
+gfx950: /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots").
+
+    tools/pmc_traffic.py <fetch_dir> <write_dir> out.json
+
+Reads the *_counter_collection.csv of both passes, averages per kernel symbol and per (symbol, grid size) so that one
+shape can be singled out. FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB and stored here as reported (bytes);
+see the "note" field for the gfx950 correction the guide prescribes.
+"""
+import collections
+import csv
+import glob
+import json
+import re
+import sys
+
+
+def load(d, counter):
+    acc = collections.defaultdict(lambda: [0, 0.0])
+    for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            if r["Counter_Name"] != counter:
+                continue
+            n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cb::", "").replace("cb::", "")
+            if not ("gemm_kernel" in n or "flash" in n or n.startswith("gn_") or "layernorm" in n or "splitk" in n):
+                continue
+            key = (n, int(r["Grid_Size"]))
+            acc[key][0] += 1
+            acc[key][1] += float(r["Counter_Value"])
+    return acc
+
+
+def main():
+    fd, wd, out = sys.argv[1:4]
+    f = load(fd, "FETCH_SIZE")
+    w = load(wd, "WRITE_SIZE")
+    rows, sym = [], collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+    for key in sorted(set(f) | set(w)):
+        nf, sf = f.get(key, [0, 0.0])
+        nw, sw = w.get(key, [0, 0.0])
+        rows.append({"kernel": key[0], "grid": key[1], "launches": max(nf, nw),
+                     "fetch_bytes_per_launch": 1024.0 * sf / nf if nf else None,
+                     "write_bytes_per_launch": 1024.0 * sw / nw if nw else None})
+        a = sym[key[0]]
+        a[0] += nf; a[1] += 1024.0 * sf; a[2] += nw; a[3] += 1024.0 * sw
+    per_symbol = {k: {"launches": max(a[0], a[2]), "fetch_bytes_per_launch": a[1] / a[0] if a[0] else None,
+                      "write_bytes_per_launch": a[3] / a[2] if a[2] else None} for k, a in sym.items()}
+    note = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), KiB -> bytes, AS REPORTED. Guide correction for gfx950: "
+            "FETCH_SIZE counts a 128-B request of a wide coalesced streaming read as 64 B (x2 for such kernels); the implicit-GEMM "
+            "loaders here issue 64-B segments (16 channels x 4 B per pixel row), for which the guide gives no calibration, so the raw "
+            "value is a lower bound and 2x raw an upper bound. Infinity-cache hits are included in FETCH_SIZE.")
+    json.dump({"note": note, "per_symbol": per_symbol, "per_grid": rows}, open(out, "w"), indent=1)
+    for k, v in sorted(per_symbol.items(), key=lambda kv: -(kv[1]["fetch_bytes_per_launch"] or 0) * kv[1]["launches"])[:12]:
+        print(k, v)
+
+
+if __name__ == "__main__":
+    main()
