@@ -3,9 +3,10 @@
 The reference wraps HF `CLIPTextModel` and monkey-patches its embedding layer so the embedding manager runs between the
 token-embedding lookup and the position embedding (modules.py:176-298). Here the text tower runs in libcelebbasis_hip.so
 (cb_clip_*) with the same hook point; state-dict keys are the HF ones under `transformer.text_model.`.
-The celeb basis (modules.py:472-624) is shipped as data (`celeb_embeddings`, shape (es, 1+K, 768)): SVD sign/rotation
-ambiguity makes a recomputed basis incomparable; `celebbasis_amd.basis.build_celeb_basis` restates the
-construction for users who have the CLIP token table.
+The celeb basis (modules.py:472-624) is normally shipped as data (`celeb_embeddings`, shape (es, 1+K, 768), e.g. the
+`celeb_basis.pt` that scripts/extract_pt.py writes): coefficients are only meaningful against the basis they were trained
+with. `_get_celeb_embeddings` rebuilds it from the name list when the BPE vocab and the token table are available
+(`celebbasis_amd.basis`, pinned against the reference's own method in tests/golden/basis_mini.pt).
 """
 import torch
 
@@ -22,7 +23,9 @@ class FrozenCLIPEmbedder(FrozenModule):
         self.cfg = dict(vocab=vocab, width=width, layers=layers, heads=heads, ctx_len=max_length, mlp=mlp)
         self.version, self.device, self.max_length = version, device, max_length
         self.use_celeb, self.n_components, self.num_embeds_per_token = use_celeb, n_components, num_embeds_per_token
-        self.celeb_txt = celeb_txt
+        self.celeb_txt, self.use_svd, self.rm_repeats, self.use_flatten = celeb_txt, use_svd, rm_repeats, use_flatten
+        if use_sample_reduce:
+            raise NotImplementedError("use_sample_reduce (off in aigc_id.yaml:111) is outside the CelebBasis path")
         self.allow_offline_tokens = True
         self.celeb_embeddings = None          # (es, 1+n_components, width); set by load_celeb_basis / a checkpoint
         self._tokenizer = None
@@ -55,6 +58,29 @@ class FrozenCLIPEmbedder(FrozenModule):
 
     def freeze(self):
         return self
+
+    def _get_celeb_embeddings(self, n_components=None, tokenize=None):
+        """modules.py:472-624: build the (es, 1+K, width) basis from `celeb_txt` and the loaded token-embedding table.
+        `tokenize(name) -> [ids]` overrides the BPE tokenizer (which needs the vocab files on disk)."""
+        from .... import basis as _basis
+        names = _basis.read_names(self.celeb_txt, self.rm_repeats)
+        if tokenize is None:
+            self.allow_offline_tokens = False            # stand-in ids would silently produce a meaningless basis
+            try:
+                rows = [self.tokenize(n)[0].tolist() for n in names]
+            finally:
+                self.allow_offline_tokens = True
+        else:
+            rows = [[49406] + list(tokenize(n)) + [49407] for n in names]
+        table = self.state_dict()[self.PREFIX + "embeddings.token_embedding.weight"]
+        self.celeb_embeddings = _basis.build_celeb_basis(table, rows, self.n_components if n_components is None else n_components,
+                                                         self.num_embeds_per_token, self.use_svd, self.use_flatten)
+        return self.celeb_embeddings
+
+    def save_celeb_embeddings(self, pth_path):
+        """modules.py:626-630"""
+        assert isinstance(self.celeb_embeddings, torch.Tensor), "No celeb_embeddings!"
+        torch.save(self.celeb_embeddings.cpu(), pth_path)
 
     def _build(self, ctx):
         return _lib.Clip(ctx, _lib.WeightTable(self.state_dict()), _lib.clip_cfg(**self.cfg), prefix=self.PREFIX)

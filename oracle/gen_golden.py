@@ -298,6 +298,41 @@ def gen_ddim(manifest):
                                 "reference UNetModel (mini config)")
 
 
+def gen_basis(manifest):
+    """the reference's own FrozenCLIPEmbedder._get_celeb_embeddings (modules.py:472-624) run unbound on a stand-in `self`:
+    real name list (infer_images/wiki_names_v2.txt) with the real BPE ids the reference recorded (infer_images/token_len.txt),
+    a seeded token-embedding table at reduced width (no CLIP weights exist offline)."""
+    import re
+    import tempfile
+    from ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    tab = {}
+    for line in open(os.path.join(REF, "infer_images", "token_len.txt")):
+        m = re.match(r"\d+ (.*): len=(\d+), token=\[(.*)\]", line.strip())
+        if m:
+            tab[m.group(1)] = [int(x) for x in m.group(3).split(",") if x.strip()]
+    names = [n for n in open(os.path.join(REF, "infer_images", "wiki_names_v2.txt")).read().splitlines() if n in tab]   # keeps duplicates
+    width, K = 96, 64
+    table = torch.randn(49408, width, generator=torch.Generator().manual_seed(61)) * 0.02
+
+    def tokenizer(name, **kw):
+        ids = [49406] + tab[name] + [49407] * (77 - 1 - len(tab[name]))
+        return {"input_ids": torch.tensor([ids])}
+
+    out = dict(table_seed=61, width=width, n_components=K, names=names, token_table={n: tab[n] for n in set(names)})
+    with tempfile.TemporaryDirectory() as td:
+        txt = os.path.join(td, "names.txt")
+        open(txt, "w").write("\n".join(names))
+        for flatten in (False, True):
+            me = types.SimpleNamespace(celeb_txt=txt, rm_repeats=True, tokenizer=tokenizer, max_length=77, dev=False,
+                                       transformer=lambda input_ids, only_embedding: table[input_ids], use_flatten=flatten,
+                                       num_embeds_per_token=2, use_sample_reduce=False, n_samples=513, use_svd=True, device="cpu")
+            FrozenCLIPEmbedder._get_celeb_embeddings(me, n_components=K)
+            out["basis_flatten" if flatten else "basis"] = me.celeb_embeddings.clone()
+    torch.save(out, os.path.join(OUT, "basis_mini.pt"))
+    manifest["basis_mini.pt"] = ("ldm/modules/encoders/modules.py FrozenCLIPEmbedder._get_celeb_embeddings:472-619 (use_svd, rm_repeats, "
+                                 "flatten on/off) on infer_images/wiki_names_v2.txt with the BPE ids of infer_images/token_len.txt")
+
+
 def _fr_reinit(net, seed):
     """the reference initialises convs with N(0, 0.1) which overflows at depth with random BN stats; re-seed small"""
     g = torch.Generator().manual_seed(seed)
@@ -460,6 +495,8 @@ def main():
         digests["vae_decoder_sd14"] = gen_vae_decoder(manifest)
     if want("ddim"):
         gen_ddim(manifest)
+    if want("basis"):
+        gen_basis(manifest)
     if want("frnet"):
         digests["iresnet100"] = gen_frnet(manifest)
     if want("manager"):

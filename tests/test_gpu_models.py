@@ -353,3 +353,25 @@ def test_sampler_sd14_vs_oracle(cb):
     close("sampler_sd14.samples", x, ref, 1e-3)
     close("sampler_sd14.image", img, ref_img, 5e-4)
     d.close()
+
+
+def test_extract_pt_formats(cb, tmp_path):
+    """scripts/extract_pt.py:96-139 interchange files: names, shapes, dtypes and values (einsum with the basis + mean)"""
+    from celebbasis_amd.scripts.extract_pt import extract
+    g = torch.Generator().manual_seed(17)
+    es, h, K, W, max_ids = 2, 1, 512, 768, 10
+    basis = torch.randn(es, 1 + K, W, generator=g) * 0.05
+    coefs = [torch.randn(es, h, K, generator=g) for _ in range(max_ids)]
+    for fp16 in (False, True):
+        folder = tmp_path / ("ti16" if fp16 else "ti32")
+        extract(coefs, basis, str(tmp_path / "celeb_basis.pt"), str(folder), save_fp16=fp16, device=DEV)
+        assert torch.equal(torch.load(tmp_path / "celeb_basis.pt"), basis)
+        tag = "_fp16" if fp16 else ""
+        assert sorted(os.listdir(folder)) == sorted([f"id_embedding{tag}_{i:03d}.pt" for i in range(max_ids)] +
+                                                    [f"id_coefficient{tag}_{i:03d}.pt" for i in range(max_ids)])
+        for i in (0, 9):
+            z = torch.load(folder / f"id_embedding{tag}_{i:03d}.pt"); c = torch.load(folder / f"id_coefficient{tag}_{i:03d}.pt")
+            assert z.dtype == (torch.float16 if fp16 else torch.float32) and tuple(z.shape) == (es * h, W) and tuple(c.shape) == (es, h, K)
+            ref = (torch.einsum("ehk,ekc->ehc", coefs[i], basis[:, 1:]) + basis[:, 0].unsqueeze(1)).reshape(es * h, W)
+            close(f"extract_pt.z{tag}.{i}", z.float(), ref, 2e-3 if fp16 else 1e-5)
+            assert torch.equal(c.float(), coefs[i].half().float() if fp16 else coefs[i])

@@ -227,3 +227,31 @@ def test_host_ddim_schedule_matches_reference(golden_dir):
         assert torch.equal(torch.as_tensor(sg), ref["sigmas"].float()) and torch.equal(torch.as_tensor(s1m), ref["sqrt_one_minus_alphas"])
         assert torch.equal(torch.as_tensor(s.ddim_sigmas), ref["sigmas"])            # float64, as the reference keeps it
     assert torch.equal(torch.as_tensor(ddim_timesteps("quad", 10, 1000)), fx["quad_10"])
+
+
+def test_celeb_basis_builder_vs_reference(golden_dir):
+    """celebbasis_amd.basis against the reference's own _get_celeb_embeddings (run on its name list and recorded BPE ids):
+    mean row bit-exact; the singular vectors agree as a matrix when LAPACK matches, and at least per-row up to sign"""
+    from celebbasis_amd import basis as B
+    fx = _load(golden_dir, "basis_mini.pt")
+    table = torch.randn(49408, fx["width"], generator=torch.Generator().manual_seed(fx["table_seed"])) * 0.02
+    names = sorted(set(fx["names"]))                                   # rm_repeats + sort, modules.py:477-486
+    assert len(names) == 580 and names[0] == "Adam Sandler"
+    rows = [[49406] + fx["token_table"][n] + [49407] * (76 - len(fx["token_table"][n])) for n in names]
+    for key, flatten in (("basis", False), ("basis_flatten", True)):
+        ref = fx[key]
+        got = B.build_celeb_basis(table, rows, n_components=fx["n_components"], num_embeds_per_token=2, use_flatten=flatten)
+        assert got.shape == ref.shape == (2, 1 + fx["n_components"], fx["width"])
+        assert torch.allclose(got[:, 0], ref[:, 0], atol=1e-7, rtol=0)                       # the mean embedding
+        cos = (got[:, 1:] * ref[:, 1:]).sum(-1)                                              # rows are unit vectors
+        assert torch.all(cos.abs() > 1 - 1e-4), float(cos.abs().min())
+        assert torch.allclose(got, ref, atol=1e-5, rtol=0), "LAPACK sign convention differs from the fixture's"
+    # ragged rows (just the name's own tokens) give the same columns as padded rows
+    cols_a = B.name_token_columns(rows)
+    cols_b = B.name_token_columns([[49406] + fx["token_table"][n] for n in names])
+    assert cols_a == cols_b and len(cols_a[0]) == 580 and len(cols_a[1]) == 576            # 4 single-token names
+    # the documented quirk: the reference never drops repeated tokens; the intended filter would
+    assert len(B.name_token_columns(rows, dedupe_tokens=True)[0]) < 580
+    pm = B.build_celeb_basis(table, rows, n_components=8, sign="positive_max")
+    lead = pm[:, 1:].gather(2, pm[:, 1:].abs().argmax(dim=2, keepdim=True))
+    assert torch.all(lead > 0)
