@@ -95,7 +95,7 @@ struct GemmArgs {
     long sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0;
     // epilogue: C = alpha*acc + bias[n] + rowbias[m / rows_per_img][n] + R[m][n] + beta*C
     const float* bias = nullptr;
-    const float* rowbias = nullptr; int rows_per_img = 1;
+    const float* rowbias = nullptr; int rows_per_img = 1; long ld_rowbias = 0;   // ld 0 = N
     const float* R = nullptr; long ldr = 0; long sRb = 0, sRh = 0;
     float alpha = 1.f, beta = 0.f;
     ConvGeom g;

@@ -106,7 +106,7 @@ struct Graph {
     void backward();
 
     // ops (forward now, backward pushed on the tape when an input requires grad)
-    Ten* conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias = nullptr, Ten* residual = nullptr);
+    Ten* conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias = nullptr, Ten* residual = nullptr, int rowbias_col = 0);
     Ten* linear(Ten* x, const Lin& l, Ten* residual = nullptr);
     Ten* groupnorm(Ten* x, const Norm& nm, bool silu);
     Ten* layernorm(Ten* x, const Norm& nm);
@@ -136,6 +136,7 @@ Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& pr
                     bool conv1x1 = false);
 Norm load_norm(Ctx* ctx, const WTab& wt, const std::string& prefix, int c, float eps);
 // concatenate bias-free [out_i, in] projections of different widths into one [sum(out_i), in] weight
-Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs);
+Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs,
+                        bool bias = false);
 
 }  // namespace cb

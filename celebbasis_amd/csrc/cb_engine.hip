@@ -134,16 +134,19 @@ Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& pr
     }
     return l;
 }
-Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs) {
+Lin load_linear_cat_var(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, const std::vector<int>& outs,
+                        bool bias) {
     CB_CHECK(prefixes.size() == outs.size(), CB_ERR_ARG, "load_linear_cat_var: size mismatch");
     Lin l; l.in = in; l.out = 0;
     for (int o : outs) l.out += o;
     l.w = ctx->pool.allocf((size_t)l.out * in);
+    if (bias) l.b = ctx->pool.allocf((size_t)l.out);
     Launch L = ctx->launch();
     size_t row = 0;
     for (size_t i = 0; i < prefixes.size(); ++i) {
         float* w = ctx->upload(wt, prefixes[i] + ".weight", {outs[i], in});
         k_axpby(L, l.w + row * in, w, (long)outs[i] * in, 1.f, 0.f);
+        if (bias) k_axpby(L, l.b + row, ctx->upload(wt, prefixes[i] + ".bias", {outs[i]}), outs[i], 1.f, 0.f);
         row += outs[i];
     }
     return l;
@@ -247,7 +250,7 @@ void conv_dgrad(Graph* G, const float* dy, const Conv& cv, ConvMode mode, int N,
     }
 }
 
-Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* residual) {
+Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* residual, int rowbias_col) {
     CB_CHECK(x->c == cv.cin, CB_ERR_SHAPE, "conv: input has %d channels, weight expects %d", x->c, cv.cin);
     const int H = x->h, W = x->w;
     ConvGeom g; int Ho, Wo;
@@ -255,13 +258,13 @@ Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* resid
     bool rg = x->rg || (residual && residual->rg);
     Ten* y = make(x->n, Ho, Wo, cv.cout, rg);
     if (residual) CB_CHECK(residual->numel() == y->numel() && residual->c == y->c, CB_ERR_SHAPE, "conv: residual shape");
-    if (rowbias) CB_CHECK(rowbias->rows() == x->n && rowbias->c == cv.cout, CB_ERR_SHAPE, "conv: rowbias shape");
+    if (rowbias) CB_CHECK(rowbias->rows() == x->n && rowbias_col >= 0 && rowbias->c >= rowbias_col + cv.cout, CB_ERR_SHAPE, "conv: rowbias shape");
     GemmArgs a;
     a.A = x->p; a.B = cv.w; a.C = y->p;
     a.M = (int)y->rows(); a.N = cv.cout; a.K = cv.ks * cv.ks * cv.cin;
     a.a_kind = LD_CONV; a.b_kind = LD_ROW; a.ldb = a.K; a.ldc = cv.cout;
     a.bias = cv.b;
-    if (rowbias) { a.rowbias = rowbias->p; a.rows_per_img = Ho * Wo; }
+    if (rowbias) { a.rowbias = rowbias->p + rowbias_col; a.ld_rowbias = rowbias->c; a.rows_per_img = Ho * Wo; }   // column view of a wider table
     if (residual) { a.R = residual->p; a.ldr = cv.cout; }
     a.g = g;
     run_gemm(this, a);

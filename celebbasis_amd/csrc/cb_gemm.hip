@@ -299,6 +299,21 @@ __device__ __forceinline__ void store_rcontig(float (*T)[ROWS + 4], const float4
     }
 }
 
+// k-contiguous operand, VEC path: LDS layout [row][16 k] without padding, 16-byte chunk c of row r stored at chunk
+// c ^ ((r >> 2) & 3). Both the store (a 16-lane group = 4 rows x 4 chunks) and the MFMA fragment read (a 16-lane group =
+// 16 rows x 1 chunk) then touch 16 distinct 4-bank groups: conflict-free ds_write_b128 / ds_read_b128 with loop-invariant
+// per-lane addresses (no address arithmetic left in the k loop).
+template <int ROWS>
+__device__ __forceinline__ void store_kc(float* buf, const float4 (&reg)[ROWS / 64], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int r = idx >> 2;
+        int c = (idx & 3) ^ ((r >> 2) & 3);
+        *reinterpret_cast<float4*>(buf + r * 16 + c * 4) = reg[i];
+    }
+}
+
 __device__ __forceinline__ int xcd_remap(int b, int n) {
     // bijective "XCD x gets a contiguous chunk" remap (guide §5: XCD swizzle must be bijective)
     int q = n >> 3, r = n & 7;
@@ -385,12 +400,19 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
             else load_col<BN>(rb, Bp, a.ldb, n0, a.N, k0, kend, p.b_vec, tid);
         }
     };
+    constexpr bool A_KC = VEC && (AK != LD_COL);          // k-contiguous operands use the swizzled [row][16] layout
+    constexpr bool B_KC = VEC && (BKIND == LD_ROW);
+    constexpr int A_BUF = BK * (BM + 4), B_BUF = BK * (BN + 4);
+    float* const AsF = &As[0][0][0];
+    float* const BsF = &Bs[0][0][0];
     auto storeA = [&](int buf) {
-        if constexpr (AK == LD_COL) store_rcontig<BM>(As[buf], ra, tid, ma);
+        if constexpr (A_KC) store_kc<BM>(AsF + buf * A_BUF, ra, tid);
+        else if constexpr (AK == LD_COL) store_rcontig<BM>(As[buf], ra, tid, ma);
         else store_kcontig<BM>(As[buf], ra, tid, ma);
     };
     auto storeB = [&](int buf) {
-        if constexpr (BKIND == LD_COL) store_rcontig<BN>(Bs[buf], rb, tid, mb);
+        if constexpr (B_KC) store_kc<BN>(BsF + buf * B_BUF, rb, tid);
+        else if constexpr (BKIND == LD_COL) store_rcontig<BN>(Bs[buf], rb, tid, mb);
         else store_kcontig<BN>(Bs[buf], rb, tid, mb);
     };
 
@@ -402,6 +424,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
 
     int cur = 0;
     const int kl = lane >> 5, ml = lane & 31;
+    const int swz = (ml >> 2) & 3;                                         // == ((row >> 2) & 3): sub-tile bases are multiples of 32
+    const int clo = ((2 * kl) ^ swz) * 4, chi = ((2 * kl + 1) ^ swz) * 4;  // float offsets of the lane's two 16-byte chunks
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
         const bool more = (k0 + BK) < kend;
         if (more) loadAB(k0 + BK);
@@ -412,12 +436,36 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
         // all MFMA fragments of the tile are requested from LDS up front; the compiler then waits with counted lgkmcnt(N)
         // in front of each MFMA group instead of a full drain per k-step
         float av[BK / 2][TM], bv[BK / 2][TN];
+        // k-contiguous operands: lane (ml, kl) owns k = 8*kl .. 8*kl+7 of its row = chunks 2*kl ("lo", MFMA steps 0-3) and
+        // 2*kl+1 ("hi", steps 4-7), one ds_read_b128 each; the lo chunks of A and B are requested first
+        const float* arow = AsF + cur * A_BUF + (wm * (BM / 2) + ml) * 16;
+        const float* brow = BsF + cur * B_BUF + (wn * (BN / 2) + ml) * 16;
 #pragma unroll
-        for (int kk = 0; kk < BK / 2; ++kk) {
+        for (int half = 0; half < 2; ++half) {
+            if constexpr (A_KC) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) av[kk][i] = As[cur][kk + (BK / 2) * kl][wm * (BM / 2) + i * 32 + ml];
+                for (int i = 0; i < TM; ++i) {
+                    const float4 v = *reinterpret_cast<const float4*>(arow + i * 512 + (half ? chi : clo));
+                    av[4 * half + 0][i] = v.x; av[4 * half + 1][i] = v.y; av[4 * half + 2][i] = v.z; av[4 * half + 3][i] = v.w;
+                }
+            } else {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[cur][kk + (BK / 2) * kl][wn * (BN / 2) + j * 32 + ml];
+                for (int kk = 4 * half; kk < 4 * half + 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) av[kk][i] = As[cur][kk + (BK / 2) * kl][wm * (BM / 2) + i * 32 + ml];
+            }
+            if constexpr (B_KC) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const float4 v = *reinterpret_cast<const float4*>(brow + j * 512 + (half ? chi : clo));
+                    bv[4 * half + 0][j] = v.x; bv[4 * half + 1][j] = v.y; bv[4 * half + 2][j] = v.z; bv[4 * half + 3][j] = v.w;
+                }
+            } else {
+#pragma unroll
+                for (int kk = 4 * half; kk < 4 * half + 4; ++kk)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j) bv[kk][j] = Bs[cur][kk + (BK / 2) * kl][wn * (BN / 2) + j * 32 + ml];
+            }
         }
         __builtin_amdgcn_sched_barrier(0);      // keep the reads above: the scheduler otherwise sinks each pair next to its MFMAs
 #pragma unroll
@@ -463,7 +511,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
                 int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 if (row < a.M) {
                     float v = a.alpha * acc[i][j][r] + bcol;
-                    if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * a.N + col];
+                    if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
                     if (Rp) v += Rp[(long)row * a.ldr + col];
                     float* c = Cp + (long)row * a.ldc + col;
                     if (a.beta != 0.f) v += a.beta * (*c);
@@ -487,7 +535,7 @@ __global__ void splitk_reduce_kernel(const KArgs p) {
         int zb = z / a.nh, zh = z - zb * a.nh;
         float v = a.alpha * s;
         if (a.bias) v += a.bias[col];
-        if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * a.N + col];
+        if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
         if (a.R) v += a.R[zb * a.sRb + zh * a.sRh + (long)row * a.ldr + col];
         float* c = a.C + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col;
         if (a.beta != 0.f) v += a.beta * (*c);

@@ -999,22 +999,32 @@ void k_l2norm_bwd(const Launch& L, float* dx, const float* y, const float* norms
     LAUNCH(l2norm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, y, norms, dy, rows, D);
 }
 // z[r,e,c] = sum_k coef[r,e,k] * basis[e,1+k,c] + basis[e,0,c]   (einsum 'behk,ekc->behc' with h=1)
-__global__ void basis_fwd_kernel(float* __restrict__ z, const float* __restrict__ coef, const float* __restrict__ basis, int R,
-                                 int E, int Kc, int Cz) {
-    long total = (long)R * E * Cz;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % Cz);
-        long re = i / Cz;
-        int e = (int)(re % E);
-        const float* bs = basis + (long)e * (Kc + 1) * Cz;
-        const float* cf = coef + re * Kc;
-        float acc = 0.f;
-        for (int k = 0; k < Kc; ++k) acc += cf[k] * bs[(long)(1 + k) * Cz + c];
-        z[i] = acc + bs[c];
+// block = 64 columns c x 4 k-slices (one wave each, coalesced over c), partial sums combined through LDS
+__global__ __launch_bounds__(256) void basis_fwd_kernel(float* __restrict__ z, const float* __restrict__ coef,
+                                                         const float* __restrict__ basis, int R, int E, int Kc, int Cz) {
+    __shared__ float part[4][64];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + lane;
+    const long re = blockIdx.y;
+    const int e = (int)(re % E);
+    const float* bs = basis + (long)e * (Kc + 1) * Cz;
+    const float* cf = coef + re * Kc;
+    float acc = 0.f;
+    if (c < Cz) {
+        int k = w;
+        for (; k + 12 < Kc; k += 16) {
+            float b0 = bs[(long)(1 + k) * Cz + c], b1 = bs[(long)(5 + k) * Cz + c], b2 = bs[(long)(9 + k) * Cz + c],
+                  b3 = bs[(long)(13 + k) * Cz + c];
+            acc += cf[k] * b0; acc += cf[k + 4] * b1; acc += cf[k + 8] * b2; acc += cf[k + 12] * b3;
+        }
+        for (; k < Kc; k += 4) acc += cf[k] * bs[(long)(1 + k) * Cz + c];
     }
+    part[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && c < Cz) z[re * Cz + c] = ((part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane])) + bs[c];
 }
 void k_basis_fwd(const Launch& L, float* z, const float* coef, const float* basis, int R, int E, int Kc, int Cz) {
-    LAUNCH(basis_fwd_kernel, grid1d((long)R * E * Cz, 64), dim3(64), L, z, coef, basis, R, E, Kc, Cz);
+    LAUNCH(basis_fwd_kernel, dim3(cdiv(Cz, 64), R * E), dim3(256), L, z, coef, basis, R, E, Kc, Cz);
 }
 // dcoef[r,e,k] = sum_c dz[r,e,c] * basis[e,1+k,c] : one wave per (r,e,k)
 __global__ __launch_bounds__(256) void basis_bwd_kernel(float* __restrict__ dcoef, const float* __restrict__ dz,
@@ -1043,36 +1053,42 @@ __global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict_
                                                                const float* __restrict__ z, const int64_t* __restrict__ tokens,
                                                                int32_t* __restrict__ map, int T, int C, int reps,
                                                                int64_t placeholder) {
+    // grid (B, slices): every block rebuilds the (tiny) row map from an LDS copy of the sample's tokens and copies its
+    // slice of output rows; the serial part no longer waits on T dependent global loads
     __shared__ int smap[256];
-    int b = blockIdx.x;
+    __shared__ unsigned char hit[256];
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) hit[i] = tokens[(long)b * T + i] == placeholder;
+    __syncthreads();
     if (threadIdx.x == 0) {
         int cnt = 0;
-        for (int i = 0; i < T; ++i) if (tokens[(long)b * T + i] == placeholder) ++cnt;
+        for (int i = 0; i < T; ++i) cnt += hit[i];
         int keep = T - cnt * (reps - 1);  // rows of the source that survive ("drop the last")
         for (int o = 0; o < T; ++o) smap[o] = o;  // untouched rows keep their own content
         int shift = 0;
         for (int i = 0; i < keep && i < T; ++i) {
             int tgt = i + shift;
             if (tgt < T) smap[tgt] = i;
-            if (tokens[(long)b * T + i] == placeholder) {
+            if (hit[i]) {
                 for (int j = 0; j < reps; ++j) if (tgt + j < T) smap[tgt + j] = -(1 + j);
                 shift += reps - 1;
             }
         }
     }
     __syncthreads();
-    for (int o = threadIdx.x; o < T; o += blockDim.x) map[(long)b * T + o] = smap[o];
-    for (int i = threadIdx.x; i < T * C; i += blockDim.x) {
-        int o = i / C, c = i - o * C;
-        int s = smap[o];
-        float v = (s >= 0) ? in[((long)b * T + s) * C + c] : z[((long)b * reps + (-s - 1)) * C + c];
-        out[((long)b * T + o) * C + c] = v;
+    if (blockIdx.y == 0)
+        for (int o = threadIdx.x; o < T; o += blockDim.x) map[(long)b * T + o] = smap[o];
+    for (int o = blockIdx.y; o < T; o += gridDim.y) {
+        const int s = smap[o];
+        const float* src = (s >= 0) ? in + ((long)b * T + s) * C : z + ((long)b * reps + (-s - 1)) * C;
+        float* dst = out + ((long)b * T + o) * C;
+        for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = src[c];
     }
 }
 void k_row_surgery_fwd(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens, int32_t* map, int B,
                        int T, int C, int reps, int64_t placeholder) {
     CB_CHECK(T <= 256, CB_ERR_SHAPE, "row surgery: T=%d > 256", T);
-    LAUNCH(row_surgery_fwd_kernel, dim3(B), dim3(256), L, out, in, z, tokens, map, T, C, reps, placeholder);
+    LAUNCH(row_surgery_fwd_kernel, dim3(B, T < 16 ? T : 16), dim3(256), L, out, in, z, tokens, map, T, C, reps, placeholder);
 }
 // dz[b][j][c] = sum over output rows o with map == -(1+j) of dout[b][o][c]
 __global__ void row_surgery_bwd_kernel(float* __restrict__ dz, const float* __restrict__ dout, const int32_t* __restrict__ map,

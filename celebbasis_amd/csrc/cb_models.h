@@ -13,7 +13,8 @@ struct UNetCfg {
     int num_heads = 8;
     int context_dim = 768;
 };
-struct ResBlockW { Norm n1; Conv c1; Lin emb; Norm n2; Conv c2; bool has_skip = false; Lin skip; int cin = 0, cout = 0; };
+struct ResBlockW { Norm n1; Conv c1; Norm n2; Conv c2; bool has_skip = false; Lin skip; int cin = 0, cout = 0;
+                   int emb_col = 0; /* column of this block's emb_layers output inside UNet::emb_all */ };
 struct XfmrW { Norm norm; Lin proj_in; Norm ln1, ln2, ln3; Lin qkv1, out1, q2, out2, ff1, ff2, proj_out; int ch = 0, heads = 0;
                int kv_col = 0; /* column of this layer's K block inside UNet::kv_all (V follows at kv_col + ch) */ };
 struct UBlock { bool has_res = false; ResBlockW res; bool has_xf = false; XfmrW xf; bool has_down = false; Conv down;
@@ -26,6 +27,7 @@ struct UNet {
     ResBlockW mid1, mid2; XfmrW midx;
     std::vector<UBlock> out_blocks;
     Norm out_norm; Conv out_conv;
+    Lin emb_all;         // the emb_layers.1 Linear of all 22 ResBlocks stacked: [sum cout, 4*model_channels] (+ bias)
     Lin kv_all;          // every cross-attention to_k / to_v of the UNet stacked: [sum 2*ch, context_dim]
 };
 void unet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const UNetCfg& cfg, UNet* U);

@@ -8,11 +8,16 @@ namespace cb {
 static std::string S(const std::string& a, int i) { return a + std::to_string(i); }
 
 // ================================================================= UNet
-static ResBlockW load_resblock(Ctx* ctx, const WTab& wt, const std::string& p, int cin, int cout, int emb_dim) {
+// Every ResBlock's emb_layers (SiLU -> Linear on the shared time embedding) is stacked into one weight and evaluated by one
+// launch per step; the blocks read column views of the result as their per-image row bias.
+struct CatCollect { std::vector<std::string> prefixes; std::vector<int> outs; int cols = 0; };
+typedef CatCollect KvCollect;
+static ResBlockW load_resblock(Ctx* ctx, const WTab& wt, const std::string& p, int cin, int cout, CatCollect* embc) {
     ResBlockW r; r.cin = cin; r.cout = cout;
     r.n1 = load_norm(ctx, wt, p + ".in_layers.0", cin, 1e-5f);              // GroupNorm32, util.py:214-216
     r.c1 = load_conv(ctx, wt, p + ".in_layers.2", cin, cout, 3, true);
-    r.emb = load_linear(ctx, wt, p + ".emb_layers.1", emb_dim, cout);
+    r.emb_col = embc->cols;
+    embc->prefixes.push_back(p + ".emb_layers.1"); embc->outs.push_back(cout); embc->cols += cout;
     r.n2 = load_norm(ctx, wt, p + ".out_layers.0", cout, 1e-5f);
     r.c2 = load_conv(ctx, wt, p + ".out_layers.3", cout, cout, 3, true);
     if (cin != cout) { r.has_skip = true; r.skip = load_conv1x1_as_linear(ctx, wt, p + ".skip_connection", cin, cout); }
@@ -20,7 +25,6 @@ static ResBlockW load_resblock(Ctx* ctx, const WTab& wt, const std::string& p, i
 }
 // The 32 cross-attention K/V projections depend only on the conditioning: they are stacked into ONE weight at load time and
 // evaluated by one GEMM per step (and one dgrad GEMM back to the context) instead of 16 + 16 tiny M=77 launches.
-struct KvCollect { std::vector<std::string> prefixes; std::vector<int> outs; int cols = 0; };
 static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, int heads, int ctx_dim, KvCollect* kvc) {
     XfmrW x; x.ch = ch; x.heads = heads;
     x.norm = load_norm(ctx, wt, p + ".norm", ch, 1e-6f);                    // attention.py:76-77 Normalize eps 1e-6
@@ -52,13 +56,14 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
     U->conv_in = load_conv(ctx, wt, pre + "input_blocks.0.0", cfg.in_channels, mc, 3, false);
     std::vector<int> chans{mc};
     KvCollect kvc;
+    CatCollect embc;
     int ch = mc, ds = 1, idx = 1;
     for (int level = 0; level < cfg.n_mult; ++level) {
         int mult = cfg.channel_mult[level];
         for (int r = 0; r < cfg.num_res_blocks; ++r) {
             UBlock b;
             b.has_res = true;
-            b.res = load_resblock(ctx, wt, pre + S("input_blocks.", idx) + ".0", ch, mult * mc, ted);
+            b.res = load_resblock(ctx, wt, pre + S("input_blocks.", idx) + ".0", ch, mult * mc, &embc);
             ch = mult * mc;
             if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, pre + S("input_blocks.", idx) + ".1", ch, cfg.num_heads, cfg.context_dim, &kvc); }
             U->in_blocks.push_back(b);
@@ -72,9 +77,9 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
             chans.push_back(ch); ds *= 2; ++idx;
         }
     }
-    U->mid1 = load_resblock(ctx, wt, pre + "middle_block.0", ch, ch, ted);
+    U->mid1 = load_resblock(ctx, wt, pre + "middle_block.0", ch, ch, &embc);
     U->midx = load_xfmr(ctx, wt, pre + "middle_block.1", ch, cfg.num_heads, cfg.context_dim, &kvc);
-    U->mid2 = load_resblock(ctx, wt, pre + "middle_block.2", ch, ch, ted);
+    U->mid2 = load_resblock(ctx, wt, pre + "middle_block.2", ch, ch, &embc);
     int oidx = 0;
     for (int level = cfg.n_mult - 1; level >= 0; --level) {
         int mult = cfg.channel_mult[level];
@@ -83,7 +88,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
             UBlock b;
             const std::string bp = pre + S("output_blocks.", oidx);
             b.has_res = true;
-            b.res = load_resblock(ctx, wt, bp + ".0", ch + ich, mc * mult, ted);
+            b.res = load_resblock(ctx, wt, bp + ".0", ch + ich, mc * mult, &embc);
             ch = mc * mult;
             int sub = 1;
             if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, bp + ".1", ch, cfg.num_heads, cfg.context_dim, &kvc); sub = 2; }
@@ -99,13 +104,13 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
     U->out_norm = load_norm(ctx, wt, pre + "out.0", ch, 1e-5f);
     U->out_conv = load_conv(ctx, wt, pre + "out.2", mc, cfg.out_channels, 3, true);
     U->kv_all = load_linear_cat_var(ctx, wt, kvc.prefixes, cfg.context_dim, kvc.outs);
+    U->emb_all = load_linear_cat_var(ctx, wt, embc.prefixes, ted, embc.outs, true);
 }
 
 // openaimodel.py:255-275 ResBlock._forward (use_scale_shift_norm=False, no up/down, dropout 0)
-static Ten* resblock(Graph& G, const ResBlockW& r, Ten* x, Ten* semb) {
+static Ten* resblock(Graph& G, const ResBlockW& r, Ten* x, Ten* emb_all) {
     Ten* h = G.groupnorm(x, r.n1, true);
-    Ten* embo = G.linear(semb, r.emb);                 // emb_layers = SiLU -> Linear; SiLU(emb) is shared (semb)
-    h = G.conv(h, r.c1, CONV_SAME, embo);              // h + emb_out[..., None, None] fused as a per-image row bias
+    h = G.conv(h, r.c1, CONV_SAME, emb_all, nullptr, r.emb_col);   // h + emb_out[..., None, None] fused as a per-image row bias
     h = G.groupnorm(h, r.n2, true);
     Ten* skip = r.has_skip ? G.linear(x, r.skip) : x;
     return G.conv(h, r.c2, CONV_SAME, nullptr, skip);  // skip_connection(x) + h fused as a residual epilogue
@@ -140,7 +145,7 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     Ten* e = G.linear(temb, U.te0);
     e = G.silu(e);
     Ten* emb = G.linear(e, U.te2);
-    Ten* semb = G.silu(emb);
+    Ten* semb = G.linear(G.silu(emb), U.emb_all);      // emb_layers of all ResBlocks: SiLU(emb) is shared, one stacked Linear
     // all cross-attention keys/values of the step in one GEMM; the layers read column views of it. Its gradient buffer is
     // zero-filled up front because the 16 layers each accumulate into their own disjoint column block.
     Ten* kv_all = G.linear(context, U.kv_all);
