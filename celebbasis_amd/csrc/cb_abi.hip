@@ -684,6 +684,24 @@ int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg,
     *out = t.release();
     CB_END
 }
+// Views of the trainer's frozen networks for the sampling path: the returned objects alias the trainer's device weights
+// (which live in the context's pool), so personalisation and txt2img of the same run hold one copy of SD v1-4.
+int cb_trainer_share_unet(cb_trainer* t, cb_unet** out) {
+    CB_TRY
+    require(t, "trainer"); require(out, "out");
+    std::unique_ptr<cb_unet> u(new cb_unet());
+    u->ctx = t->ctx; u->U = t->T.unet;
+    *out = u.release();
+    CB_END
+}
+int cb_trainer_share_clip(cb_trainer* t, cb_clip** out) {
+    CB_TRY
+    require(t, "trainer"); require(out, "out");
+    std::unique_ptr<cb_clip> c(new cb_clip());
+    c->ctx = t->ctx; c->C = t->T.clip;
+    *out = c.release();
+    CB_END
+}
 int cb_trainer_destroy(cb_trainer* t) {
     CB_TRY
     delete t;

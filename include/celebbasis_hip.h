@@ -213,6 +213,11 @@ int cb_trainer_cfg_default(cb_trainer_cfg* cfg);   /* SD v1-4 + aigc_id.yaml val
  * celeb_embeddings [es,1+inner,width]; optional id_embeddings [max_ids, es*width], id_coefficients [max_ids, es*inner] */
 int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg, cb_trainer** out);
 int cb_trainer_destroy(cb_trainer* t);
+/* cb_unet / cb_clip views that alias the trainer's device weights (no second copy of SD v1-4): the same run can personalise
+ * (cb_trainer_step) and then sample (cb_clip_forward + cb_unet_ddim_sample), as stable_txt2img.py does with the trained model.
+ * Destroy them with cb_unet_destroy / cb_clip_destroy; they must not outlive the cb_ctx. */
+int cb_trainer_share_unet(cb_trainer* t, cb_unet** out);
+int cb_trainer_share_clip(cb_trainer* t, cb_clip** out);
 typedef struct {
     const float* image;       /* [B,S,S,3]  batch['image']                 */
     const float* faces;       /* [B,S,S,6]  batch['image_ori']['faces']    */

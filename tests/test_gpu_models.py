@@ -375,3 +375,52 @@ def test_extract_pt_formats(cb, tmp_path):
             ref = (torch.einsum("ehk,ekc->ehc", coefs[i], basis[:, 1:]) + basis[:, 0].unsqueeze(1)).reshape(es * h, W)
             close(f"extract_pt.z{tag}.{i}", z.float(), ref, 2e-3 if fp16 else 1e-5)
             assert torch.equal(c.float(), coefs[i].half().float() if fp16 else coefs[i])
+
+
+def test_txt2img_script_mini(cb, tmp_path):
+    """the stable_txt2img counterpart end to end at mini sizes: YAML with the reference's target strings -> .ckpt ->
+    embeddings_gs-*.pt -> prompts -> DDIM with guidance -> decoded .jpg files (orchestration; numerics are covered above)"""
+    import yaml
+    from PIL import Image
+    from celebbasis_amd.scripts import stable_txt2img
+    from celebbasis_amd.ldm.modules.encoders.modules import FrozenCLIPEmbedder
+    from oracle import cb_oracle as O
+    ucfg = dict(in_channels=4, out_channels=4, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2), attention_resolutions=(1, 2),
+                num_heads=2, context_dim=48)
+    vcfg = dict(ch=32, ch_mult=(1, 2, 2), num_res_blocks=1, in_channels=3, z_channels=4)
+    ccfg = dict(vocab=49408, width=48, layers=1, heads=4, ctx_len=77, mlp=96)
+    K = 16
+    cfg = dict(model=dict(target="ldm.models.diffusion.ddpm.LatentDiffusion", params=dict(
+        linear_start=0.00085, linear_end=0.012, timesteps=1000, scale_factor=0.18215, image_size=16, channels=4,
+        first_stage_key="image", cond_stage_key="caption", conditioning_key="crossattn", cond_stage_trainable=False,
+        personalization_config=dict(target="ldm.modules.embedding_manager.EmbeddingManagerId", params=dict(
+            placeholder_strings=["sks"], initializer_words=["face"], max_ids=10, num_embeds_per_token=2, meta_mlp_depth=1,
+            loss_type="none", meta_inner_dim=K, test_mode="coefficient", momentum=0.99, save_fp16=False)),
+        unet_config=dict(target="ldm.modules.diffusionmodules.openaimodel.UNetModel", params=dict(
+            image_size=16, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[1, 2], num_res_blocks=1,
+            channel_mult=[1, 2, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1, context_dim=48)),
+        first_stage_config=dict(target="ldm.models.autoencoder.AutoencoderKL", params=dict(embed_dim=4, ddconfig=dict(
+            double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32, ch_mult=[1, 2, 2], num_res_blocks=1,
+            attn_resolutions=[], dropout=0.0))),
+        cond_stage_config=dict(target="ldm.modules.encoders.modules.FrozenCLIPEmbedder", params=dict(
+            vocab=49408, width=48, layers=1, heads=4, mlp=96, num_embeds_per_token=2, n_components=K)))))
+    (tmp_path / "mini.yaml").write_text(yaml.safe_dump(cfg))
+    sd = {"model.diffusion_model." + k: v for k, v in O.init_weights(O.unet_param_shapes(ucfg), seed=21).items()}
+    sd.update({"first_stage_model." + k: v for k, v in O.init_weights(O.vae_decoder_param_shapes(vcfg), seed=22).items()})
+    clip_shapes = {"cond_stage_model." + FrozenCLIPEmbedder.PREFIX + k: v for k, v in FrozenCLIPEmbedder.param_shapes(ccfg).items()}
+    sd.update(O.init_weights(clip_shapes, seed=23))
+    g = torch.Generator().manual_seed(24)
+    sd["celeb_embeddings"] = torch.randn(2, 1 + K, 48, generator=g) * 0.05
+    torch.save({"state_dict": sd}, tmp_path / "mini.ckpt")
+    torch.save({"id_coefficients": [torch.randn(2, 1, K, generator=g) for _ in range(10)]}, tmp_path / "embeddings_gs-800.pt")
+    (tmp_path / "prompts.txt").write_text("a photo of sks person\nsks person on the beach\n")
+    out = tmp_path / "out"
+    stable_txt2img.main(["--config", str(tmp_path / "mini.yaml"), "--ckpt", str(tmp_path / "mini.ckpt"),
+                         "--embedding_path", str(tmp_path / "embeddings_gs-800.pt"), "--from-file", str(tmp_path / "prompts.txt"),
+                         "--n_samples", "2", "--ddim_steps", "3", "--H", "64", "--W", "64", "--scale", "5", "--eval_id1", "3",
+                         "--outdir", str(out), "--fixed_code"])
+    files = sorted(os.listdir(out / "samples"))
+    assert files == ["00000.jpg", "00001.jpg", "00002.jpg", "00003.jpg"]
+    assert Image.open(out / "samples" / "00000.jpg").size == (64, 64)
+    grids = [f for f in os.listdir(out) if f.endswith(".jpg")]
+    assert len(grids) == 2 and Image.open(out / grids[0]).size == (128, 64)

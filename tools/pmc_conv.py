@@ -12,7 +12,7 @@ from celebbasis_amd import lib  # noqa: E402
 L = lib.load()
 ctx = lib.Context()
 DEV = "cuda:0"
-for (N, H, W, Ci, Co) in [(1, 256, 256, 256, 256), (1, 64, 64, 320, 320), (1, 16, 16, 1280, 1280)]:
+for (N, H, W, Ci, Co) in [(1, 256, 256, 256, 256), (1, 512, 512, 128, 128), (1, 128, 128, 512, 512), (1, 64, 64, 320, 320), (1, 16, 16, 1280, 1280)]:
     x = torch.randn(N, H, W, Ci, device=DEV); w = torch.randn(Co, 9 * Ci, device=DEV) * 0.01; b = torch.zeros(Co, device=DEV)
     y = torch.empty(N, H, W, Co, device=DEV)
     for _ in range(5):
