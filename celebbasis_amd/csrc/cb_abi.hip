@@ -328,6 +328,13 @@ int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int
     k_row_surgery_fwd(ctx->c.launch(), out, embedded, z, tokens, map, B, T, C, reps, placeholder);
     CB_END
 }
+int cb_row_surgery_multi(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map, int B,
+                         int T, int C, int reps, const int64_t* placeholders, int nph) {
+    CB_TRY
+    require(ctx, "ctx"); require(placeholders, "placeholders");
+    k_row_surgery_multi(ctx->c.launch(), out, embedded, z, tokens, map, B, T, C, reps, placeholders, nph);
+    CB_END
+}
 int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int64_t n, int* step_dev, float lr, float b1,
                   float b2, float eps, float wd) {
     CB_TRY

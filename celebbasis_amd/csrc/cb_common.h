@@ -180,6 +180,8 @@ void k_basis_fwd(const Launch& L, float* z, const float* coef, const float* basi
 void k_basis_bwd(const Launch& L, float* dcoef, const float* dz, const float* basis, int R, int E, int Kc, int Cz);
 void k_row_surgery_fwd(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens,
                        int32_t* map, int B, int T, int C, int reps, int64_t placeholder);
+void k_row_surgery_multi(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens, int32_t* map, int B,
+                         int T, int C, int reps, const int64_t* placeholders_dev, int nph);
 void k_row_surgery_bwd(const Launch& L, float* dz, const float* dout, const int32_t* map, int B, int T, int C, int reps);
 void k_ema_update(const Launch& L, float* id_emb, float* id_coef, const float* z, const float* coef,
                   const int64_t* ids, int ids_stride, int B, int embN, int coefN, int max_ids, float m);

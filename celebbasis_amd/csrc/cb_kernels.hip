@@ -1049,20 +1049,29 @@ void k_basis_bwd(const Launch& L, float* dcoef, const float* dz, const float* ba
 
 // Row surgery (helpers.py:13-41 shift_tensor_dim0 + embedding_manager.py:347-360), one block per sample.
 // map[b][o] = source row i >= 0 (copy in[b][i]) or -(1+j) (take z[b][j], j < reps).
+// Up to CB_MAX_PLACEHOLDERS placeholder tokens per sample (embedding_manager.py:323-391: one / two / three persons in a prompt):
+// `placeholders` is a device array [B][nph] (negative = unused); an occurrence of placeholder k takes rows z[b][k*reps + j].
 __global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict__ out, const float* __restrict__ in,
                                                                const float* __restrict__ z, const int64_t* __restrict__ tokens,
                                                                int32_t* __restrict__ map, int T, int C, int reps,
-                                                               int64_t placeholder) {
+                                                               int64_t placeholder, const int64_t* __restrict__ placeholders, int nph) {
     // grid (B, slices): every block rebuilds the (tiny) row map from an LDS copy of the sample's tokens and copies its
     // slice of output rows; the serial part no longer waits on T dependent global loads
     __shared__ int smap[256];
-    __shared__ unsigned char hit[256];
+    __shared__ unsigned char hit[256];          // 0 = ordinary token, 1 + k = occurrence of placeholder k
     const int b = blockIdx.x;
-    for (int i = threadIdx.x; i < T; i += blockDim.x) hit[i] = tokens[(long)b * T + i] == placeholder;
+    for (int i = threadIdx.x; i < T; i += blockDim.x) {
+        const int64_t tk = tokens[(long)b * T + i];
+        int h = 0;
+        if (placeholders) {
+            for (int k = nph - 1; k >= 0; --k) { const int64_t ph = placeholders[(long)b * nph + k]; if (ph >= 0 && tk == ph) h = 1 + k; }
+        } else if (tk == placeholder) h = 1;
+        hit[i] = (unsigned char)h;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         int cnt = 0;
-        for (int i = 0; i < T; ++i) cnt += hit[i];
+        for (int i = 0; i < T; ++i) cnt += hit[i] != 0;
         int keep = T - cnt * (reps - 1);  // rows of the source that survive ("drop the last")
         for (int o = 0; o < T; ++o) smap[o] = o;  // untouched rows keep their own content
         int shift = 0;
@@ -1070,7 +1079,8 @@ __global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict_
             int tgt = i + shift;
             if (tgt < T) smap[tgt] = i;
             if (hit[i]) {
-                for (int j = 0; j < reps; ++j) if (tgt + j < T) smap[tgt + j] = -(1 + j);
+                const int k = hit[i] - 1;
+                for (int j = 0; j < reps; ++j) if (tgt + j < T) smap[tgt + j] = -(1 + k * reps + j);
                 shift += reps - 1;
             }
         }
@@ -1078,9 +1088,10 @@ __global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict_
     __syncthreads();
     if (blockIdx.y == 0)
         for (int o = threadIdx.x; o < T; o += blockDim.x) map[(long)b * T + o] = smap[o];
+    const int zrows = reps * (placeholders ? nph : 1);
     for (int o = blockIdx.y; o < T; o += gridDim.y) {
         const int s = smap[o];
-        const float* src = (s >= 0) ? in + ((long)b * T + s) * C : z + ((long)b * reps + (-s - 1)) * C;
+        const float* src = (s >= 0) ? in + ((long)b * T + s) * C : z + ((long)b * zrows + (-s - 1)) * C;
         float* dst = out + ((long)b * T + o) * C;
         for (int c = threadIdx.x; c < C; c += blockDim.x) dst[c] = src[c];
     }
@@ -1088,7 +1099,15 @@ __global__ __launch_bounds__(256) void row_surgery_fwd_kernel(float* __restrict_
 void k_row_surgery_fwd(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens, int32_t* map, int B,
                        int T, int C, int reps, int64_t placeholder) {
     CB_CHECK(T <= 256, CB_ERR_SHAPE, "row surgery: T=%d > 256", T);
-    LAUNCH(row_surgery_fwd_kernel, dim3(B, T < 16 ? T : 16), dim3(256), L, out, in, z, tokens, map, T, C, reps, placeholder);
+    LAUNCH(row_surgery_fwd_kernel, dim3(B, T < 16 ? T : 16), dim3(256), L, out, in, z, tokens, map, T, C, reps, placeholder,
+           (const int64_t*)nullptr, 1);
+}
+void k_row_surgery_multi(const Launch& L, float* out, const float* in, const float* z, const int64_t* tokens, int32_t* map, int B,
+                         int T, int C, int reps, const int64_t* placeholders_dev, int nph) {
+    CB_CHECK(T <= 256, CB_ERR_SHAPE, "row surgery: T=%d > 256", T);
+    CB_CHECK(nph >= 1 && nph <= 8 && nph * reps <= 120, CB_ERR_ARG, "row surgery: nph=%d reps=%d unsupported", nph, reps);
+    LAUNCH(row_surgery_fwd_kernel, dim3(B, T < 16 ? T : 16), dim3(256), L, out, in, z, tokens, map, T, C, reps, (int64_t)-1,
+           placeholders_dev, nph);
 }
 // dz[b][j][c] = sum over output rows o with map == -(1+j) of dout[b][o][c]
 __global__ void row_surgery_bwd_kernel(float* __restrict__ dz, const float* __restrict__ dout, const int32_t* __restrict__ map,

@@ -515,6 +515,18 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     // momentum dictionaries (embedding_manager.py:484-489) use the first face chunk (meta1 / cef1)
     k_ema_update(L, T->id_emb, T->id_coef, zz->p, xn->p, bt.ids, 2, B, es * w, es * K, c.max_ids, c.momentum);
     ph_id.reset();
+
+    // (3) conditioning: token embedding -> manager hook (row surgery) -> CLIP   (modules.py:176-298, 345-404). It needs the
+    // identity embedding but not the latent, so it stays on the side stream: ~200 M=77 launches hidden under the VAE encode.
+    std::unique_ptr<Phase> ph_clip(new Phase(L, "phase:clip_fwd"));
+    Ten* emb0 = G.make(B, T77, 1, w);
+    k_gather_rows(L, emb0->p, T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
+    Ten* emb1 = G.make(B, T77, 1, w, true);
+    int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
+    k_row_surgery_fwd(L, emb1->p, emb0->p, zz->p, bt.tokens, map, B, T77, w, es, c.placeholder_token);
+    Ten* cond = clip_encode(G, T->clip, emb1);
+    ph_clip.reset();
+
     if (fork) { CB_HIP(hipEventRecord(ctx->ev_join, ctx->aux)); G.L.stream = main_stream; }
 
     // (1) first stage: VAE encode -> posterior sample * scale_factor   (ddpm.py:702-759, 590-597) — no grad, main stream
@@ -528,17 +540,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         G.tap("z0", z0);
     }
 
-    if (fork) CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));   // join: the conditioning needs the identity embedding
-
-    // (3) conditioning: token embedding -> manager hook (row surgery) -> CLIP   (modules.py:176-298, 345-404)
-    std::unique_ptr<Phase> ph_clip(new Phase(L, "phase:clip_fwd"));
-    Ten* emb0 = G.make(B, T77, 1, w);
-    k_gather_rows(L, emb0->p, T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
-    Ten* emb1 = G.make(B, T77, 1, w, true);
-    int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
-    k_row_surgery_fwd(L, emb1->p, emb0->p, zz->p, bt.tokens, map, B, T77, w, es, c.placeholder_token);
-    Ten* cond = clip_encode(G, T->clip, emb1);
-    ph_clip.reset();
+    if (fork) CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));   // join: the UNet needs the conditioning
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
     std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));

@@ -56,6 +56,10 @@ class DDIMSampler(object):
             raise AssertionError("alphas have to be defined for each timestep")
         prev = torch.as_tensor(self.model.alphas_cumprod_prev).detach().float().cpu()
         self.ddim_timesteps = ddim_timesteps(ddim_discretize, ddim_num_steps, self.ddpm_num_timesteps)
+        if int(self.ddim_timesteps.max()) >= self.ddpm_num_timesteps:
+            # same failure as the reference (its `alphacums[ddim_timesteps]` raises too), with the reason spelled out
+            raise IndexError(f"ddim_num_steps={ddim_num_steps} does not divide {self.ddpm_num_timesteps}: the '+1' shifted schedule "
+                             f"reaches step {int(self.ddim_timesteps.max())}")
         full = dict(betas=torch.as_tensor(self.model.betas).detach().float().cpu(), alphas_cumprod=acp, alphas_cumprod_prev=prev,
                     sqrt_alphas_cumprod=acp.sqrt(), sqrt_one_minus_alphas_cumprod=(1. - acp).sqrt(),
                     log_one_minus_alphas_cumprod=(1. - acp).log(), sqrt_recip_alphas_cumprod=(1. / acp).sqrt(),

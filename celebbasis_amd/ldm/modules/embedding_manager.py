@@ -106,6 +106,25 @@ class EmbeddingManagerId:
             self.meta_id_net.load_trainable_state_dict(ckpt["meta_id_net"])
 
     # ---- inference-time hook (embedding_manager.py:312-319 test branch + 464-475): coefficients -> embedding -> row surgery
+    def _predicted_embedding(self, id_idx, basis, dev):
+        """embedding_manager.py:464-475 `_momentum_update` in eval mode: (es*h, W) for one identity"""
+        es, K, W = self.num_es, self.inner_dim, self.token_dim
+        if self.test_mode != "coefficient":
+            return self.id_embeddings[id_idx].to(dev).float().reshape(es, W)
+        L, ctx = _lib.load(), context_for(dev)
+        coef = self.id_coefficients[id_idx].to(dev).float().reshape(es, K).contiguous()
+        z = torch.empty(es, W, device=dev)
+        for e in range(es):      # z[e] = coef[e] @ basis[e,1:] + basis[e,0]   (einsum 'e h k, e k c -> e h c')
+            d = _lib.GemmDesc()
+            d.A = coef[e].data_ptr(); d.B = basis[e, 1:].data_ptr(); d.C = z[e].data_ptr()
+            d.M, d.N, d.K = 1, W, K
+            d.lda, d.ldb, d.ldc = K, W, W
+            d.a_layout, d.b_layout, d.batch = 0, 1, 1
+            d.bias = basis[e, 0].data_ptr(); d.alpha, d.beta = 1.0, 0.0
+            _lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+        self._keep = (coef, z)
+        return z
+
     def forward(self, tokenized_text, embedded_text, face_image=None, img_ori=None, celeb_embeddings=None):
         if img_ori is None:
             return embedded_text
@@ -116,29 +135,28 @@ class EmbeddingManagerId:
         ctx = context_for(dev)
         L = _lib.load()
         B, T, W = embedded_text.shape
-        es, K = self.num_es, self.inner_dim
+        reps = self.num_es * self.meta_heads
         basis = (celeb_embeddings if celeb_embeddings is not None else self.celeb_embeddings).to(dev).float().contiguous()
-        ids = img_ori["ids"]
-        z = torch.empty(B, es, W, device=dev)
-        if self.test_mode == "coefficient":
-            for b in range(B):
-                coef = self.id_coefficients[int(ids[b][0])].to(dev).float().reshape(es, K).contiguous()
-                for e in range(es):      # z[e] = coef[e] @ basis[e,1:] + basis[e,0]   (einsum 'e h k, e k c -> e h c')
-                    d = _lib.GemmDesc()
-                    d.A = coef[e].data_ptr(); d.B = basis[e, 1:].data_ptr(); d.C = z[b, e].data_ptr()
-                    d.M, d.N, d.K = 1, W, K
-                    d.lda, d.ldb, d.ldc = K, W, W
-                    d.a_layout, d.b_layout, d.batch = 0, 1, 1
-                    d.bias = basis[e, 0].data_ptr(); d.alpha, d.beta = 1.0, 0.0
-                    _lib.check(L.cb_gemm(ctx.h, C.byref(d)))
-        else:
-            for b in range(B):
-                z[b] = self.id_embeddings[int(ids[b][0])].to(dev).reshape(es, W)
+        ids, num_ids = img_ori["ids"], img_ori.get("num_ids")
+        # one / two / three persons per prompt (embedding_manager.py:323-391): person k is written where placeholder_strings[k] occurs
+        counts = [int(num_ids[b]) if num_ids is not None else 1 for b in range(B)]
+        nph = max(counts)
+        if nph < 1 or nph > 3 or nph > len(self.placeholder_strings):
+            raise ValueError(f"num_ids={nph} needs that many placeholder_strings (have {self.placeholder_strings}); 1..3 are supported")
+        z = torch.zeros(B, nph * reps, W, device=dev)
+        ph = torch.full((B, nph), -1, dtype=torch.int64)
+        for b in range(B):
+            for k in range(counts[b]):
+                tok = self.string_to_token_dict[self.placeholder_strings[k]]
+                if tok is None:
+                    raise RuntimeError(f"the BPE id of placeholder '{self.placeholder_strings[k]}' is unknown offline")
+                ph[b, k] = tok
+                z[b, k * reps:(k + 1) * reps] = self._predicted_embedding(int(ids[b][k]), basis, dev)
+        ph = ph.to(dev)
         out = torch.empty_like(embedded_text)
         mp = torch.empty(B * T, dtype=torch.int32, device=dev)
-        ph = self.string_to_token_dict[self.placeholder_strings[0]]
-        _lib.check(L.cb_row_surgery(ctx.h, _lib.ptr(embedded_text.contiguous()), _lib.ptr(z), _lib.ptr(tokenized_text.contiguous(), torch.int64),
-                                    _lib.ptr(out), C.c_void_p(mp.data_ptr()), B, T, W, es * self.meta_heads, ph))
+        _lib.check(L.cb_row_surgery_multi(ctx.h, _lib.ptr(embedded_text.contiguous()), _lib.ptr(z), _lib.ptr(tokenized_text.contiguous(), torch.int64),
+                                          _lib.ptr(out), C.c_void_p(mp.data_ptr()), B, T, W, reps, _lib.ptr(ph, torch.int64), nph))
         return out
 
     __call__ = forward

@@ -132,6 +132,10 @@ int cb_mse_loss(cb_ctx* ctx, const float* pred_nhwc, const float* target_nchw, f
 int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size); /* meta_net.py:253-260 */
 int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map,
                    int B, int T, int C, int reps, int64_t placeholder);                               /* helpers.py:13-41 */
+/* the two / three person prompts of embedding_manager.py:323-345, 363-391: placeholders = device int64 [B][nph] (negative =
+ * unused slot), z = [B][nph*reps][C]; an occurrence of placeholder k is replaced by rows z[b][k*reps .. k*reps+reps-1] */
+int cb_row_surgery_multi(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map,
+                         int B, int T, int C, int reps, const int64_t* placeholders, int nph);
 int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int64_t n, int* step_dev, float lr, float b1,
                   float b2, float eps, float wd);                                                     /* ddpm.py:1454 */
 int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W);

@@ -586,6 +586,26 @@ def shift_rows(tokens_1d, embedded_2d, z_rows, placeholder, reps):
     return out
 
 
+def shift_rows_multi(tokens_1d, embedded_2d, z_list, placeholders, reps):
+    """helpers.py:6-41 with several placeholder tokens + embedding_manager.py:323-345 / 363-391 (two / three persons):
+    every occurrence of placeholders[k] is widened to `reps` rows that take z_list[k]; later rows move right, the tail is dropped."""
+    T = tokens_1d.shape[0]
+    toks = tokens_1d.tolist()
+    pos = [(i, k) for k, ph in enumerate(placeholders) for i, tk in enumerate(toks) if tk == ph]
+    offset = np.zeros(T, dtype=np.int64)
+    for p, _ in pos:
+        offset[p + 1:] += reps - 1
+    keep = T - len(pos) * (reps - 1)
+    target = (np.arange(T) + offset)[:keep]
+    out = embedded_2d.clone()
+    out[torch.as_tensor(target)] = embedded_2d[:keep]
+    for p, k in pos:
+        for j in range(reps):
+            if p < keep and target[p] + j < T:
+                out[int(target[p]) + j] = z_list[k][j]
+    return out
+
+
 def celeb_head(W, v, es, inner):
     """meta_net.py:266-289: EqualLinear(lr_mul=1)+LeakyReLU(0.2) -> (b,e,h=1,d) -> L2 norm over d -> einsum with basis + mean.
     v: [R,512] normalised FR features. returns (coef [R,es,inner], z [R,es,width])"""

@@ -139,6 +139,24 @@ def gen_shift_rows(manifest):
         cases.append(dict(tokens=toks, placeholder=ph, reps=reps, embedded=emb, z=z, out=out))
     torch.save(cases, os.path.join(OUT, "shift_rows.pt"))
     manifest["shift_rows.pt"] = "ldm/modules/id_embedding/helpers.py:6-41 + embedding_manager.py:347-360"
+    # several placeholder tokens in one prompt (two / three persons, embedding_manager.py:323-345, 363-391)
+    multi = []
+    mspecs = [
+        (torch.LongTensor([0, 1, 2, 2, 3, 4, 5, 6, 7, 99] + [99] * 20), [2, 6], 2),                 # helpers.py:44-54, its own rep_tokens
+        (torch.LongTensor([49406, 320, 1125, 539, 48136, 2533, 537, 662, 2533, 49407] + [49407] * 67), [48136, 662], 2),   # sks ... ks
+        (torch.LongTensor([49406, 662, 267, 48136, 537, 4236, 49407] + [49407] * 70), [48136, 662, 4236], 2),               # ks, sks and ata
+        (torch.LongTensor([49406, 320, 1125, 539, 48136, 2533, 49407] + [49407] * 70), [48136, 662], 2),                    # second token absent
+    ]
+    for toks, phs, reps in mspecs:
+        emb = torch.randn(toks.shape[0], 6, generator=g)
+        zs = [torch.randn(reps, 6, generator=g) for _ in phs]
+        out, final = shift_tensor_dim0(emb.clone(), get_rep_pos(toks, phs), reps)
+        for k in range(len(phs)):
+            for one_pos in final[k]:
+                out[one_pos] = zs[k]
+        multi.append(dict(tokens=toks, placeholders=phs, reps=reps, embedded=emb, z=zs, out=out))
+    torch.save(multi, os.path.join(OUT, "shift_rows_multi.pt"))
+    manifest["shift_rows_multi.pt"] = "ldm/modules/id_embedding/helpers.py:6-41 + embedding_manager.py:323-345, 363-391 (several placeholders)"
 
 
 def gen_unet(manifest):
@@ -296,6 +314,17 @@ def gen_ddim(manifest):
     manifest["ddim_mini.pt"] = ("ldm/models/diffusion/ddim.py DDIMSampler.make_schedule:25-54, sample:56-111, ddim_sampling:113-163, "
                                 "p_sample_ddim:166-204; util.py make_ddim_timesteps:46-60, make_ddim_sampling_parameters:63-74 — over the "
                                 "reference UNetModel (mini config)")
+
+
+def gen_templates():
+    """sha256 + length of the caption template list (ldm/data/face_id.py:17-99), read without importing torchvision"""
+    import ast
+    tree = ast.parse(open(os.path.join(REF, "ldm", "data", "face_id.py")).read())
+    for node in tree.body:
+        if isinstance(node, ast.Assign) and getattr(node.targets[0], "id", "") == "imagenet_templates_small":
+            lst = ast.literal_eval(node.value)
+            return dict(sha256=hashlib.sha256("\n".join(lst).encode()).hexdigest(), count=len(lst))
+    raise RuntimeError("imagenet_templates_small not found")
 
 
 def gen_basis(manifest):
@@ -497,6 +526,8 @@ def main():
         gen_ddim(manifest)
     if want("basis"):
         gen_basis(manifest)
+    if want("templates"):
+        digests["imagenet_templates_small"] = gen_templates()
     if want("frnet"):
         digests["iresnet100"] = gen_frnet(manifest)
     if want("manager"):

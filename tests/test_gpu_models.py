@@ -417,7 +417,7 @@ def test_txt2img_script_mini(cb, tmp_path):
     out = tmp_path / "out"
     stable_txt2img.main(["--config", str(tmp_path / "mini.yaml"), "--ckpt", str(tmp_path / "mini.ckpt"),
                          "--embedding_path", str(tmp_path / "embeddings_gs-800.pt"), "--from-file", str(tmp_path / "prompts.txt"),
-                         "--n_samples", "2", "--ddim_steps", "3", "--H", "64", "--W", "64", "--scale", "5", "--eval_id1", "3",
+                         "--n_samples", "2", "--ddim_steps", "4", "--H", "64", "--W", "64", "--f", "4", "--scale", "5", "--eval_id1", "3",
                          "--outdir", str(out), "--fixed_code"])
     files = sorted(os.listdir(out / "samples"))
     assert files == ["00000.jpg", "00001.jpg", "00002.jpg", "00003.jpg"]

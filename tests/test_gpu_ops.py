@@ -335,6 +335,18 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
                                    lib.ptr(toks, torch.int64), lib.ptr(o), C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], case["placeholder"]))
         ctx.sync()
         assert torch.equal(o[0].cpu(), case["out"]), f"row surgery case {i} is not bit-exact"
+    # several placeholder tokens per prompt (two / three persons), incl. the reference's own helpers.py:44-54 example
+    for i, case in enumerate(torch.load(os.path.join(golden_dir, "shift_rows_multi.pt"), weights_only=False)):
+        toks = case["tokens"][None].contiguous().to(_dev())
+        T, Cw = case["embedded"].shape
+        nph = len(case["placeholders"])
+        o = torch.empty(1, T, Cw, device=_dev()); mp = torch.empty(T, dtype=torch.int32, device=_dev())
+        ph = torch.tensor([case["placeholders"]], dtype=torch.int64, device=_dev())
+        zcat = dv(torch.cat(case["z"], dim=0)[None])                       # [1][nph*reps][C]
+        lib.check(L.cb_row_surgery_multi(ctx.h, lib.ptr(dv(case["embedded"][None])), lib.ptr(zcat), lib.ptr(toks, torch.int64), lib.ptr(o),
+                                         C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], lib.ptr(ph, torch.int64), nph))
+        ctx.sync()
+        assert torch.equal(o[0].cpu(), case["out"]), f"multi-placeholder row surgery case {i} is not bit-exact"
     # AdamW, 5 steps
     g = torch.Generator().manual_seed(0)
     p = torch.randn(1000, generator=g); m = torch.zeros(1000); v = torch.zeros(1000)

@@ -107,6 +107,11 @@ def test_product_tables_match_oracle_and_reference_digests(golden_dir):
     with open(os.path.join(golden_dir, "state_dict_digests.json")) as f:
         d = json.load(f)
     assert keys_digest(UNetModel.param_shapes(synthetic.UNET_SD14)) == d["unet_sd14"]
+    # the caption templates of the feeder are the reference's list (face_id.py:17-99), by digest
+    import hashlib
+    from celebbasis_amd.ldm.data.face_id import imagenet_templates_small
+    assert len(imagenet_templates_small) == d["imagenet_templates_small"]["count"]
+    assert hashlib.sha256("\n".join(imagenet_templates_small).encode()).hexdigest() == d["imagenet_templates_small"]["sha256"]
 
 
 def test_reference_yaml_is_drop_in(tmp_path):

@@ -35,6 +35,12 @@ def test_shift_rows_bit_exact(golden_dir):
         assert torch.equal(out, case["out"]), case["tokens"][:12]
 
 
+def test_shift_rows_multi_bit_exact(golden_dir):
+    for case in _load(golden_dir, "shift_rows_multi.pt"):
+        out = O.shift_rows_multi(case["tokens"], case["embedded"], case["z"], case["placeholders"], case["reps"])
+        assert torch.equal(out, case["out"]), case["placeholders"]
+
+
 def test_state_dict_tables_match_reference(golden_dir):
     with open(os.path.join(golden_dir, "state_dict_digests.json")) as f:
         d = json.load(f)
@@ -227,6 +233,9 @@ def test_host_ddim_schedule_matches_reference(golden_dir):
         assert torch.equal(torch.as_tensor(sg), ref["sigmas"].float()) and torch.equal(torch.as_tensor(s1m), ref["sqrt_one_minus_alphas"])
         assert torch.equal(torch.as_tensor(s.ddim_sigmas), ref["sigmas"])            # float64, as the reference keeps it
     assert torch.equal(torch.as_tensor(ddim_timesteps("quad", 10, 1000)), fx["quad_10"])
+    import pytest
+    with pytest.raises(IndexError):          # 1000 // 3 = 333 -> steps [1, 334, 667, 1000]: out of range, as in the reference
+        s.make_schedule(3, verbose=False)
 
 
 def test_celeb_basis_builder_vs_reference(golden_dir):
