@@ -323,10 +323,8 @@ __device__ __forceinline__ int xcd_remap(int b, int n) {
 }
 
 template <int BM, int BN, int AK, int BKIND, bool VEC>
-__global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
+__device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4], float (*Bs)[BK][BN + 4]) {
     constexpr int TM = BM / 64, TN = BN / 64;
-    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
-    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
 
     const GemmArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -522,6 +520,21 @@ __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
 }
 
 // split-K reduce + epilogue: one thread per output element
+template <int BM, int BN, int AK, int BKIND, bool VEC>
+__global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN + 4];
+    gemm_body<BM, BN, AK, BKIND, VEC>(p, As, Bs);
+}
+// Same body, register budget capped at 128 VGPRs (accumulators included) so that 4 blocks instead of 3 are resident per CU:
+// an experiment switch for the 128x128 tile (CB_GEMM_OCC4=1), which otherwise needs 152 registers.
+template <int AK, int BKIND>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void gemm_kernel_occ4(const KArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[2][BK][128 + 4];
+    __shared__ __attribute__((aligned(16))) float Bs[2][BK][128 + 4];
+    gemm_body<128, 128, AK, BKIND, true>(p, As, Bs);
+}
+
 __global__ void splitk_reduce_kernel(const KArgs p) {
     const GemmArgs& a = p.a;
     long MN = (long)a.M * a.N;
@@ -585,7 +598,11 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
 
 template <int AK, int BKIND, bool VEC>
 static void launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
-    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    static const bool occ4 = [] { const char* e = getenv("CB_GEMM_OCC4"); return e && e[0] == '1'; }();
+    if (pl.BM == 128 && pl.BN == 128) {
+        if constexpr (VEC) { if (occ4) { hipLaunchKernelGGL((gemm_kernel_occ4<AK, BKIND>), grid, dim3(256), 0, s, ka); return; } }
+        hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    }
     else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<64, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     else hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
