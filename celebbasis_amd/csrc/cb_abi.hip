@@ -321,6 +321,23 @@ int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* o
     k_resize_bilinear_ac(L, out, warped, nface * B, S, S, out_size, out_size, 3);
     CB_END
 }
+int cb_face_augment(cb_ctx* ctx, const float* in, const float* params, float* out, int B, int S) {
+    CB_TRY
+    require(ctx, "ctx"); require(in, "in"); require(params, "params"); require(out, "out");
+    CB_CHECK(in != out, CB_ERR_ARG, "face augment: in-place is not supported (the flip reads mirrored pixels)");
+    Ctx* c = &ctx->c;
+    plan_and_run(c, [&]() {
+        float* ws = c->arena.allocf(face_augment_ws_floats(B));
+        k_face_augment(c->launch(), out, in, params, ws, B, S);
+    });
+    CB_END
+}
+int cb_paste_on_canvas(cb_ctx* ctx, const float* img, const int32_t* geom, float* out, int B, int S, int C) {
+    CB_TRY
+    require(ctx, "ctx"); require(img, "img"); require(geom, "geom"); require(out, "out");
+    k_paste_bg(ctx->c.launch(), out, img, geom, B, S, C);
+    CB_END
+}
 int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map, int B,
                    int T, int C, int reps, int64_t placeholder) {
     CB_TRY

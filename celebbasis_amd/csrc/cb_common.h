@@ -84,7 +84,7 @@ struct ConvGeom {
 };
 
 // ---------------------------------------------------------------- GEMM arguments
-enum { LD_ROW = 0, LD_COL = 1, LD_CONV = 2 };
+enum { LD_ROW = 0, LD_COL = 1, LD_CONV = 2, LD_CONVF = 3 /* kernel-internal: conv with the scalar tap walk (cb_gemm.hip) */ };
 struct GemmArgs {
     const float* A = nullptr; const float* B = nullptr; float* C = nullptr;
     int M = 0, N = 0, K = 0;
@@ -173,6 +173,10 @@ void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* po
 // face pre-processing (meta_net.py:250-260)
 void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* theta);
 void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C);
+// feeder augmentations (face_id.py:526-532, 712-730)
+size_t face_augment_ws_floats(int B);
+void k_face_augment(const Launch& L, float* out, const float* in, const float* params_dev, float* ws, int B, int S);
+void k_paste_bg(const Launch& L, float* out, const float* img, const int* geom_dev, int B, int S, int C);
 // manager
 void k_l2norm_fwd(const Launch& L, float* y, float* norms, const float* x, long rows, int D);
 void k_l2norm_bwd(const Launch& L, float* dx, const float* y, const float* norms, const float* dy, long rows, int D);

@@ -353,14 +353,16 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[BM / 64], rb[BN / 64];
+    // LD_CONVF is the host's choice for VEC && !up && !tr && C % BK == 0 convs: the tap / channel walk of the k loop is then
+    // wave-uniform (SGPRs). It is a separate instantiation so that the general gather's per-row state does not cost the
+    // common kernel registers.
+    constexpr bool conv_fast = (AK == LD_CONVF);
+    static_assert(!conv_fast || VEC, "LD_CONVF needs the vector loaders");
     ConvRows<BM> cr;
     ConvFast<BM> cf;
-    const bool conv_fast = VEC && AK == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % BK == 0);    // wave-uniform
     int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0
-    if constexpr (AK == LD_CONV) {
-        if (conv_fast) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
-        else cr.init(a.g, m0, a.M, kbeg, tid);
-    }
+    if constexpr (conv_fast) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
+    else if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
 
     const unsigned ma = ~0u, mb = ~0u;
     __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
@@ -375,7 +377,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
             int oa[BM / 64], ob[BN / 64];
             if constexpr (AK == LD_ROW) offs_row<BM>(oa, roA, k0, kend, tid);
             else if constexpr (AK == LD_COL) offs_col<BM>(oa, a.lda, m0, a.M, k0, kend, tid);
-            else if (conv_fast) {
+            else if constexpr (conv_fast) {
                 const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
                 const int kx = tap_u - ky * a.g.ks;
                 offs_conv_fast<BM>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 4);
@@ -598,9 +600,18 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
 
 template <int AK, int BKIND, bool VEC>
 static void launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
-    static const bool occ4 = [] { const char* e = getenv("CB_GEMM_OCC4"); return e && e[0] == '1'; }();
+    // 128x128 tile: 152 registers -> 3 blocks per CU (768 slots); the register-capped twin holds 4 (1024 slots). Measured on
+    // MI355X (profiles/README.md, run 21): the twin wins when the launch then needs fewer rounds of blocks (1024 blocks +7 %,
+    // 2048 blocks +12 %) and loses ~1 % otherwise; the variants that spill under the cap (general conv gather, ROW x COL) never use it.
+    // CB_GEMM_OCC4=0/1 forces the choice (experiments).
+    static const int occ4_env = [] { const char* e = getenv("CB_GEMM_OCC4"); return e ? (e[0] == '1' ? 1 : 0) : -1; }();
     if (pl.BM == 128 && pl.BN == 128) {
-        if constexpr (VEC) { if (occ4) { hipLaunchKernelGGL((gemm_kernel_occ4<AK, BKIND>), grid, dim3(256), 0, s, ka); return; } }
+        if constexpr (VEC && (AK == LD_CONVF || (AK == LD_ROW && BKIND == LD_ROW))) {
+            const long blocks = (long)grid.x * grid.y * grid.z;
+            const long r4 = (blocks + 1023) / 1024 * 4, r3 = (blocks + 767) / 768 * 3;
+            const bool use4 = occ4_env >= 0 ? occ4_env == 1 : (blocks >= 1024 && r4 < r3);
+            if (use4) { hipLaunchKernelGGL((gemm_kernel_occ4<AK, BKIND>), grid, dim3(256), 0, s, ka); return; }
+        }
         hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     }
     else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
@@ -674,7 +685,10 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_COL && a.b_kind == LD_ROW) launch_tiles<LD_COL, LD_ROW>(pl, grid, L.stream, ka, vec);
-    else if (a.a_kind == LD_CONV) launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka, vec);
+    else if (a.a_kind == LD_CONV) {
+        if (vec && !a.g.up && !a.g.tr && (a.g.C % BK == 0)) launch_tiles2<LD_CONVF, LD_ROW, true>(pl, grid, L.stream, ka);
+        else launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka, vec);
+    }
     else fail(CB_ERR_ARG, "gemm: unsupported operand kinds %d/%d", a.a_kind, a.b_kind);
     CB_HIP(hipGetLastError());
     // the event pair brackets the GEMM kernel alone, so a variant's average matches the rocprofv3 per-symbol average;

@@ -939,6 +939,125 @@ void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S
     LAUNCH(affine_warp_kernel, grid1d((long)nface * B * S * S), dim3(256), L, out, faces, B, S, nface, th[0], th[1], th[2], th[3],
            th[4], th[5]);
 }
+// ------------------------------------------------------------------ feeder augmentations on the device
+// face_id.py:526-532 `trans` after the resize: RandomHorizontalFlip + ColorJitter(b, c, s in [0.8,1.2], hue 0.01) + Normalize,
+// on HWC images in [-1,1]. torchvision's tensor formulas, applied in the fixed order brightness -> contrast -> saturation -> hue
+// (torchvision draws a random order; bit-exact parity with its PIL path is not a goal).
+// params[b] = {flip, brightness, contrast, saturation, hue_shift}
+constexpr int AUG_NCHUNK = 64;
+__device__ __forceinline__ float clamp01(float v) { return fminf(fmaxf(v, 0.f), 1.f); }
+__device__ __forceinline__ float gray_of(float r, float g, float b) { return 0.2989f * r + 0.587f * g + 0.114f * b; }
+// pass 1: per (sample, chunk) sum of the grayscale of the brightness-adjusted image (the contrast pivot is its mean)
+__global__ __launch_bounds__(256) void jitter_gray_partial_kernel(float* __restrict__ part, const float* __restrict__ in,
+                                                                   const float* __restrict__ params, int HW) {
+    __shared__ float sh[4];
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const float br = params[b * 5 + 1];
+    const int per = (HW + AUG_NCHUNK - 1) / AUG_NCHUNK;
+    const int p0 = chunk * per, p1 = min(HW, p0 + per);
+    float acc = 0.f;
+    for (int p = p0 + threadIdx.x; p < p1; p += 256) {
+        const float* px = in + ((long)b * HW + p) * 3;
+        float r = clamp01((px[0] + 1.f) * 0.5f * br), g = clamp01((px[1] + 1.f) * 0.5f * br), bl = clamp01((px[2] + 1.f) * 0.5f * br);
+        acc += gray_of(r, g, bl);
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[b * AUG_NCHUNK + chunk] = (sh[0] + sh[1]) + (sh[2] + sh[3]);
+}
+__global__ __launch_bounds__(256) void jitter_apply_kernel(float* __restrict__ out, const float* __restrict__ in,
+                                                            const float* __restrict__ params, const float* __restrict__ part, int S) {
+    __shared__ float mean_s;
+    const int b = blockIdx.y, HW = S * S;
+    if (threadIdx.x == 0) {
+        float m = 0.f;
+        for (int i = 0; i < AUG_NCHUNK; ++i) m += part[b * AUG_NCHUNK + i];       // fixed order: deterministic
+        mean_s = m / (float)HW;
+    }
+    __syncthreads();
+    const float flip = params[b * 5], br = params[b * 5 + 1], ct = params[b * 5 + 2], sa = params[b * 5 + 3], hu = params[b * 5 + 4];
+    const float mean = mean_s;
+    for (int p = blockIdx.x * 256 + threadIdx.x; p < HW; p += gridDim.x * 256) {
+        const int y = p / S, x = p - y * S;
+        const int xs = flip != 0.f ? S - 1 - x : x;
+        const float* px = in + ((long)b * HW + (long)y * S + xs) * 3;
+        float r = clamp01((px[0] + 1.f) * 0.5f * br), g = clamp01((px[1] + 1.f) * 0.5f * br), bl = clamp01((px[2] + 1.f) * 0.5f * br);
+        r = clamp01(ct * r + (1.f - ct) * mean); g = clamp01(ct * g + (1.f - ct) * mean); bl = clamp01(ct * bl + (1.f - ct) * mean);
+        const float gr = gray_of(r, g, bl);
+        r = clamp01(sa * r + (1.f - sa) * gr); g = clamp01(sa * g + (1.f - sa) * gr); bl = clamp01(sa * bl + (1.f - sa) * gr);
+        if (hu != 0.f) {   // rgb -> hsv, shift h, hsv -> rgb (torchvision _rgb2hsv / _hsv2rgb)
+            const float mx = fmaxf(r, fmaxf(g, bl)), mn = fminf(r, fminf(g, bl));
+            const float d = mx - mn, v = mx;
+            const float sat = mx > 0.f ? d / mx : 0.f;
+            float h = 0.f;
+            if (d > 0.f) {
+                if (mx == r) h = (g - bl) / d;
+                else if (mx == g) h = 2.f + (bl - r) / d;
+                else h = 4.f + (r - g) / d;
+                h = h / 6.f;
+                h = h - floorf(h);
+            }
+            h = h + hu; h = h - floorf(h);
+            const float h6 = h * 6.f;
+            const float fi = floorf(h6), f = h6 - fi;
+            const int i = ((int)fi) % 6;
+            const float pp = clamp01(v * (1.f - sat)), q = clamp01(v * (1.f - f * sat)), t = clamp01(v * (1.f - (1.f - f) * sat));
+            switch (i) {
+                case 0: r = v; g = t; bl = pp; break;
+                case 1: r = q; g = v; bl = pp; break;
+                case 2: r = pp; g = v; bl = t; break;
+                case 3: r = pp; g = q; bl = v; break;
+                case 4: r = t; g = pp; bl = v; break;
+                default: r = v; g = pp; bl = q; break;
+            }
+        }
+        float* o = out + ((long)b * HW + p) * 3;
+        o[0] = r * 2.f - 1.f; o[1] = g * 2.f - 1.f; o[2] = bl * 2.f - 1.f;
+    }
+}
+void k_face_augment(const Launch& L, float* out, const float* in, const float* params_dev, float* ws, int B, int S) {
+    L.count(2);
+    if (L.dry) return;
+    hipLaunchKernelGGL(jitter_gray_partial_kernel, dim3(AUG_NCHUNK, B), dim3(256), 0, L.stream, ws, in, params_dev, S * S);
+    hipLaunchKernelGGL(jitter_apply_kernel, dim3(cdiv((long)S * S, 256 * 4), B), dim3(256), 0, L.stream, out, in, params_dev, ws, S);
+    CB_HIP(hipGetLastError());
+}
+size_t face_augment_ws_floats(int B) { return (size_t)B * AUG_NCHUNK; }
+
+// face_id.py:712-730 `_add_bg`: the face bilinearly rescaled (align_corners=True) to rh x rw and pasted at (pos_h, pos_w) on a
+// canvas of -1. geom[b] = {rh, rw, pos_h, pos_w} (int32, drawn on the host like the reference's np.random calls).
+__global__ void paste_bg_kernel(float* __restrict__ out, const float* __restrict__ img, const int* __restrict__ geom, int B, int S,
+                                int C) {
+    long total = (long)B * S * S * C;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % C);
+        long r = i / C;
+        int x = (int)(r % S);
+        r /= S;
+        int y = (int)(r % S);
+        int b = (int)(r / S);
+        const int rh = geom[b * 4], rw = geom[b * 4 + 1], ph = geom[b * 4 + 2], pw = geom[b * 4 + 3];
+        float v = -1.f;
+        const int yy = y - ph, xx = x - pw;
+        if (yy >= 0 && yy < rh && xx >= 0 && xx < rw) {
+            const float sy = rh > 1 ? (float)(S - 1) / (float)(rh - 1) : 0.f, sx = rw > 1 ? (float)(S - 1) / (float)(rw - 1) : 0.f;
+            const float fy = sy * yy, fx = sx * xx;
+            int y0 = (int)fy, x0 = (int)fx;
+            int y1 = min(y0 + 1, S - 1), x1 = min(x0 + 1, S - 1);
+            const float wy = fy - y0, wx = fx - x0;
+            const float* base = img + (long)b * S * S * C + c;
+            const float v00 = base[((long)y0 * S + x0) * C], v01 = base[((long)y0 * S + x1) * C];
+            const float v10 = base[((long)y1 * S + x0) * C], v11 = base[((long)y1 * S + x1) * C];
+            v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+        }
+        out[i] = v;
+    }
+}
+void k_paste_bg(const Launch& L, float* out, const float* img, const int* geom_dev, int B, int S, int C) {
+    LAUNCH(paste_bg_kernel, grid1d((long)B * S * S * C), dim3(256), L, out, img, geom_dev, B, S, C);
+}
+
 // F.interpolate(mode='bilinear', align_corners=True), NHWC
 __global__ void resize_bilinear_ac_kernel(float* __restrict__ out, const float* __restrict__ in, int N, int Hin, int Win,
                                           int Hout, int Wout, int C) {

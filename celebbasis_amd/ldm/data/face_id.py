@@ -1,9 +1,11 @@
 """Feeder counterpart of ldm/data/face_id.py `FaceIdDatasetStyleGAN3` / `FaceIdDatasetOneShot` (reference :471-757).
 It produces the same sample dict (face_id.py:598-644): image (512,512,3) f32 in [-1,1], image_ori {faces (512,512,6), ids (2,),
 num_ids}, caption, id_idx, img_idx — with the same 81-template caption list and `diff_cnt=0 => id_cnt=2`.
-Augmentations (flip, colour jitter, `_add_bg` rescale-paste) are restated on torch tensors; bit-exact torchvision parity is not
-a goal: parity of the training step is defined on a replay stream. Without a dataset on disk the feeder
-synthesises seeded faces so the rest of the pipeline can run offline."""
+Augmentations (flip, colour jitter, `_add_bg` rescale-paste): the random draws are made on the host like the reference's
+transforms; the pixel work runs either per sample on the CPU (`__getitem__`, DataLoader workers, as in the reference) or for a
+whole batch on the device (`DeviceAugmenter`: cb_face_augment + cb_paste_on_canvas), which is what keeps the feeder ahead of a
+21 steps/s training loop. Bit-exact torchvision/PIL parity is not a goal: parity of the training step is defined
+on a replay stream. Without a dataset on disk the feeder synthesises seeded faces so the rest of the pipeline can run offline."""
 import pickle
 import random
 
@@ -69,29 +71,48 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         return len(self.ids) * (self.repeats if self.split == "train" else 1)
 
     def _aug(self, img):
-        """flip + mild brightness/contrast/saturation jitter in [0.8, 1.2] (face_id.py:526-532)"""
-        if self.rng.random() < self.flip_p:
-            img = img.flip(1)
-        x = (img + 1) * 0.5
-        b, c, s = (self.rng.uniform(0.8, 1.2) for _ in range(3))
+        """flip + colour jitter on the CPU worker (face_id.py:526-532), same parameter draws and formulas as the device path"""
+        flip, b, c, sat, hue = self._jitter_params()
+        x = (img.flip(1) if flip else img + 0) * 0.5 + 0.5
+        gray = lambda t: 0.2989 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]
         x = (x * b).clamp(0, 1)
-        m = x.mean()
-        x = ((x - m) * c + m).clamp(0, 1)
-        gray = x.mean(dim=-1, keepdim=True)
-        x = ((x - gray) * s + gray).clamp(0, 1)
+        x = (c * x + (1 - c) * gray(x).mean()).clamp(0, 1)
+        x = (sat * x + (1 - sat) * gray(x).unsqueeze(-1)).clamp(0, 1)
+        if hue != 0.0:
+            mx, mn = x.max(-1).values, x.min(-1).values
+            d = mx - mn
+            s_ = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
+            dd = torch.where(d > 0, d, torch.ones_like(d))
+            r, g, bl = x[..., 0], x[..., 1], x[..., 2]
+            h = torch.where(mx == r, (g - bl) / dd, torch.where(mx == g, 2 + (bl - r) / dd, 4 + (r - g) / dd))
+            h = (torch.where(d > 0, (h / 6) % 1.0, torch.zeros_like(h)) + hue) % 1.0
+            fi = torch.floor(h * 6); f = h * 6 - fi; i = fi.long() % 6
+            p_, q, t = (mx * (1 - s_)).clamp(0, 1), (mx * (1 - f * s_)).clamp(0, 1), (mx * (1 - (1 - f) * s_)).clamp(0, 1)
+            pick = lambda *a: torch.stack(a, -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
+            x = torch.stack([pick(mx, q, p_, p_, t, mx), pick(t, mx, mx, q, p_, p_), pick(p_, p_, t, mx, mx, q)], -1)
         return x * 2 - 1
 
-    def _add_bg(self, img):
-        """face_id.py:712-730: rescale by U[0.1,1]·aspect U[0.9,1.1], paste at a random offset on a -1 canvas"""
+    def _bg_geometry(self):
+        """the draws of face_id.py:719-727: rh = min(int(h U[0.1,1]), h), rw = min(int(rh U[0.9,1.1]), w), offsets randint"""
         S = self.size
-        sc = self.rng.uniform(0.1, 1.0)
-        h = max(8, min(S, int(S * sc)))
-        w = max(8, min(S, int(S * sc * self.rng.uniform(0.9, 1.1))))
-        small = F.interpolate(img.permute(2, 0, 1)[None], size=(h, w), mode="bilinear", align_corners=False)[0].permute(1, 2, 0)
-        canvas = torch.full((S, S, 3), -1.0)
-        y0, x0 = self.rng.randint(0, S - h), self.rng.randint(0, S - w)
-        canvas[y0:y0 + h, x0:x0 + w] = small
+        rh = max(1, min(int(S * self.rng.uniform(0.1, 1.0)), S))
+        rw = max(1, min(int(rh * self.rng.uniform(0.9, 1.1)), S))
+        pos_h = self.rng.randrange(S - rh) if S > rh else 0
+        pos_w = self.rng.randrange(S - rw) if S > rw else 0
+        return rh, rw, pos_h, pos_w
+
+    def _add_bg(self, img):
+        """face_id.py:712-730: bilinear (align_corners=True) rescale, paste at a random offset on a -1 canvas"""
+        rh, rw, y0, x0 = self._bg_geometry()
+        small = F.interpolate(img.permute(2, 0, 1)[None], size=(rh, rw), mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+        canvas = torch.full((self.size, self.size, 3), -1.0)
+        canvas[y0:y0 + rh, x0:x0 + rw] = small
         return canvas
+
+    def _jitter_params(self):
+        """flip, brightness, contrast, saturation, hue of ColorJitter((0.8,1.2),(0.8,1.2),(0.8,1.2),0.01) + RandomHorizontalFlip"""
+        r = self.rng
+        return [1.0 if r.random() < self.flip_p else 0.0, r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(-0.01, 0.01)]
 
     def __getitem__(self, i):
         ident = self.ids[i % len(self.ids)]
@@ -105,3 +126,35 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
 
 class FaceIdDatasetOneShot(FaceIdDatasetStyleGAN3):
     pass
+
+
+class DeviceAugmenter:
+    """Batch-level counterpart of `__getitem__` with the pixel work on the GPU: the base faces stay resident in HBM, the host
+    draws the per-sample parameters (the same distributions as the CPU path) and two native launches per augmentation produce
+    `image` (B,S,S,3), `image_ori.faces` (B,S,S,6) and the ids/captions of face_id.py:598-644."""
+
+    def __init__(self, dataset, device="cuda"):
+        from ... import lib as _lib
+        from ..modules.frozen import context_for
+        self.ds, self.dev, self._lib = dataset, torch.device(device), _lib
+        self.ctx = context_for(self.dev)
+        self.idents = list(dataset.ids)
+        self.base = torch.stack([dataset.faces[i] for i in self.idents]).to(self.dev).float().contiguous()     # (n_ids,S,S,3)
+
+    def batch(self, indices):
+        ds, L = self.ds, self._lib
+        B = len(indices)
+        which = [i % len(self.idents) for i in indices]
+        src = self.base[torch.tensor(which, device=self.dev)].contiguous()
+        p1 = torch.tensor([ds._jitter_params() for _ in range(B)], dtype=torch.float32, device=self.dev)
+        p3 = torch.tensor([ds._jitter_params() for _ in range(B)], dtype=torch.float32, device=self.dev)
+        img, img3 = L.face_augment(self.ctx, src, p1), L.face_augment(self.ctx, src, p3)
+        if ds.split == "train":
+            geom = torch.tensor([ds._bg_geometry() for _ in range(B)], dtype=torch.int32, device=self.dev)
+            image = L.paste_on_canvas(self.ctx, img, geom)
+        else:
+            image = img
+        ids = torch.tensor([[self.idents[w]] * 2 for w in which], dtype=torch.int64, device=self.dev)
+        caps = [ds.rng.choice(imagenet_templates_small).format(f"face of {ds.placeholder} person") for _ in range(B)]
+        return dict(image=image, caption=caps, id_idx=ids[:, 0].clone(), img_idx=torch.tensor(list(indices)),
+                    image_ori=dict(faces=torch.cat([img, img3], dim=-1).contiguous(), ids=ids, num_ids=torch.ones(B, dtype=torch.int64)))

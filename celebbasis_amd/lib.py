@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
-    "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
+    "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
@@ -120,6 +120,7 @@ _ARGTYPES = {
     "cb_trainer_step": [_P, _P, _F], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
     "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
     "cb_row_surgery_multi": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I],
+    "cb_face_augment": [_P, _P, _P, _P, _I, _I], "cb_paste_on_canvas": [_P, _P, _P, _P, _I, _I, _I],
     "cb_trainer_share_unet": [_P, _P], "cb_trainer_share_clip": [_P, _P],
     "cb_unet_ddim_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P],
     "cb_ddim_update": [_P, _P, _P, _P, _I, _I, _I, _I, _F, _F, _F, _F, _F, _P],
@@ -413,6 +414,22 @@ def ddim_update(ctx, x, eps, a_t, a_prev, sigma_t, sqrt_one_minus_at, scale=1.0,
                                 C.c_float(scale), C.c_float(a_t), C.c_float(a_prev), C.c_float(sigma_t), C.c_float(sqrt_one_minus_at),
                                 None if p0 is None else ptr(p0)))
     return x, p0
+
+
+def face_augment(ctx, faces, params):
+    """flip + colour jitter of HWC faces [B,S,S,3] in [-1,1]; params [B,5] = flip, brightness, contrast, saturation, hue (device)"""
+    B, S = faces.shape[0], faces.shape[1]
+    out = torch.empty_like(faces)
+    check(load().cb_face_augment(ctx.h, ptr(faces), ptr(params), ptr(out), B, S))
+    return out
+
+
+def paste_on_canvas(ctx, img, geom):
+    """`_add_bg`: rescale to (rh, rw) and paste at (pos_h, pos_w) on a -1 canvas; geom [B,4] int32 (device)"""
+    B, S, _, Cc = img.shape
+    out = torch.empty_like(img)
+    check(load().cb_paste_on_canvas(ctx.h, ptr(img), ptr(geom, torch.int32), ptr(out), B, S, Cc))
+    return out
 
 
 class Clip(_Handle):

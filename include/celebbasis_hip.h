@@ -130,6 +130,12 @@ int cb_q_sample(cb_ctx* ctx, const float* x0_nhwc, const float* eps_nchw, const 
 int cb_mse_loss(cb_ctx* ctx, const float* pred_nhwc, const float* target_nchw, float* loss, float* dpred, int B, int C,
                 int HW);                                                                              /* ddpm.py:294-307 */
 int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size); /* meta_net.py:253-260 */
+/* feeder augmentations on the device (face_id.py:526-532 `trans` after the resize; :712-730 `_add_bg`), HWC images in [-1,1]:
+ * params[B][5] = {flip, brightness, contrast, saturation, hue shift} (device floats, drawn by the host like the reference's
+ * transforms); geom[B][4] = {rh, rw, pos_h, pos_w} (device int32). The colour ops follow torchvision's tensor formulas in the
+ * fixed order b -> c -> s -> h. */
+int cb_face_augment(cb_ctx* ctx, const float* in, const float* params, float* out, int B, int S);
+int cb_paste_on_canvas(cb_ctx* ctx, const float* img, const int32_t* geom, float* out, int B, int S, int C);
 int cb_row_surgery(cb_ctx* ctx, const float* embedded, const float* z, const int64_t* tokens, float* out, int32_t* map,
                    int B, int T, int C, int reps, int64_t placeholder);                               /* helpers.py:13-41 */
 /* the two / three person prompts of embedding_manager.py:323-345, 363-391: placeholders = device int64 [B][nph] (negative =

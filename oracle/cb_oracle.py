@@ -566,6 +566,43 @@ def face_warp_resize(faces_hwc, out_size=112):
 
 
 # ----------------------------------------------------------------------------- CelebBasis head + manager hook
+def color_jitter_flip(img_hwc, flip, brightness, contrast, saturation, hue):
+    """face_id.py:526-532 `trans` after the resize on one HWC image in [-1,1]: RandomHorizontalFlip + ColorJitter + Normalize with
+    torchvision's tensor formulas (functional_tensor.adjust_brightness/contrast/saturation/hue) in the order b, c, s, h"""
+    x = (img_hwc + 1.0) * 0.5
+    if flip:
+        x = x.flip(1)
+    gray = lambda t: 0.2989 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]
+    x = (x * brightness).clamp(0, 1)
+    x = (contrast * x + (1.0 - contrast) * gray(x).mean()).clamp(0, 1)
+    x = (saturation * x + (1.0 - saturation) * gray(x).unsqueeze(-1)).clamp(0, 1)
+    if hue != 0.0:
+        r, g, b = x[..., 0], x[..., 1], x[..., 2]
+        mx, mn = x.max(dim=-1).values, x.min(dim=-1).values
+        d = mx - mn
+        sat = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
+        dd = torch.where(d > 0, d, torch.ones_like(d))
+        h = torch.where(mx == r, (g - b) / dd, torch.where(mx == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd))
+        h = torch.where(d > 0, (h / 6.0) % 1.0, torch.zeros_like(h))
+        h = (h + hue) % 1.0
+        h6 = h * 6.0
+        fi = torch.floor(h6); f = h6 - fi; i = fi.to(torch.int64) % 6
+        v = mx
+        p_ = (v * (1.0 - sat)).clamp(0, 1); q = (v * (1.0 - f * sat)).clamp(0, 1); t = (v * (1.0 - (1.0 - f) * sat)).clamp(0, 1)
+        sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5], -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
+        x = torch.stack([sel(v, q, p_, p_, t, v), sel(t, v, v, q, p_, p_), sel(p_, p_, t, v, v, q)], dim=-1)
+    return x * 2.0 - 1.0
+
+
+def add_bg(img_hwc, rh, rw, pos_h, pos_w):
+    """face_id.py:712-730 `_add_bg` with the random draws made explicit"""
+    S = img_hwc.shape[0]
+    small = F.interpolate(img_hwc.permute(2, 0, 1)[None], (rh, rw), mode="bilinear", align_corners=True)[0].permute(1, 2, 0)
+    out = torch.full_like(img_hwc, -1.0)
+    out[pos_h:pos_h + rh, pos_w:pos_w + rw] = small
+    return out
+
+
 def shift_rows(tokens_1d, embedded_2d, z_rows, placeholder, reps):
     """helpers.py:13-41 shift_tensor_dim0 + embedding_manager.py:347-360 (num_ids == 1 branch), restated with explicit index
     arithmetic: rows after each placeholder move right by reps-1, the tail is dropped, rows p..p+reps-1 take z."""

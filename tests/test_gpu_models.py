@@ -145,7 +145,7 @@ def trainer_cfg(lib, m):
     return c
 
 
-def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux):
+def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux, per_step=True):
     from oracle import cb_oracle as O
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
     W = O.init_weights(shapes, seed=seed)
@@ -169,21 +169,23 @@ def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux):
             close(tag + ".tap.coef", ctx.tap("coef"), aux["coef"].reshape(-1), 1e-4)
             close(tag + ".tap.clip.cond", ctx.tap("clip.last_hidden_state"), aux["cond"].reshape(-1), 1e-4)
             close(tag + ".tap.unet.out", ctx.tap("unet.out"), nhwc(aux["eps_hat"]), 2e-4)
-        close(tag + f".s{s}.loss", tr.get_state("loss"), loss_ref.reshape(1), 1e-4)
-        close(tag + f".s{s}.grad_weight", tr.get_state("mlp.grad_weight"), aux["gW"].reshape(-1), 1e-3)
-        close(tag + f".s{s}.grad_bias", tr.get_state("mlp.grad_bias"), aux["gb"].reshape(-1), 1e-3)
+        if per_step:
+            close(tag + f".s{s}.loss", tr.get_state("loss"), loss_ref.reshape(1), 1e-4)
+            close(tag + f".s{s}.grad_weight", tr.get_state("mlp.grad_weight"), aux["gW"].reshape(-1), 1e-3)
+            close(tag + f".s{s}.grad_bias", tr.get_state("mlp.grad_bias"), aux["gb"].reshape(-1), 1e-3)
     # end state. AdamW normalises the gradient, so compare the parameter DELTA, and the north_star's L2 bar on coefficients.
     W0 = W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"].reshape(-1)
     dW_hip = tr.get_state("mlp.weight") - W0
     dW_ref = st.Wm.reshape(-1) - W0
-    close(tag + ".mlp.weight_delta", dW_hip, dW_ref, 2e-2)
-    close(tag + ".mlp.weight", tr.get_state("mlp.weight"), st.Wm.reshape(-1), 1e-4)
-    close(tag + ".mlp.bias", tr.get_state("mlp.bias"), st.bm.reshape(-1), 1e-3)
+    if per_step:
+        close(tag + ".mlp.weight_delta", dW_hip, dW_ref, 2e-2)
+    close(tag + ".mlp.weight", tr.get_state("mlp.weight"), st.Wm.reshape(-1), 1e-4 if per_step else 1e-3)
+    close(tag + ".mlp.bias", tr.get_state("mlp.bias"), st.bm.reshape(-1), 1e-3 if per_step else 2e-2)
     coef_hip = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)
     l2 = (coef_hip - st.id_coef).norm(dim=1).max().item()
     REPORT[tag + ".id_coefficients.L2"] = l2
     assert l2 <= 1e-3, f"{tag}: coefficient L2 distance {l2:.3e} exceeds the north_star bar 1e-3"
-    close(tag + ".id_embeddings", tr.get_state("id_embeddings"), st.id_emb.reshape(-1), 1e-4)
+    close(tag + ".id_embeddings", tr.get_state("id_embeddings"), st.id_emb.reshape(-1), 1e-4 if per_step else 1e-3)
     assert int(tr.get_state("step").item()) == steps
     tr.close()
 
@@ -191,6 +193,15 @@ def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux):
 def test_train_step_mini_vs_oracle(cb):
     lib, ctx = cb
     run_steps(lib, ctx, MINI, B=2, steps=3, lr=1e-2, seed=1, check_aux=True)
+
+
+def test_train_40_steps_mini_coefficient_bar(cb):
+    """the north_star bar over a longer horizon: 40 optimiser steps (bs=2, replay stream) — coefficient dictionaries within
+    1e-3 L2 of the CPU oracle, MLP weights within 1e-3 of their scale (AdamW amplifies round-off in tiny gradients, so the
+    per-step gradient checks of the short runs are not repeated here)"""
+    lib, ctx = cb
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    run_steps(lib, ctx, MINI, B=2, steps=40, lr=5e-3, seed=7, check_aux=False, per_step=False)
 
 
 def test_train_step_mini_b1_vs_oracle(cb):

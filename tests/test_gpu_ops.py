@@ -358,3 +358,34 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
                                   1e-2, 0.9, 0.999, 1e-8, 1e-2))
     close("adamw.p", pd, p, 1e-5)
     assert int(step.item()) == 5
+
+
+def test_feeder_augmentations_vs_oracle(cb):
+    """cb_face_augment / cb_paste_on_canvas against the oracle's restatement of face_id.py:526-532 (torchvision tensor
+    formulas) and :712-730 (`_add_bg`), plus the batch-level DeviceAugmenter contract (layouts, dtypes, ranges)"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    g = torch.Generator().manual_seed(5)
+    B, S = 3, 96
+    low = torch.rand(B, 3, 12, 12, generator=g) * 2 - 1
+    faces = torch.nn.functional.interpolate(low, size=S, mode="bilinear", align_corners=True).permute(0, 2, 3, 1).contiguous()
+    params = torch.tensor([[1.0, 1.13, 0.87, 1.19, 0.009], [0.0, 0.81, 1.2, 0.8, -0.01], [1.0, 1.0, 1.0, 1.0, 0.0]])
+    out = lib.face_augment(ctx, dv(faces), dv(params))
+    ctx.sync()
+    ref = torch.stack([O.color_jitter_flip(faces[b], bool(params[b, 0]), *[float(v) for v in params[b, 1:]]) for b in range(B)])
+    close("feeder.jitter", out, ref, 2e-5)
+    assert torch.equal(out[2].cpu(), faces[2].flip(1)) or (out[2].cpu() - faces[2].flip(1)).abs().max() < 1e-6   # identity jitter = flip only
+    geom = torch.tensor([[40, 43, 10, 7], [96, 96, 0, 0], [1, 1, 95, 95]], dtype=torch.int32)
+    pasted = lib.paste_on_canvas(ctx, out, geom.to(_dev()))
+    ctx.sync()
+    refp = torch.stack([O.add_bg(ref[b], *[int(v) for v in geom[b]]) for b in range(B)])
+    close("feeder.add_bg", pasted, refp, 2e-5)
+    # batch-level feeder
+    from celebbasis_amd.ldm.data.face_id import DeviceAugmenter, FaceIdDatasetOneShot
+    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=2, size=64, seed=3)
+    b = DeviceAugmenter(ds, _dev()).batch([0, 1, 2])
+    ctx.sync()
+    assert tuple(b["image"].shape) == (3, 64, 64, 3) and tuple(b["image_ori"]["faces"].shape) == (3, 64, 64, 6)
+    assert b["image_ori"]["ids"].dtype == torch.int64 and b["image_ori"]["ids"].tolist() == [[1, 1], [2, 2], [1, 1]]
+    assert float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0 and torch.isfinite(b["image_ori"]["faces"]).all()
+    assert all("sks" in c for c in b["caption"])
