@@ -146,7 +146,7 @@ size_t gn_ws_floats(int N, int HW, int C, int G);
 void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
                      float* stats, float* ws, int N, int HW, int C, int G, float eps, int silu);
 void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
-                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta);
+                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta, bool chn_valid = false);
 // LayerNorm over last dim C; stats = [rows][2]
 void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
                      float* stats, long rows, int C, float eps);

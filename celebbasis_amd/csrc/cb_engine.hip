@@ -329,7 +329,7 @@ Ten* Graph::groupnorm(Ten* x, const Norm& nm, bool silu) {
         tape.push_back([this, x, y, nc, stats, ws, N, HW, C, silu]() {
             if (!y->ginit) return;
             float beta; float* gx = grad(x, &beta);
-            k_groupnorm_bwd(L, gx, x->p, y->g, nc.g, nc.b, stats, ws, N, HW, C, 32, silu ? 1 : 0, beta);
+            k_groupnorm_bwd(L, gx, x->p, y->g, nc.g, nc.b, stats, ws, N, HW, C, 32, silu ? 1 : 0, beta, /*chn_valid=*/true);
         });
     }
     return y;

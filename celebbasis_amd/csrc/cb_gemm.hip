@@ -694,6 +694,9 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     // the event pair brackets the GEMM kernel alone, so a variant's average matches the rocprofv3 per-symbol average;
     // the split-K reduce is its own (HBM-bound) record: split partial reads + one output write (+ residual/accumulate read)
     if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
+    // The partials are combined by a separate, chip-wide kernel. A fused "last block to arrive sums its tile" variant was
+    // built and measured (profiles/README.md, runs 23/24): correct, but 46 -> 78-87 ms per step — agent-scope visibility needs
+    // either whole-L2 write-back/invalidate fences or L2-bypassing sc1 accesses, and the fix-up serialises on one CU per tile.
     if (pl.splitk > 1) {
         long total = (long)a.M * a.N * a.batch;
         unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);

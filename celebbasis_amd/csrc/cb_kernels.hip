@@ -494,16 +494,17 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ d
     }
 }
 void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
-                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta) {
+                     const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta, bool chn_valid) {
     CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm bwd: C=%d G=%d unsupported", C, G);
     int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
     float* part = ws;
     float* chn = ws + (size_t)N * nchunk * G * 2;
     float* gs = chn + (size_t)N * C * 4;
-    (void)L.count(4);
+    (void)L.count(chn_valid ? 3 : 4);
     if (L.dry) return;
     ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? "groupnorm_silu_bwd" : "groupnorm_bwd", 0.0, 5.0 * N * HW * (double)C * 4, L.stream);
-    hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
+    // chn_valid: `ws` is the forward call's workspace and still holds its per-channel constants (the tape's case)
+    if (!chn_valid) hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, dy, chn, HW, C, G,
                        nchunk, rpb, silu);
     hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
