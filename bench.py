@@ -39,11 +39,15 @@ def pmc_traffic(kernel):
     files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.json")))
     if not files:
         return None, None
+    kinds = {"ROW": 0, "COL": 1, "CONV": 2, "CONVF": 3}
     m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+),(\w+)(,generic)?>", kernel)
-    if not m:
+    m4 = re.match(r"gemm_kernel_occ4<(\w+),(\w+)>", kernel)
+    if m:
+        sym = f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
+    elif m4:
+        sym = f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"
+    else:
         return None, None
-    kinds = {"ROW": 0, "COL": 1, "CONV": 2}
-    sym = f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
     d = json.load(open(files[-1]))
     e = d.get("per_symbol", {}).get(sym)
     if not e or e["fetch_bytes_per_launch"] is None or e["write_bytes_per_launch"] is None:

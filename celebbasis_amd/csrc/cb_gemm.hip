@@ -561,6 +561,11 @@ __global__ void splitk_reduce_kernel(const KArgs p) {
 // ---------------------------------------------------------------- host side
 struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
 
+// fixed cost of the extra (reduce) launch in the planner's units (1e6 ~ 3.7 us of one CU's MFMA time); CB_SPLITK_COST overrides
+static double splitk_launch_cost() {
+    static const double c = [] { const char* e = getenv("CB_SPLITK_COST"); return e ? atof(e) : 1.0e6; }();
+    return c;
+}
 static Plan make_plan(const GemmArgs& a) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
@@ -585,7 +590,7 @@ static Plan make_plan(const GemmArgs& a) {
             if (blocks <= 1024) waves = (double)cdiv((long)blocks, 256);
             double tcost = waves * (double)BM * BN * kps / eff[t];
             // split-K traffic: partial writes + reduce reads/writes ~ (2*split+1)*M*N*4 B at ~3 TB/s, plus one more launch
-            if (split > 1) tcost += 1.0e6 + 0.41 * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
+            if (split > 1) tcost += splitk_launch_cost() + 0.41 * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
             if (tcost < best) { best = tcost; pl = Plan{BM, BN, (int)tm, (int)tn, split, kps}; }
         }
     }
@@ -599,7 +604,7 @@ size_t gemm_ws_bytes(const GemmArgs& a) {
 }
 
 template <int AK, int BKIND, bool VEC>
-static void launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+static bool launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     // 128x128 tile: 152 registers -> 3 blocks per CU (768 slots); the register-capped twin holds 4 (1024 slots). Measured on
     // MI355X (profiles/README.md, run 21): the twin wins when the launch then needs fewer rounds of blocks (1024 blocks +7 %,
     // 2048 blocks +12 %) and loses ~1 % otherwise; the variants that spill under the cap (general conv gather, ROW x COL) never use it.
@@ -610,17 +615,18 @@ static void launch_tiles2(const Plan& pl, dim3 grid, hipStream_t s, const KArgs&
             const long blocks = (long)grid.x * grid.y * grid.z;
             const long r4 = (blocks + 1023) / 1024 * 4, r3 = (blocks + 767) / 768 * 3;
             const bool use4 = occ4_env >= 0 ? occ4_env == 1 : (blocks >= 1024 && r4 < r3);
-            if (use4) { hipLaunchKernelGGL((gemm_kernel_occ4<AK, BKIND>), grid, dim3(256), 0, s, ka); return; }
+            if (use4) { hipLaunchKernelGGL((gemm_kernel_occ4<AK, BKIND>), grid, dim3(256), 0, s, ka); return true; }
         }
         hipLaunchKernelGGL((gemm_kernel<128, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     }
     else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_kernel<128, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_kernel<64, 128, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
     else hipLaunchKernelGGL((gemm_kernel<64, 64, AK, BKIND, VEC>), grid, dim3(256), 0, s, ka);
+    return false;
 }
 template <int AK, int BKIND>
-static void launch_tiles(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka, bool vec) {
-    if (vec) launch_tiles2<AK, BKIND, true>(pl, grid, s, ka); else launch_tiles2<AK, BKIND, false>(pl, grid, s, ka);
+static bool launch_tiles(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka, bool vec) {
+    return vec ? launch_tiles2<AK, BKIND, true>(pl, grid, s, ka) : launch_tiles2<AK, BKIND, false>(pl, grid, s, ka);
 }
 
 void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
@@ -668,11 +674,8 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     if (a.b_kind == LD_COL) vec = vec && (a.N % 4 == 0); else vec = vec && (a.K % 4 == 0);
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     ProfRec rec; bool prof = L.prof && L.prof->on;
+    const bool convf = a.a_kind == LD_CONV && vec && !a.g.up && !a.g.tr && (a.g.C % BK == 0);
     if (prof) {
-        static const char* kn[3] = {"ROW", "COL", "CONV"};
-        char nm[96];
-        snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s%s>", pl.BM, pl.BN, kn[a.a_kind], kn[a.b_kind], vec ? "" : ",generic");
-        rec.variant = L.prof->id_of(nm);
         rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
         // algorithmic HBM bytes: each operand once + the output once (conv A = the input image, not its im2col expansion)
         double ea_ = a.a_kind == LD_CONV ? (double)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (double)a.M * a.K * a.batch;
@@ -681,19 +684,28 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
         CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
-    if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka, vec);
+    bool occ4 = false;
+    if (a.a_kind == LD_ROW && a.b_kind == LD_ROW) occ4 = launch_tiles<LD_ROW, LD_ROW>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_ROW && a.b_kind == LD_COL) launch_tiles<LD_ROW, LD_COL>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_COL && a.b_kind == LD_COL) launch_tiles<LD_COL, LD_COL>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_COL && a.b_kind == LD_ROW) launch_tiles<LD_COL, LD_ROW>(pl, grid, L.stream, ka, vec);
     else if (a.a_kind == LD_CONV) {
-        if (vec && !a.g.up && !a.g.tr && (a.g.C % BK == 0)) launch_tiles2<LD_CONVF, LD_ROW, true>(pl, grid, L.stream, ka);
+        if (convf) occ4 = launch_tiles2<LD_CONVF, LD_ROW, true>(pl, grid, L.stream, ka);
         else launch_tiles<LD_CONV, LD_ROW>(pl, grid, L.stream, ka, vec);
     }
     else fail(CB_ERR_ARG, "gemm: unsupported operand kinds %d/%d", a.a_kind, a.b_kind);
     CB_HIP(hipGetLastError());
-    // the event pair brackets the GEMM kernel alone, so a variant's average matches the rocprofv3 per-symbol average;
-    // the split-K reduce is its own (HBM-bound) record: split partial reads + one output write (+ residual/accumulate read)
-    if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
+    // the event pair brackets the GEMM kernel alone and the record is named after the symbol that ran, so a variant's average
+    // matches the rocprofv3 per-symbol average; the split-K reduce is its own (HBM-bound) record
+    if (prof) {
+        static const char* kn[4] = {"ROW", "COL", "CONV", "CONVF"};
+        char nm[96];
+        const char* ak = kn[convf ? 3 : a.a_kind];
+        if (occ4) snprintf(nm, sizeof nm, "gemm_kernel_occ4<%s,%s>", ak, kn[a.b_kind]);
+        else snprintf(nm, sizeof nm, "gemm_kernel<%d,%d,%s,%s%s>", pl.BM, pl.BN, ak, kn[a.b_kind], vec ? "" : ",generic");
+        rec.variant = L.prof->id_of(nm);
+        CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
+    }
     // The partials are combined by a separate, chip-wide kernel. A fused "last block to arrive sums its tile" variant was
     // built and measured (profiles/README.md, runs 23/24): correct, but 46 -> 78-87 ms per step — agent-scope visibility needs
     // either whole-L2 write-back/invalidate fences or L2-bypassing sc1 accesses, and the fix-up serialises on one CU per tile.

@@ -23,6 +23,7 @@ def load(d, counter):
             if r["Counter_Name"] != counter:
                 continue
             n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cb::", "").replace("cb::", "")
+            n = n.replace("(cb::_anonymous_namespace_)::", "")
             if not ("gemm_kernel" in n or "flash" in n or n.startswith("gn_") or "layernorm" in n or "splitk" in n):
                 continue
             key = (n, int(r["Grid_Size"]))
