@@ -321,6 +321,29 @@ int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* o
     k_resize_bilinear_ac(L, out, warped, nface * B, S, S, out_size, out_size, 3);
     CB_END
 }
+// meta_net.py:262-289 after the FR backbone: F.normalize(v) -> EqualLinear + LeakyReLU(0.2) -> 'b (e h d) -> b e h d' ->
+// L2-normalise over d -> einsum with the celeb basis + mean. feat [N,I] (raw FR features), W [es*K, I], b [es*K],
+// basis [es, 1+K, Wd] -> coef [N, es*K] (unit rows per e), z [N, es*Wd]. The inference-time `test_mode: image` path.
+int cb_celeb_head_forward(cb_ctx* ctx, const float* feat, const float* W, const float* b, const float* basis, int N, int I, int es,
+                          int K, int Wd, float* coef, float* z) {
+    CB_TRY
+    require(ctx, "ctx"); require(feat, "feat"); require(W, "W"); require(b, "b"); require(basis, "basis"); require(coef, "coef");
+    require(z, "z");
+    Ctx* c = &ctx->c;
+    plan_and_run(c, [&]() {
+        Graph G(c);
+        const int O = es * K;
+        Ten* v = G.make(N, 1, 1, I);
+        k_l2norm_fwd(G.L, v->p, nullptr, feat, N, I);
+        Lin head; head.w = const_cast<float*>(W); head.b = const_cast<float*>(b); head.in = I; head.out = O;
+        Ten* pre = G.linear(v, head);
+        Ten* act = G.make(N, 1, 1, O);
+        k_leakyrelu_fwd(G.L, act->p, pre->p, act->numel(), 0.2f);
+        k_l2norm_fwd(G.L, coef, nullptr, act->p, (long)N * es, K);
+        k_basis_fwd(G.L, z, coef, basis, N, es, K, Wd);
+    });
+    CB_END
+}
 int cb_face_augment(cb_ctx* ctx, const float* in, const float* params, float* out, int B, int S) {
     CB_TRY
     require(ctx, "ctx"); require(in, "in"); require(params, "params"); require(out, "out");

@@ -125,6 +125,24 @@ class EmbeddingManagerId:
         self._keep = (coef, z)
         return z
 
+    def _embedding_from_faces(self, faces, basis, dev):
+        """`test_mode: image` (embedding_manager.py:296-300 with faces given): FR-net + MLP head on every face chunk of
+        `faces` (B,S,S,3k) -> z (k, B, es*h, W), the k-th entry belonging to the k-th person of the prompt"""
+        L, ctx = _lib.load(), context_for(dev)
+        B, S, _, c3 = faces.shape
+        k = c3 // 3
+        es, K, W = self.num_es, self.inner_dim, self.token_dim
+        fr = self.meta_id_net.id_model.native(dev)
+        f = faces.to(dev).float().contiguous()
+        warped = torch.empty(k * B, S, S, 3, device=dev); small = torch.empty(k * B, fr.in_size, fr.in_size, 3, device=dev)
+        _lib.check(L.cb_face_warp_resize(ctx.h, _lib.ptr(f), _lib.ptr(warped), _lib.ptr(small), B, S, k, fr.in_size))
+        feat = fr.forward(small)
+        Wm, bm = self.meta_id_net.weight.to(dev).float().contiguous(), self.meta_id_net.bias.to(dev).float().contiguous()
+        coef = torch.empty(k * B, es * K, device=dev); z = torch.empty(k * B, es * W, device=dev)
+        _lib.check(L.cb_celeb_head_forward(ctx.h, _lib.ptr(feat), _lib.ptr(Wm), _lib.ptr(bm), _lib.ptr(basis), k * B, feat.shape[1], es, K, W,
+                                           _lib.ptr(coef), _lib.ptr(z)))
+        return z.reshape(k, B, es * self.meta_heads, W)
+
     def forward(self, tokenized_text, embedded_text, face_image=None, img_ori=None, celeb_embeddings=None):
         if img_ori is None:
             return embedded_text
@@ -145,13 +163,18 @@ class EmbeddingManagerId:
             raise ValueError(f"num_ids={nph} needs that many placeholder_strings (have {self.placeholder_strings}); 1..3 are supported")
         z = torch.zeros(B, nph * reps, W, device=dev)
         ph = torch.full((B, nph), -1, dtype=torch.int64)
+        from_faces = None
+        if self.test_mode == "image" and img_ori.get("faces") is not None:
+            from_faces = self._embedding_from_faces(img_ori["faces"], basis, dev)
+            if from_faces.shape[0] < nph:
+                raise ValueError(f"{nph} persons in the prompt but only {from_faces.shape[0]} face images were given")
         for b in range(B):
             for k in range(counts[b]):
                 tok = self.string_to_token_dict[self.placeholder_strings[k]]
                 if tok is None:
                     raise RuntimeError(f"the BPE id of placeholder '{self.placeholder_strings[k]}' is unknown offline")
                 ph[b, k] = tok
-                z[b, k * reps:(k + 1) * reps] = self._predicted_embedding(int(ids[b][k]), basis, dev)
+                z[b, k * reps:(k + 1) * reps] = from_faces[k, b] if from_faces is not None else self._predicted_embedding(int(ids[b][k]), basis, dev)
         ph = ph.to(dev)
         out = torch.empty_like(embedded_text)
         mp = torch.empty(B * T, dtype=torch.int32, device=dev)

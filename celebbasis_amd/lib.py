@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
-    "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
+    "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
@@ -120,6 +120,7 @@ _ARGTYPES = {
     "cb_trainer_step": [_P, _P, _F], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
     "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
     "cb_row_surgery_multi": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I],
+    "cb_celeb_head_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cb_face_augment": [_P, _P, _P, _P, _I, _I], "cb_paste_on_canvas": [_P, _P, _P, _P, _I, _I, _I],
     "cb_trainer_share_unet": [_P, _P], "cb_trainer_share_clip": [_P, _P],
     "cb_unet_ddim_sample": [_P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P, _P, _P, _P, _F, _P, _P],

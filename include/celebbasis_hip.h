@@ -130,6 +130,11 @@ int cb_q_sample(cb_ctx* ctx, const float* x0_nhwc, const float* eps_nchw, const 
 int cb_mse_loss(cb_ctx* ctx, const float* pred_nhwc, const float* target_nchw, float* loss, float* dpred, int B, int C,
                 int HW);                                                                              /* ddpm.py:294-307 */
 int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size); /* meta_net.py:253-260 */
+/* MetaIdNet head after the FR backbone (meta_net.py:262-289): normalize -> EqualLinear+LeakyReLU(0.2) -> per-(e) L2 norm ->
+ * celeb-basis contraction. feat [N,I], W [es*K,I], b [es*K], basis [es,1+K,Wd] -> coef [N,es*K], z [N,es*Wd]. Forward only: the
+ * training-time head (with its backward and AdamW) lives inside cb_trainer_step; this entry serves `test_mode: image`. */
+int cb_celeb_head_forward(cb_ctx* ctx, const float* feat, const float* W, const float* b, const float* basis, int N, int I, int es,
+                          int K, int Wd, float* coef, float* z);
 /* feeder augmentations on the device (face_id.py:526-532 `trans` after the resize; :712-730 `_add_bg`), HWC images in [-1,1]:
  * params[B][5] = {flip, brightness, contrast, saturation, hue shift} (device floats, drawn by the host like the reference's
  * transforms); geom[B][4] = {rh, rw, pos_h, pos_w} (device int32). The colour ops follow torchvision's tensor formulas in the

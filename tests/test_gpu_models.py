@@ -435,3 +435,47 @@ def test_txt2img_script_mini(cb, tmp_path):
     assert Image.open(out / "samples" / "00000.jpg").size == (64, 64)
     grids = [f for f in os.listdir(out) if f.endswith(".jpg")]
     assert len(grids) == 2 and Image.open(out / grids[0]).size == (128, 64)
+
+
+def test_manager_image_mode_mini_vs_oracle(cb):
+    """eval-mode EmbeddingManagerId with `test_mode: image` (embedding_manager.py:296-300): faces -> warp/resize -> FR-net ->
+    MLP head -> basis -> row surgery, all native, against the oracle composition; two persons in one prompt"""
+    from celebbasis_amd.ldm.modules.embedding_manager import EmbeddingManagerId
+    from celebbasis_amd.ldm.modules.id_embedding.iresnet import IResNet
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    fr = MINI["fr"]; es, K, Wd = MINI["es"], MINI["inner"], MINI["clip"]["width"]
+
+    class Embedder:                    # the two things the manager asks of the CLIP wrapper
+        cfg = dict(width=Wd)
+
+        def tokenize(self, s):
+            ids = torch.full((1, 77), 49407, dtype=torch.int64); ids[0, 0] = 49406
+            ids[0, 1] = {"sks": 99, "ks": 98}[s]
+            return ids
+
+    em = EmbeddingManagerId(Embedder(), placeholder_strings=["sks", "ks"], max_ids=3, num_embeds_per_token=es, meta_mlp_depth=1,
+                            loss_type="none", meta_inner_dim=K, test_mode="image", save_fp16=False).eval()
+    Wfr = O.init_weights(O.frnet_param_shapes(fr), seed=31)
+    em.meta_id_net.id_model = IResNet(fr["layers"], fr["feat"], fr["width"], fr["in_size"])
+    em.meta_id_net.id_model.load_state_dict(Wfr)
+    g = torch.Generator().manual_seed(32)
+    em.meta_id_net.weight = torch.randn(es * K, 512, generator=g); em.meta_id_net.bias = torch.randn(es * K, generator=g) * 0.1
+    basis = torch.randn(es, 1 + K, Wd, generator=g) * 0.05
+    B, S = 2, 64
+    faces = torch.rand(B, S, S, 6, generator=g) * 2 - 1
+    tokens = torch.randint(0, 90, (B, 77), generator=g)
+    tokens[0, 4] = 99; tokens[0, 9] = 98; tokens[1, 2] = 98; tokens[1, 30] = 99
+    emb = torch.randn(B, 77, Wd, generator=g)
+    ori = dict(faces=faces, ids=torch.tensor([[1, 2], [2, 1]]), num_ids=torch.tensor([2, 2]))
+    out = em(dv(tokens), dv(emb), None, ori, dv(basis))
+    ctx.sync()
+    Wh = {"embedding_manager.meta_id_net.stylegan_mlp.net.0.weight": em.meta_id_net.weight,
+          "embedding_manager.meta_id_net.stylegan_mlp.net.0.bias": em.meta_id_net.bias, "celeb_embeddings": basis}
+    with torch.no_grad():
+        stack = torch.cat([faces[..., :3], faces[..., 3:]], 0)                           # chunk(num, -1) -> cat(0), meta_net.py:337-338
+        _, small = O.face_warp_resize(stack, fr["in_size"])
+        v = torch.nn.functional.normalize(O.frnet_forward(Wfr, fr, small), dim=-1, p=2)
+        _, z = O.celeb_head(Wh, v, es, K)                                                # [2B, es, Wd]
+        ref = torch.stack([O.shift_rows_multi(tokens[b], emb[b], [z[b], z[B + b]], [99, 98], es) for b in range(B)])
+    close("manager.image_mode", out, ref, 2e-4)

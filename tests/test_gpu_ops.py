@@ -389,3 +389,24 @@ def test_feeder_augmentations_vs_oracle(cb):
     assert b["image_ori"]["ids"].dtype == torch.int64 and b["image_ori"]["ids"].tolist() == [[1, 1], [2, 2], [1, 1]]
     assert float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0 and torch.isfinite(b["image_ori"]["faces"]).all()
     assert all("sks" in c for c in b["caption"])
+
+
+def test_celeb_head_forward_vs_oracle(cb):
+    """cb_celeb_head_forward (the `test_mode: image` head, meta_net.py:262-289) against the oracle's restatement"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    L = lib.load()
+    g = torch.Generator().manual_seed(11)
+    N, I, es, K, Wd = 3, 512, 2, 512, 768
+    feat = torch.randn(N, I, generator=g) * 3.0
+    W = {"embedding_manager.meta_id_net.stylegan_mlp.net.0.weight": torch.randn(es * K, I, generator=g),
+         "embedding_manager.meta_id_net.stylegan_mlp.net.0.bias": torch.randn(es * K, generator=g) * 0.1,
+         "celeb_embeddings": torch.randn(es, 1 + K, Wd, generator=g) * 0.05}
+    coef = torch.empty(N, es * K, device=_dev()); z = torch.empty(N, es * Wd, device=_dev())
+    lib.check(L.cb_celeb_head_forward(ctx.h, lib.ptr(dv(feat)), lib.ptr(dv(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"])),
+                                      lib.ptr(dv(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"])), lib.ptr(dv(W["celeb_embeddings"])),
+                                      N, I, es, K, Wd, lib.ptr(coef), lib.ptr(z)))
+    ctx.sync()
+    cref, zref = O.celeb_head(W, torch.nn.functional.normalize(feat, dim=-1, p=2), es, K)
+    close("celeb_head.coef", coef.reshape(N, es, K), cref, 2e-5)
+    close("celeb_head.z", z.reshape(N, es, Wd), zref, 2e-5)
