@@ -561,17 +561,33 @@ __global__ void splitk_reduce_kernel(const KArgs p) {
 // ---------------------------------------------------------------- host side
 struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
 
-// fixed cost of the extra (reduce) launch in the planner's units (1e6 ~ 3.7 us of one CU's MFMA time); CB_SPLITK_COST overrides
-static double splitk_launch_cost() {
-    static const double c = [] { const char* e = getenv("CB_SPLITK_COST"); return e ? atof(e) : 1.0e6; }();
-    return c;
+// Planner constants (unit = one MAC on one CU at the fp32 MFMA rate), each overridable from the environment for sweeps on the
+// GPU box (profiles/README.md, runs 26-29):
+//   CB_SPLITK_COST     fixed cost of the extra reduce launch            (0.25e6 ~ 1 us; 1e6 was 1.2 % slower per step)
+//   CB_PLAN_TRAFFIC    cost per (2*split+1) partial element moved
+//   CB_PLAN_BLOCK_OVH  per-block prologue/epilogue, in k-tiles
+//   CB_PLAN_MINK       fewest k-tiles a split may get
+//   CB_PLAN_EFF        relative MFMA efficiency of the 128x128,128x64,64x128,64x64 tiles
+struct PlanKnobs { double splitk_cost, traffic, block_ovh; int mink; double eff[4]; };
+static const PlanKnobs& plan_knobs() {
+    static const PlanKnobs k = [] {
+        PlanKnobs k{0.25e6, 0.41, 0.0, 4, {1.0, 0.80, 0.80, 0.58}};
+        if (const char* e = getenv("CB_SPLITK_COST")) k.splitk_cost = atof(e);
+        if (const char* e = getenv("CB_PLAN_TRAFFIC")) k.traffic = atof(e);
+        if (const char* e = getenv("CB_PLAN_BLOCK_OVH")) k.block_ovh = atof(e);
+        if (const char* e = getenv("CB_PLAN_MINK")) k.mink = atoi(e) > 0 ? atoi(e) : 1;
+        if (const char* e = getenv("CB_PLAN_EFF")) sscanf(e, "%lf,%lf,%lf,%lf", &k.eff[0], &k.eff[1], &k.eff[2], &k.eff[3]);
+        return k;
+    }();
+    return k;
 }
 static Plan make_plan(const GemmArgs& a) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
     // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
     static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    static const double eff[4] = {1.0, 0.80, 0.80, 0.58};
+    const PlanKnobs& kn = plan_knobs();
+    const double* eff = kn.eff;
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const int ksteps = cdiv(a.K, BK);
     double best = 1e300;
@@ -582,15 +598,15 @@ static Plan make_plan(const GemmArgs& a) {
         if (BN == 128 && a.N <= 64) continue;
         const long tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
         for (int sp : splits) {
-            if (sp > 1 && ksteps / sp < 4) break;            // keep >= 4 k-tiles (64 k) per split
+            if (sp > 1 && ksteps / sp < kn.mink) break;      // keep >= mink k-tiles per split
             int kps = cdiv(ksteps, sp) * BK;
             int split = cdiv(a.K, kps);
             double blocks = (double)tm * tn * a.batch * split;
             double waves = blocks / 256.0;
             if (blocks <= 1024) waves = (double)cdiv((long)blocks, 256);
-            double tcost = waves * (double)BM * BN * kps / eff[t];
+            double tcost = waves * (double)BM * BN * (kps + kn.block_ovh * BK) / eff[t];
             // split-K traffic: partial writes + reduce reads/writes ~ (2*split+1)*M*N*4 B at ~3 TB/s, plus one more launch
-            if (split > 1) tcost += splitk_launch_cost() + 0.41 * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
+            if (split > 1) tcost += kn.splitk_cost + kn.traffic * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
             if (tcost < best) { best = tcost; pl = Plan{BM, BN, (int)tm, (int)tn, split, kps}; }
         }
     }
