@@ -8,15 +8,19 @@
 //   C[M,N] = alpha * A[M,K] . B[K,N] + bias[n] + rowbias[img(m)][n] + R[m][n] + beta * C[m][n]
 //
 // Design (CDNA4): 256 threads = 4 wave64 in a 2x2 arrangement; each wave owns a (BM/2)x(BN/2)
-// sub-tile made of 32x32 fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF chip peak).
-// Operand tiles are staged through LDS *k-major* ([BK][BM+4]) so that the MFMA fragment read
-// (lane l -> A[m=l&31][k=l>>5]) is a conflict-free ds_read_b32 of 32 consecutive floats per half-wave,
-// and so that a transposed operand (M-contiguous in memory) needs no shuffle at all.
-// Global->register prefetch of tile t+1 is issued before the MFMA block of tile t (one barrier per
-// k-tile, double-buffered LDS). Split-K (partials in a workspace + a fused reduce/epilogue kernel)
-// fills the 256 CUs for the small-M / deep-K layers (8x8 and 16x16 UNet levels, CLIP, attention bwd).
-// blockIdx -> tile mapping is XCD-aware (bijective remap) so that tiles sharing an A row-panel
-// land on the same XCD L2.
+// sub-tile made of 32x32 fp32 MFMA tiles (v_mfma_f32_32x32x2_f32: exact fp32, 157 TF chip peak); BK = 16.
+// LDS staging depends on how the operand lies in memory:
+//  * k-contiguous (activations, conv gathers, [out][in] weights; the 16-byte-load kernels): [row][16 k], the four 16-byte
+//    chunks of a row XOR-swizzled by (row >> 2) & 3. One conflict-free ds_write_b128 per global 16-byte load; a lane's
+//    fragments for all 8 MFMA k-steps of the tile are two conflict-free ds_read_b128 at loop-invariant addresses. MFMA
+//    step s contracts the k-pair (s, s + 8) — any pairing is a valid contraction as long as A and B agree.
+//  * m-contiguous (transposed operands) and the scalar fallback loaders: k-major [BK][BM+4]; the fragment read
+//    (lane l -> A[m = l & 31][k = s + 8 * (l >> 5)]) is a conflict-free ds_read_b32 per half-wave, no shuffle needed.
+// Global->register prefetch of tile t+1 is issued before the MFMA block of tile t (one barrier per k-tile,
+// double-buffered LDS). Split-K (partials in a workspace + a chip-wide reduce/epilogue kernel) fills the 256 CUs for the
+// small-M / deep-K layers (8x8 and 16x16 UNet levels, CLIP, attention bwd). blockIdx -> tile mapping is XCD-aware
+// (bijective remap) so that tiles sharing an A row-panel land on the same XCD L2. Measurements behind these choices:
+// profiles/r01_pmc_conv.md (PMC) and profiles/README.md (per-step history, rejected experiments).
 #include "cb_common.h"
 #include <cstdarg>
 
