@@ -769,6 +769,17 @@ int cb_trainer_step(cb_trainer* t, const cb_batch* b, float lr) {
     CB_END
 }
 
+int cb_trainer_prefetch(cb_trainer* t, const cb_batch* b) {
+    CB_TRY
+    require(t, "trainer"); require(b, "batch");
+    if (!t->ctx->dry) { require(b->image, "batch.image"); require(b->faces, "batch.faces"); require(b->post_noise, "batch.post_noise"); }
+    Batch bt;
+    bt.image = b->image; bt.faces = b->faces; bt.ids = b->ids; bt.tokens = b->tokens; bt.t = b->t; bt.noise = b->noise;
+    bt.post_noise = b->post_noise; bt.B = b->B;
+    trainer_prefetch(&t->T, bt);
+    CB_END
+}
+
 struct StateRef { void* p; long n; bool is_int; };
 static StateRef find_state(cb_trainer* t, const char* name) {
     Trainer& T = t->T;

@@ -116,6 +116,22 @@ struct Trainer {
     float* sqrt_ac = nullptr; float* sqrt_1mac = nullptr;
     float* loss = nullptr;                        // device scalar
     size_t arena_need = 0; int arena_B = 0;
+    // ---- optional first-stage prefetch (trainer_prefetch): the frozen, gradient-free stages of the NEXT batch (VAE encode ->
+    // z0, FR backbone -> features) run on their own stream and arena while the current step's UNet is in flight
+    struct Prefetch {
+        hipStream_t stream = nullptr; hipEvent_t ready = nullptr;
+        Arena arena; size_t need = 0; int planned_B = 0;
+        // two result slots: prefetch(n+1) is enqueued before step(n) consumes slot n
+        struct Slot { float* z0 = nullptr; float* feat = nullptr; hipEvent_t done = nullptr;
+                      const void *image = nullptr, *faces = nullptr, *post_noise = nullptr; int B = 0; bool valid = false; } slot[2];
+        int next = 0;
+        ~Prefetch() {
+            if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+            if (ready) (void)hipEventDestroy(ready);
+            for (auto& sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
+            if (arena.base) (void)hipFree(arena.base);
+        }
+    } pf;
 };
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T);
 struct Batch {
@@ -129,5 +145,8 @@ struct Batch {
     int B = 1;
 };
 void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only);
+// Enqueue the first stage of `next` (image -> z0, faces -> FR features) on the prefetch stream. A following trainer_step on the
+// same buffers consumes the results instead of recomputing them; any other batch recomputes inline. Results are identical.
+void trainer_prefetch(Trainer* T, const Batch& next);
 
 }  // namespace cb

@@ -474,6 +474,79 @@ struct Phase {
     ~Phase() { if (on) L.prof->end(&rec, L.stream); }
 };
 
+// first stage, part A: warp + resize + iresnet on both face chunks (meta_net.py:250-262), no grad -> raw features [2B, 512]
+static Ten* first_stage_faces(Graph& G, Trainer* T, const Batch& bt) {
+    const TrainerCfg& c = T->cfg;
+    const int NF = 2 * bt.B, S_ = c.image_size;
+    Ten* warped = G.make(NF, S_, S_, 3);
+    k_affine_warp(G.L, warped->p, bt.faces, bt.B, S_, 2, kTheta);
+    Ten* small = G.make(NF, c.fr_in, c.fr_in, 3);
+    k_resize_bilinear_ac(G.L, small->p, warped->p, NF, S_, S_, c.fr_in, c.fr_in, 3);
+    return frnet_forward(G, T->fr, small);
+}
+// first stage, part B: VAE encode -> posterior sample * scale_factor (ddpm.py:702-759, 590-597), no grad -> z0 [B,h,w,zc]
+static Ten* first_stage_latent(Graph& G, Trainer* T, const Batch& bt) {
+    const TrainerCfg& c = T->cfg;
+    Ten* img = G.wrap(const_cast<float*>(bt.image), bt.B, c.image_size, c.image_size, c.vae.in_channels);
+    Ten* mom = vae_encode_moments(G, T->vae, img);
+    Ten* z0 = G.make(bt.B, mom->h, mom->w, c.vae.z_channels);
+    k_vae_sample(G.L, z0->p, mom->p, bt.post_noise, bt.B, mom->h * mom->w, c.vae.z_channels, c.scale_factor);
+    return z0;
+}
+
+static void prefetch_impl(Trainer* T, const Batch& bt, Trainer::Prefetch::Slot& sl) {
+    Ctx* ctx = T->ctx;
+    Graph G(ctx);
+    G.L.stream = T->pf.stream;
+    Ten* feat = first_stage_faces(G, T, bt);
+    Ten* z0 = first_stage_latent(G, T, bt);
+    k_axpby(G.L, sl.feat, feat->p, feat->numel(), 1.f, 0.f);
+    k_axpby(G.L, sl.z0, z0->p, z0->numel(), 1.f, 0.f);
+}
+void trainer_prefetch(Trainer* T, const Batch& bt) {
+    Ctx* ctx = T->ctx;
+    CB_CHECK(bt.B >= 1 && bt.B <= 4, CB_ERR_ARG, "trainer: batch %d unsupported (1..4)", bt.B);
+    Trainer::Prefetch& pf = T->pf;
+    const TrainerCfg& c = T->cfg;
+    if (ctx->dry) return;
+    if (!pf.stream) {
+        CB_HIP(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
+        CB_HIP(hipEventCreateWithFlags(&pf.ready, hipEventDisableTiming));
+        const int lat = c.image_size / (1 << (c.vae.n_mult - 1));
+        for (auto& sl : pf.slot) {
+            CB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
+            sl.z0 = ctx->pool.allocf((size_t)4 * lat * lat * c.vae.z_channels);      // sized for the largest batch (4)
+            sl.feat = ctx->pool.allocf((size_t)2 * 4 * T->fr.feat);
+        }
+    }
+    Trainer::Prefetch::Slot& sl = pf.slot[pf.next];
+    pf.next ^= 1;
+    sl.valid = false;
+    // the prefetch graph allocates from its own arena: the step arena is rewound while these kernels may still be running
+    std::swap(ctx->arena, pf.arena);
+    try {
+        if (pf.planned_B != bt.B) {
+            Stats saved = ctx->stats;
+            ctx->dry = true; ctx->arena.dry = true; ctx->arena.reset(); ctx->arena.peak = 0;
+            try { prefetch_impl(T, bt, sl); } catch (...) { ctx->dry = false; ctx->arena.dry = false; ctx->stats = saved; throw; }
+            pf.need = ctx->arena.peak;
+            ctx->dry = false; ctx->arena.dry = false; ctx->stats = saved;
+            CB_HIP(hipStreamSynchronize(pf.stream));
+            ctx->ensure_arena(pf.need);
+            pf.planned_B = bt.B;
+        }
+        ctx->arena.reset();
+        // everything enqueued on the caller's stream so far — the step that consumed this slot two prefetches ago and whatever
+        // produced the batch buffers — happens before the prefetch; the step enqueued after this call overlaps with it
+        CB_HIP(hipEventRecord(pf.ready, ctx->stream));
+        CB_HIP(hipStreamWaitEvent(pf.stream, pf.ready, 0));
+        prefetch_impl(T, bt, sl);
+        CB_HIP(hipEventRecord(sl.done, pf.stream));
+    } catch (...) { std::swap(ctx->arena, pf.arena); throw; }
+    std::swap(ctx->arena, pf.arena);
+    sl.image = bt.image; sl.faces = bt.faces; sl.post_noise = bt.post_noise; sl.B = bt.B; sl.valid = true;
+}
+
 static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ctx* ctx = T->ctx;
     const TrainerCfg& c = T->cfg;
@@ -493,12 +566,18 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));    // ... happens before the side branch
         G.L.stream = ctx->aux;
     }
+    // a batch whose first stage was enqueued by trainer_prefetch: wait for it instead of recomputing (bitwise the same values)
+    Trainer::Prefetch::Slot* ps = nullptr;
+    if (!ctx->dry)
+        for (auto& sl : T->pf.slot)
+            if (sl.valid && sl.image == bt.image && sl.faces == bt.faces && sl.post_noise == bt.post_noise && sl.B == B) ps = &sl;
+    const bool prefetched = ps != nullptr;
+    if (prefetched) {
+        CB_HIP(hipStreamWaitEvent(G.L.stream, ps->done, 0)); CB_HIP(hipStreamWaitEvent(main_stream, ps->done, 0));
+        ps->valid = false;                              // consumed; the slot is rewritten no earlier than the prefetch after next
+    }
     std::unique_ptr<Phase> ph_id(new Phase(L, "phase:frnet_head"));
-    Ten* warped = G.make(NF, S_, S_, 3);
-    k_affine_warp(L, warped->p, bt.faces, B, S_, 2, kTheta);
-    Ten* small = G.make(NF, c.fr_in, c.fr_in, 3);
-    k_resize_bilinear_ac(L, small->p, warped->p, NF, S_, S_, c.fr_in, c.fr_in, 3);
-    Ten* feat = frnet_forward(G, T->fr, small);
+    Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat) : first_stage_faces(G, T, bt);
     const int I = T->fr.feat, O = es * K;
     Ten* v = G.make(NF, 1, 1, I);
     k_l2norm_fwd(L, v->p, nullptr, feat->p, NF, I);
@@ -533,10 +612,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ten* z0;
     {
         Phase ph(L, "phase:vae_encode");
-        Ten* img = G.wrap(const_cast<float*>(bt.image), B, S_, S_, c.vae.in_channels);
-        Ten* mom = vae_encode_moments(G, T->vae, img);
-        z0 = G.make(B, mom->h, mom->w, zc);
-        k_vae_sample(L, z0->p, mom->p, bt.post_noise, B, mom->h * mom->w, zc, c.scale_factor);
+        z0 = prefetched ? G.wrap(ps->z0, B, S_ >> (c.vae.n_mult - 1), S_ >> (c.vae.n_mult - 1), zc) : first_stage_latent(G, T, bt);
         G.tap("z0", z0);
     }
 

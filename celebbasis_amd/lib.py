@@ -81,7 +81,7 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
-    "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
+    "cb_trainer_prefetch", "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
@@ -117,7 +117,7 @@ _ARGTYPES = {
     "cb_clip_backward_embeds": [_P, _P, _P],
     "cb_frnet_create": [_P, _P, C.c_char_p, _P, _I, _I, _P], "cb_frnet_destroy": [_P], "cb_frnet_forward": [_P, _P, _I, _P],
     "cb_trainer_cfg_default": [_P], "cb_trainer_create": [_P, _P, _P, _P], "cb_trainer_destroy": [_P],
-    "cb_trainer_step": [_P, _P, _F], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
+    "cb_trainer_step": [_P, _P, _F], "cb_trainer_prefetch": [_P, _P], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
     "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
     "cb_row_surgery_multi": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I],
     "cb_celeb_head_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -497,6 +497,15 @@ class Trainer(_Handle):
             b.ids, b.tokens, b.t = ptr(ids, torch.int64), ptr(tokens, torch.int64), ptr(t, torch.int64)
             b.noise, b.post_noise = ptr(noise), ptr(post_noise)
         check(load().cb_trainer_step(self.h, C.byref(b), C.c_float(lr)))
+
+    def prefetch(self, image, faces, post_noise):
+        """enqueue the first stage (VAE encode, FR backbone) of the NEXT batch so that it overlaps the step enqueued after this
+        call; `step` on the same tensors then consumes it (identical results). Order: prefetch(batch[i+1]); step(batch[i])."""
+        b = Batch()
+        b.B = int(image.shape[0])
+        if not self.ctx.dry:
+            b.image, b.faces, b.post_noise = ptr(image), ptr(faces), ptr(post_noise)
+        check(load().cb_trainer_prefetch(self.h, C.byref(b)))
 
     def unet(self):
         """UNet view sharing the trainer's device weights (sampling after personalisation without a second copy)"""

@@ -244,6 +244,13 @@ typedef struct {
     int B;
 } cb_batch;
 int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
+/* Optional software pipelining across steps: enqueue the gradient-free first stage of the NEXT batch (VAE encode -> latent,
+ * FR backbone -> face features; only image / faces / post_noise / B of `next` are read) on a library-owned stream so that it
+ * overlaps the UNet of the step that is enqueued afterwards. A later cb_trainer_step on the same buffers consumes the result
+ * (bitwise identical to computing it in the step); any other batch is computed inline as usual. Call order per iteration:
+ * cb_trainer_prefetch(batch[i+1]); cb_trainer_step(batch[i]). */
+int cb_trainer_prefetch(cb_trainer* t, const cb_batch* next);
+
 /* state names: "loss"(1) "mlp.weight" "mlp.bias" "mlp.grad_weight" "mlp.grad_bias" "adam.m_weight" "adam.v_weight"
  * "adam.m_bias" "adam.v_bias" "id_embeddings" "id_coefficients" "step"(1, as float) */
 int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);

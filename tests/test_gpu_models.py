@@ -479,3 +479,35 @@ def test_manager_image_mode_mini_vs_oracle(cb):
         _, z = O.celeb_head(Wh, v, es, K)                                                # [2B, es, Wd]
         ref = torch.stack([O.shift_rows_multi(tokens[b], emb[b], [z[b], z[B + b]], [99, 98], es) for b in range(B)])
     close("manager.image_mode", out, ref, 2e-4)
+
+
+def test_prefetch_pipeline_is_bitwise_identical(cb):
+    """cb_trainer_prefetch (first stage of the next batch on its own stream) must not change a single bit: 4 steps with the
+    pipeline (incl. one batch that was never prefetched and one prefetched batch that is skipped) against 4 plain steps"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    m = MINI
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = O.init_weights(shapes, seed=9)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    batches = [{k: dv(v) for k, v in make_batch(2, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 300 + s, m["max_ids"]).items()}
+               for s in range(5)]
+    step = lambda tr, b: tr.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], 5e-3)
+    pre = lambda tr, b: tr.prefetch(b["image"], b["faces"], b["post_noise"])
+    results = []
+    for pipelined in (False, True):
+        tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+        if pipelined:
+            pre(tr, batches[0])
+            pre(tr, batches[1]); step(tr, batches[0])
+            pre(tr, batches[4]); step(tr, batches[1])          # batches[4] is prefetched but never stepped ...
+            step(tr, batches[2])                               # ... and batches[2] is stepped without a prefetch
+            pre(tr, batches[3]); step(tr, batches[3])          # prefetch immediately followed by its own step
+        else:
+            for i in range(4):
+                step(tr, batches[i])
+        ctx.sync()
+        results.append({k: tr.get_state(k).clone() for k in ("loss", "mlp.weight", "mlp.bias", "id_coefficients", "id_embeddings")})
+        tr.close()
+    for k in results[0]:
+        assert torch.equal(results[0][k], results[1][k]), f"pipelined run differs in {k}"
