@@ -847,7 +847,10 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss,
 }
 void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw, int B, int C, int HW) {
     LAUNCH(fill_kernel, dim3(1), dim3(64), L, loss, 1L, 0.f);
-    LAUNCH(mse_loss_kernel, grid1d((long)B * C * HW, 256, 64), dim3(256), L, loss, dpred, pred, target_nchw, B, C, HW);
+    // one block up to 256K elements (the latent of bs <= 16): the scalar is then summed in a fixed order — with several blocks
+    // the float atomicAdd order, and with it the last bits of the reported loss, would vary from run to run
+    const long total = (long)B * C * HW;
+    LAUNCH(mse_loss_kernel, total <= (1L << 18) ? dim3(1) : grid1d(total, 256, 64), dim3(256), L, loss, dpred, pred, target_nchw, B, C, HW);
 }
 
 // distributions.py:24-37 + ddpm.py:597: z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale

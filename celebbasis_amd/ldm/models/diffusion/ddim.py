@@ -126,8 +126,10 @@ class DDIMSampler(object):
             noise = torch.randn((S,) + tuple(shape), device=device) * temperature if np.any(sigma != 0) else None
             uc = None if unconditional_conditioning is None else self._crossattn(unconditional_conditioning).float().contiguous()
             unet = self.model.model.diffusion_model.native(device)
-            x, pred = unet.ddim_sample(x, self._crossattn(cond).float().contiguous(), uc, seq, a, a_prev, sigma, s1m,
+            c_ = self._crossattn(cond).float().contiguous()
+            x, pred = unet.ddim_sample(x, c_, uc, seq, a, a_prev, sigma, s1m,
                                        scale=float(unconditional_guidance_scale), noise=noise, want_pred_x0=True)
+            _lib.keep_alive(noise, uc, c_)
             log["x_inter"].append(x); log["pred_x0"].append(pred)
             return x, log
         for i in range(S):

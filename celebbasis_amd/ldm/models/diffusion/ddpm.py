@@ -121,7 +121,7 @@ class LatentDiffusion:
         em = self.embedding_manager
         sd = {}
         sd.update(self.model.diffusion_model.state_dict("model.diffusion_model."))
-        sd.update(self.first_stage_model.state_dict("first_stage_model."))
+        sd.update(self.first_stage_model.state_dict("first_stage_model.", only=self.first_stage_model.ENC_KEYS))   # the step never decodes
         sd.update(self.cond_stage_model.state_dict("cond_stage_model."))
         sd.update(em.meta_id_net.id_model.state_dict("embedding_manager.meta_id_net.id_model."))
         sd["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"] = em.meta_id_net.weight
@@ -151,6 +151,24 @@ class LatentDiffusion:
             self._trainer = _lib.Trainer(context_for(device), _lib.WeightTable(self._state_for_trainer()), cfg)
         return self._trainer
 
+    def _first_stage_inputs(self, batch):
+        """device tensors the native first stage reads (image, faces, posterior noise); cached on the batch so that a
+        prefetch and the step that follows hand the very same buffers to the library"""
+        prep = batch.get("_first_stage")
+        if prep is None:
+            image = batch[self.first_stage_key]
+            dev, B, lat = image.device, image.shape[0], self.image_size
+            post = batch.get("post_noise")
+            post = torch.randn(B, self.channels, lat, lat, device=dev) if post is None else post.to(dev)
+            prep = (image.float().contiguous(), batch["image_ori"]["faces"].to(dev).float().contiguous(), post.float().contiguous())
+            batch["_first_stage"] = prep
+        return prep
+
+    def prefetch_first_stage(self, next_batch):
+        """optional cross-step pipelining (cb_trainer_prefetch): call with batch i+1 before training_step(batch i)"""
+        image, faces, post = self._first_stage_inputs(next_batch)
+        self.trainer(image.device).prefetch(image, faces, post)
+
     def training_step(self, batch, batch_idx=0):
         """ddpm.py:357-370. batch keys as produced by FaceIdDatasetStyleGAN3 (face_id.py:598-644): 'image' (B,H,W,3),
         'caption' (strings or pre-tokenised ids) / 'tokens', 'image_ori' {'faces','ids','num_ids'}. Optional replay keys
@@ -166,12 +184,14 @@ class LatentDiffusion:
         t = torch.randint(0, self.num_timesteps, (B,), device=dev) if t is None else t.to(dev)
         noise = batch.get("noise")
         noise = torch.randn(B, self.channels, lat, lat, device=dev) if noise is None else noise.to(dev)
-        post = batch.get("post_noise")
-        post = torch.randn(B, self.channels, lat, lat, device=dev) if post is None else post.to(dev)
+        image_c, faces_c, post = self._first_stage_inputs(batch)
         ori = batch["image_ori"]
-        assert int(ori["num_ids"].max()) == 1, "joint multi-identity prompts (num_ids > 1) are §8(f) 'next'"
-        tr.step(image.float().contiguous(), ori["faces"].to(dev).float().contiguous(), ori["ids"].to(dev).to(torch.int64).contiguous(),
-                tokens, t.to(torch.int64).contiguous(), noise.float().contiguous(), post.float().contiguous(), float(self.learning_rate))
+        assert int(ori["num_ids"].max()) == 1, "training prompts carry one identity (dual_img is never set, face_id.py:612)"
+        ids_c, t_c, noise_c = ori["ids"].to(dev).to(torch.int64).contiguous(), t.to(torch.int64).contiguous(), noise.float().contiguous()
+        tr.step(image_c, faces_c, ids_c, tokens, t_c, noise_c, post, float(self.learning_rate))
+        # the step is only ENQUEUED here: its input buffers must outlive this call (a freed block can be refilled by the next
+        # host-to-device copy before the queued kernels have read it), so the last few steps' tensors stay referenced
+        self._inflight = (getattr(self, "_inflight", []) + [(image_c, faces_c, ids_c, tokens, t_c, noise_c, post)])[-4:]
         self.global_step += 1
         return tr
 

@@ -122,7 +122,7 @@ class EmbeddingManagerId:
             d.a_layout, d.b_layout, d.batch = 0, 1, 1
             d.bias = basis[e, 0].data_ptr(); d.alpha, d.beta = 1.0, 0.0
             _lib.check(L.cb_gemm(ctx.h, C.byref(d)))
-        self._keep = (coef, z)
+        _lib.keep_alive(coef, z, basis)
         return z
 
     def _embedding_from_faces(self, faces, basis, dev):
@@ -141,6 +141,7 @@ class EmbeddingManagerId:
         coef = torch.empty(k * B, es * K, device=dev); z = torch.empty(k * B, es * W, device=dev)
         _lib.check(L.cb_celeb_head_forward(ctx.h, _lib.ptr(feat), _lib.ptr(Wm), _lib.ptr(bm), _lib.ptr(basis), k * B, feat.shape[1], es, K, W,
                                            _lib.ptr(coef), _lib.ptr(z)))
+        _lib.keep_alive(f, warped, small, feat, Wm, bm, coef, z)
         return z.reshape(k, B, es * self.meta_heads, W)
 
     def forward(self, tokenized_text, embedded_text, face_image=None, img_ori=None, celeb_embeddings=None):
@@ -180,6 +181,7 @@ class EmbeddingManagerId:
         mp = torch.empty(B * T, dtype=torch.int32, device=dev)
         _lib.check(L.cb_row_surgery_multi(ctx.h, _lib.ptr(embedded_text.contiguous()), _lib.ptr(z), _lib.ptr(tokenized_text.contiguous(), torch.int64),
                                           _lib.ptr(out), C.c_void_p(mp.data_ptr()), B, T, W, reps, _lib.ptr(ph, torch.int64), nph))
+        _lib.keep_alive(z, ph, mp, basis, embedded_text, tokenized_text)
         return out
 
     __call__ = forward

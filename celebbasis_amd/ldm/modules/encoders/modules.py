@@ -129,7 +129,9 @@ class FrozenCLIPEmbedder(FrozenModule):
         embedded = h.embed_tokens(tokens)
         if embedding_manager is not None:
             embedded = embedding_manager(tokens, embedded, face_img, image_ori, self.celeb_embeddings)
-        return h.forward(embedded.contiguous(), need_grad=bool(kwargs.get("need_grad", False)))
+        embedded = embedded.contiguous()
+        _lib.keep_alive(tokens, embedded)
+        return h.forward(embedded, need_grad=bool(kwargs.get("need_grad", False)))
 
     def encode(self, text, **kwargs):
         return self(text, **kwargs)

@@ -155,6 +155,18 @@ def check(code):
         raise CBError(code, load().cb_last_error().decode("utf-8", "replace"))
 
 
+import collections as _collections
+
+_INFLIGHT = _collections.deque(maxlen=512)
+
+
+def keep_alive(*tensors):
+    """Native calls only ENQUEUE work. A temporary that is freed right after the call returns goes back to torch's caching
+    allocator, and a later pageable host-to-device copy may refill that block outside stream order, before the queued kernels
+    have read it. Callers that build temporaries park them here (a bounded ring) instead of synchronising."""
+    _INFLIGHT.append(tensors)
+
+
 def ptr(t, dtype=torch.float32):
     """raw pointer of a contiguous tensor (or None)"""
     if t is None:

@@ -69,6 +69,7 @@ def get_parser():
     p.add_argument("-t", "--train", action="store_true")
     p.add_argument("-s", "--seed", type=int, default=23)
     p.add_argument("-l", "--logdir", type=str, default="logs")
+    p.add_argument("--pipeline", action="store_true", help="overlap the next batch's VAE encode / FR backbone with the current step")
     p.add_argument("--actual_resume", type=str, default=None, help="Stable Diffusion checkpoint (.ckpt / .safetensors)")
     p.add_argument("--embedding_manager_ckpt", type=str, default="")
     p.add_argument("--celeb_basis", type=str, default=None, help="celeb_basis.pt (es, 1+K, 768), the format written by extract_pt.py")
@@ -136,9 +137,22 @@ def main(argv=None):
     ckptdir = os.path.join(opt.logdir, opt.name, "checkpoints")
     model.train()
     step = 0
+
+    def lookahead(loader):
+        """(batch, next batch or None): with --pipeline the next batch's first stage is enqueued before the current step"""
+        it = iter(loader)
+        cur = next(it, None)
+        while cur is not None:
+            nxt = next(it, None)
+            yield cur, nxt
+            cur = nxt
+
     while step < max_steps:
-        for batch in data.train_dataloader():
+        for batch, nxt in lookahead(data.train_dataloader()):
             batch["image"] = batch["image"].to(dev)
+            if opt.pipeline and nxt is not None:
+                nxt["image"] = nxt["image"].to(dev)
+                model.prefetch_first_stage(nxt)
             model.training_step(batch, step)
             step += 1
             if step % every == 0 or step == max_steps:

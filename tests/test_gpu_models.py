@@ -511,3 +511,56 @@ def test_prefetch_pipeline_is_bitwise_identical(cb):
         tr.close()
     for k in results[0]:
         assert torch.equal(results[0][k], results[1][k]), f"pipelined run differs in {k}"
+
+
+def test_host_training_step_mini_vs_oracle(cb, tmp_path):
+    """the reference-facing LatentDiffusion.training_step (+ prefetch_first_stage, on_save_checkpoint) at mini sizes against the
+    oracle on a pinned replay stream: loss, MLP weights, coefficient dictionary, and the embeddings_gs-*.pt written at the end"""
+    from celebbasis_amd.ldm.models.diffusion.ddpm import LatentDiffusion
+    from celebbasis_amd.ldm.modules.id_embedding.iresnet import IResNet
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    m = dict(MINI, clip=dict(vocab=49408, width=64, layers=1, heads=4, ctx_len=77, mlp=128), placeholder=48136, max_ids=10)
+    T = lambda t, p: dict(target=t, params=p)
+    model = LatentDiffusion(
+        first_stage_config=T("celebbasis_amd.ldm.models.autoencoder.AutoencoderKL",
+                             dict(embed_dim=4, ddconfig=dict(double_z=True, z_channels=4, resolution=64, in_channels=3, out_ch=3, ch=32,
+                                                             ch_mult=[1, 2, 2], num_res_blocks=1, attn_resolutions=[], dropout=0.0))),
+        cond_stage_config=T("celebbasis_amd.ldm.modules.encoders.modules.FrozenCLIPEmbedder",
+                            dict(vocab=49408, width=64, layers=1, heads=4, mlp=128, num_embeds_per_token=2, n_components=16)),
+        unet_config=T("celebbasis_amd.ldm.modules.diffusionmodules.openaimodel.UNetModel",
+                      dict(image_size=16, in_channels=4, out_channels=4, model_channels=32, attention_resolutions=[1, 2], num_res_blocks=1,
+                           channel_mult=[1, 2, 2], num_heads=2, use_spatial_transformer=True, transformer_depth=1, context_dim=64)),
+        personalization_config=T("celebbasis_amd.ldm.modules.embedding_manager.EmbeddingManagerId",
+                                 dict(placeholder_strings=["sks"], max_ids=10, num_embeds_per_token=2, meta_mlp_depth=1, loss_type="none",
+                                      meta_inner_dim=16, test_mode="coefficient", momentum=0.99, save_fp16=False)),
+        linear_start=0.00085, linear_end=0.012, timesteps=1000, scale_factor=0.18215, image_size=16, channels=4)
+    fr = m["fr"]
+    model.embedding_manager.meta_id_net.id_model = IResNet(fr["layers"], fr["feat"], fr["width"], fr["in_size"])
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], fr, es=2, inner=16, max_ids=10)
+    W = O.init_weights(shapes, seed=41)
+    model.load_state_dict(W)
+    em = model.embedding_manager
+    em.meta_id_net.weight = W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"].clone()
+    em.meta_id_net.bias = W["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"].clone()
+    em.id_coefficients = [W["id_coefficients"][i].reshape(2, 1, 16).clone() for i in range(10)]
+    em.id_embeddings = [W["id_embeddings"][i].reshape(2, 64).clone() for i in range(10)]
+    model.learning_rate = 5e-3
+    model.train()
+    st = O.TrainState(W)
+    raw = [make_batch(2, 64, 16, 40000, 48136, 500 + s, 10) for s in range(3)]
+    dev_batches = []
+    for b in raw:
+        dev_batches.append(dict(image=dv(b["image"]), tokens=b["tokens"], t=b["t"], noise=b["noise"], post_noise=b["post_noise"],
+                                image_ori=dict(faces=b["faces"], ids=b["ids"], num_ids=torch.ones(2, dtype=torch.int64))))
+    for i, b in enumerate(dev_batches):
+        if i + 1 < len(dev_batches):
+            model.prefetch_first_stage(dev_batches[i + 1])
+        model.training_step(b, i)
+        loss_ref = O.train_step(W, st, raw[i], 5e-3, m["unet"], m["vae"], m["clip"], fr, es=2, inner=16, placeholder=48136)
+        close(f"host_step.s{i}.loss", torch.tensor([model.last_loss()]), loss_ref.reshape(1), 1e-4)
+    model.on_save_checkpoint({}, ckptdir=str(tmp_path))
+    ck = torch.load(tmp_path / "embeddings_gs-3.pt", weights_only=False)
+    coef = torch.stack([c.reshape(-1) for c in ck["id_coefficients"]])
+    assert (coef - st.id_coef).norm(dim=1).max().item() <= 1e-3
+    close("host_step.mlp.weight", em.meta_id_net.weight.reshape(-1), st.Wm.reshape(-1), 1e-4)
