@@ -172,6 +172,10 @@ def main():
                         algorithmic_bytes_per_launch=round(dom.get("bytes", 0) / dom["launches"]),
                         all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
                                               achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
+                        attention_mfma=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3),
+                                             achieved_tflops=round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2),
+                                             frac_of_peak=round(p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
+                                        for p in prof if p["kernel"].startswith("flash")],
                         by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
                                    for p in sorted(prof, key=lambda p: -p["ms"])],
                         hbm_bound=[dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1),

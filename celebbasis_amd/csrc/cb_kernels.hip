@@ -255,8 +255,10 @@ void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H,
 constexpr int GN_MAXQ = 3;   // quads (float4 columns) per thread: C <= 3*256*4 = 3072
 
 static int gn_rows_per_block(int N, int HW) {
+    // ~1024 statistics blocks per call (4 per CU); CB_GN_BLOCKS overrides the target for sweeps
+    static const long target = [] { const char* e = getenv("CB_GN_BLOCKS"); long v = e ? atol(e) : 1024; return v > 0 ? v : 1024; }();
     long rows = (long)N * HW;
-    long rpb = (rows + 1023) / 1024;
+    long rpb = (rows + target - 1) / target;
     if (rpb < 8) rpb = 8;
     if (rpb > 256) rpb = 256;
     return (int)rpb;

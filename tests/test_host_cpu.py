@@ -173,3 +173,48 @@ if r == 0:
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", "29533", str(script)], check=True, env=env, timeout=300)
     assert (tmp_path / "ok").read_text() == "ok"
+
+
+def test_bench_line_contract_of_committed_profile():
+    """the bench.py JSON line committed under profiles/ carries every field of the driver's contract (keys and types), the
+    roofline and cpu_baseline objects, and internally consistent numbers"""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "BENCH_r01_run*.json")), key=lambda p: int(p.split("run")[-1].split(".")[0]))
+    full = [json.load(open(p)) for p in files]
+    full = [d for d in full if d.get("cpu_baseline")]
+    assert full, "no committed bench line with a cpu_baseline"
+    d = full[-1]
+    for k, t in dict(metric=str, value=float, unit=str, n_gpus=int, steps=int, warmup=int, ms_per_step=float, higher_is_better=bool,
+                     scaling=str, dtype=str, data=str, config=dict, roofline=dict, cpu_baseline=dict).items():
+        assert isinstance(d[k], t), (k, type(d[k]))
+    assert d["vs_baseline"] is None and d["scaling"] == "weak" and d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 0.02 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and r["peak"] == 157.3
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
+    assert d["value"] / c["value"] > 50            # the GPU path is two orders of magnitude above the host baseline
+
+
+def test_feeder_draws_and_lookahead():
+    """host side of the feeder: parameter draws stay in the reference's ranges (face_id.py:526-532, 719-727) and the
+    one-batch lookahead used by --pipeline yields every batch exactly once, in order"""
+    import random
+    from celebbasis_amd.ldm.data.face_id import FaceIdDatasetOneShot
+    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=1, size=64, seed=1)
+    ds.rng = random.Random(0)
+    for _ in range(200):
+        flip, b, c, s, h = ds._jitter_params()
+        assert flip in (0.0, 1.0) and all(0.8 <= v <= 1.2 for v in (b, c, s)) and -0.01 <= h <= 0.01
+        rh, rw, ph, pw = ds._bg_geometry()
+        assert 1 <= rh <= 64 and 1 <= rw <= 64 and 0 <= ph <= 64 - rh and 0 <= pw <= 64 - rw
+        assert rh >= int(64 * 0.1) and abs(rw - rh) <= int(0.1 * rh) + 1
+    src = open(os.path.join(ROOT, "celebbasis_amd", "main.py")).read()
+    ns = {}
+    start = src.index("    def lookahead(loader):"); end = src.index("    while step < max_steps:")
+    exec("def make():\n" + src[start:end] + "    return lookahead\n", ns)
+    pairs = list(ns["make"]()([10, 11, 12]))
+    assert pairs == [(10, 11), (11, 12), (12, None)] and list(ns["make"]()([])) == []
