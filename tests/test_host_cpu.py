@@ -218,3 +218,35 @@ def test_feeder_draws_and_lookahead():
     exec("def make():\n" + src[start:end] + "    return lookahead\n", ns)
     pairs = list(ns["make"]()([10, 11, 12]))
     assert pairs == [(10, 11), (11, 12), (12, None)] and list(ns["make"]()([])) == []
+
+
+def test_argument_errors_on_a_dry_context(built_lib):
+    """edge cases are rejected with a status + message before anything is launched (checked on a dry context, no GPU):
+    batch above the supported maximum, prompt longer than the row-surgery kernel handles, zero scale factor, eta != 0
+    without noise, bad GEMM shape"""
+    import ctypes as C
+    from celebbasis_amd import lib, synthetic
+    from oracle import cb_oracle as O
+    ctx = lib.Context(device=-1)
+    L = lib.load()
+    shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
+    wt = lib.WeightTable(shapes)
+    tr = lib.Trainer(ctx, wt)
+    for bad in (0, 5):
+        with pytest.raises(lib.CBError) as e:
+            tr.step(bad, None, None, None, None, None, None, 5e-3)
+        assert "batch" in str(e.value)
+    rc = L.cb_row_surgery(ctx.h, None, None, None, None, None, 1, 300, 768, 2, C.c_int64(48136))
+    assert rc != 0 and b"T=300" in L.cb_last_error()
+    dec = lib.VAEDecoder(ctx, wt, lib.vae_cfg(), prefix="first_stage_model.")
+    with pytest.raises(lib.CBError) as e:
+        dec.decode(torch.zeros(1, 4, 8, 8), scale_factor=0.0)
+    assert "scale_factor" in str(e.value)
+    u = lib.UNet(ctx, wt, lib.unet_cfg(), prefix="model.diffusion_model.")
+    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 4, 0.5)
+    with pytest.raises(lib.CBError) as e:
+        u.ddim_sample(torch.zeros(1, 4, 8, 8), torch.zeros(1, 77, 768), None, s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"],
+                      s["sqrt_one_minus_alphas"], noise=None)
+    assert "noise" in str(e.value)
+    d = lib.GemmDesc(); d.M, d.N, d.K, d.batch = 0, 8, 8, 1
+    assert L.cb_gemm(ctx.h, C.byref(d)) != 0 and b"shape" in L.cb_last_error()
