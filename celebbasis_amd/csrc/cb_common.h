@@ -81,13 +81,7 @@ struct ConvGeom {
     int pad = 1;                // top/left padding in virtual coordinates
     int up = 0;                 // 1: nearest-2x upsample fused: source pixel = virtual >> 1
     int tr = 0;                 // 1: transposed stride-2 (dgrad of a stride-2 conv): virtual must be even, source = virtual >> 1
-    int cm = 0;                 // K order of the packed weights / gather: 0 = tap-major k = tap*C + ci,
-                                // 1 = chunk-major k = (ci/16)*(9*16) + tap*16 + ci%16 (set by gemm() from conv_chunk_major())
 };
-// 3x3 convs over a multiple of 16 channels walk K as (16-channel chunk, tap): the nine taps of a chunk re-read the same few
-// KB of the input within nine k-tiles (L1/L2 resident), instead of re-reading the whole 3-row input panel once per tap.
-// CB_CONV_KORD=0 restores tap-major everywhere (weights must be packed under the same setting).
-bool conv_chunk_major(int C, int ks);
 
 // ---------------------------------------------------------------- GEMM arguments
 enum { LD_ROW = 0, LD_COL = 1, LD_CONV = 2, LD_CONVF = 3 /* kernel-internal: conv with the scalar tap walk (cb_gemm.hip) */ };
@@ -201,8 +195,8 @@ void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long
 void k_step_inc(const Launch& L, int* step);
 void k_gemv(const Launch& L, float* y, const float* x, const float* W, const float* bias, int M, int N, int K);
 // weight packing
-void k_pack_conv(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);          // -> [O][K] in the conv's K order
-void k_pack_conv_dgrad(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);    // -> [I][K'] flipped taps, K order of the dgrad conv (C = O)
+void k_pack_conv(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);          // -> [O][ky][kx][I]
+void k_pack_conv_dgrad(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);    // -> [I][ky'][kx'][O], flipped
 void k_pack_fc_nhwc(const Launch& L, float* out, const float* w, int O, int C, int HW);            // [O][C*HW] -> [O][HW*C]
 void k_fold_bn(const Launch& L, float* w_packed, float* bias_out, const float* bn_w, const float* bn_b,
                const float* bn_m, const float* bn_v, float eps, int O, long per_o);

@@ -92,14 +92,9 @@ __device__ __forceinline__ void load_col(float4 (&reg)[ROWS / 64], const float* 
     }
 }
 
-// k -> (tap, channel) in the conv's K order
-__device__ __forceinline__ void conv_decode(const ConvGeom& g, int k, int* tap, int* ci) {
-    if (g.cm) { const int span = g.ks * g.ks * 16, chunk = k / span, rem = k - chunk * span; *tap = rem >> 4; *ci = chunk * 16 + (rem & 15); }
-    else { *tap = k / g.C; *ci = k - *tap * g.C; }
-}
 __device__ __forceinline__ float conv_fetch(const float* __restrict__ p, const ConvGeom& g, int n, int oy, int ox, int k) {
-    int tap, ci;
-    conv_decode(g, k, &tap, &ci);
+    int tap = k / g.C;
+    int ci = k - tap * g.C;
     int ky = tap / g.ks, kx = tap - ky * g.ks;
     int vy = oy * g.stride + ky - g.pad;
     int vx = ox * g.stride + kx - g.pad;
@@ -132,10 +127,9 @@ struct ConvRows {
             } else { nb[i] = -1; vy0[i] = 0; vx0[i] = 0; }
         }
         int k = kfirst + ((tid & 3) << 2);
-        conv_decode(g, k, &tap, &ci);
+        tap = k / g.C; ci = k - tap * g.C;
     }
     __device__ __forceinline__ void advance(const ConvGeom& g) {
-        if (g.cm) { ++tap; const bool w = tap >= g.ks * g.ks; tap = w ? 0 : tap; ci += w ? 16 : 0; return; }   // one k-tile = one tap of one chunk
         ci += BK;
         if (g.C >= BK) { bool w = ci >= g.C; ci -= w ? g.C : 0; tap += w ? 1 : 0; }   // wave-uniform, one wrap at most
         else while (ci >= g.C) { ci -= g.C; ++tap; }
@@ -371,11 +365,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
     ConvRows<BM> cr;
     ConvFast<BM> cf;
     int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0
-    if constexpr (conv_fast) {
-        cf.init(a.g, m0, a.M, tid);
-        if (a.g.cm) { const int it0 = kbeg / BK, T = a.g.ks * a.g.ks; tap_u = it0 % T; ci_u = (it0 / T) * BK; }
-        else { tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
-    }
+    if constexpr (conv_fast) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
     else if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
 
     const unsigned ma = ~0u, mb = ~0u;
@@ -395,8 +385,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
                 const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
                 const int kx = tap_u - ky * a.g.ks;
                 offs_conv_fast<BM>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 4);
-                if (a.g.cm) { ++tap_u; if (tap_u >= a.g.ks * a.g.ks) { tap_u = 0; ci_u += BK; } }   // taps inner, 16-channel chunks outer
-                else { ci_u += BK; if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; } }
+                ci_u += BK;
+                if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
             } else { offs_conv<BM>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
             if constexpr (BKIND == LD_ROW) offs_row<BN>(ob, roB, k0, kend, tid);
             else offs_col<BN>(ob, a.ldb, n0, a.N, k0, kend, tid);
@@ -595,10 +585,6 @@ static const PlanKnobs& plan_knobs() {
     }();
     return k;
 }
-bool conv_chunk_major(int C, int ks) {
-    static const bool on = [] { const char* e = getenv("CB_CONV_KORD"); return e && e[0] == '1'; }();
-    return on && ks == 3 && C % 16 == 0;
-}
 static Plan make_plan(const GemmArgs& a) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
@@ -686,7 +672,6 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
 
     KArgs ka;
     ka.a = a;
-    if (a.a_kind == LD_CONV) ka.a.g.cm = conv_chunk_major(a.g.C, a.g.ks) ? 1 : 0;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
     ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
     ka.ws = ws;

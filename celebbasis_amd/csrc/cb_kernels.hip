@@ -1360,40 +1360,36 @@ void k_gemv(const Launch& L, float* y, const float* x, const float* W, const flo
 
 // ------------------------------------------------------------------ one-time weight packing
 // OIHW -> [O][ky][kx][I]  (B operand of the implicit GEMM, k = (ky*ks+kx)*I + ci)
-// OIHW -> [O][K]: tap-major K = (ky*ks + kx)*I + ci, or chunk-major K = (ci/16)*(ks*ks*16) + (ky*ks+kx)*16 + ci%16
-__global__ void pack_conv_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks, int cm) {
+__global__ void pack_conv_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
     long total = (long)O * I * ks * ks;
-    const int T = ks * ks;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long o = i / ((long)I * T);
-        const int k = (int)(i - o * (long)I * T);
-        int tap, ci;
-        if (cm) { const int chunk = k / (T * 16), rem = k - chunk * T * 16; tap = rem >> 4; ci = chunk * 16 + (rem & 15); }
-        else { tap = k / I; ci = k - tap * I; }
-        const int ky = tap / ks, kx = tap - ky * ks;
+        int ci = (int)(i % I);
+        long r = i / I;
+        int kx = (int)(r % ks);
+        r /= ks;
+        int ky = (int)(r % ks);
+        long o = r / ks;
         out[i] = w[((o * I + ci) * ks + ky) * ks + kx];
     }
 }
 void k_pack_conv(const Launch& L, float* out, const float* w, int O, int I, int ks) {
-    LAUNCH(pack_conv_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks, conv_chunk_major(I, ks) ? 1 : 0);
+    LAUNCH(pack_conv_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
 }
-// OIHW -> [I][K'] with the kernel flipped: out[ci][tap', co] = w[co][ci][ks-1-ky'][ks-1-kx'], K' ordered like the dgrad conv's K
-// (its gathered tensor is dy with C = O channels)
-__global__ void pack_conv_dgrad_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks, int cm) {
+// OIHW -> [I][ky'][kx'][O] with the kernel flipped: out[ci][ky'][kx'][co] = w[co][ci][ks-1-ky'][ks-1-kx']
+__global__ void pack_conv_dgrad_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
     long total = (long)O * I * ks * ks;
-    const int T = ks * ks;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long ci = i / ((long)O * T);
-        const int k = (int)(i - ci * (long)O * T);
-        int tap, co;
-        if (cm) { const int chunk = k / (T * 16), rem = k - chunk * T * 16; tap = rem >> 4; co = chunk * 16 + (rem & 15); }
-        else { tap = k / O; co = k - tap * O; }
-        const int ky = tap / ks, kx = tap - ky * ks;
+        int co = (int)(i % O);
+        long r = i / O;
+        int kx = (int)(r % ks);
+        r /= ks;
+        int ky = (int)(r % ks);
+        long ci = r / ks;
         out[i] = w[(((long)co * I + ci) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
     }
 }
 void k_pack_conv_dgrad(const Launch& L, float* out, const float* w, int O, int I, int ks) {
-    LAUNCH(pack_conv_dgrad_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks, conv_chunk_major(O, ks) ? 1 : 0);
+    LAUNCH(pack_conv_dgrad_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
 }
 // fc over torch.flatten(NCHW): w[o][c*HW + hw] -> out[o][hw*C + c]   (iresnet.py:176-179)
 __global__ void pack_fc_nhwc_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int C, int HW) {
