@@ -129,7 +129,7 @@ def main():
     # (VAE encode + FR backbone, no gradients) prefetched on its own stream under the UNet of batch i (cb_trainer_prefetch).
     # Every timed iteration still executes one VAE encode, one FR pass and one full step; results are bitwise identical.
     pipelined = None
-    if rank == 0 and not args.no_pipelined:
+    if rank == 0 and world == 1 and not args.no_pipelined:      # N == 1 only, like the CPU baseline: keeps the N > 1 runs lean
         def nb(i):
             return batches[i % len(batches)]
         b0 = nb(0)
