@@ -10,7 +10,7 @@ import pytest
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-REF_YAML = os.path.join(ROOT, "tests", "golden", "aigc_id.params.yaml")
+REF_PARAMS = os.path.join(ROOT, "tests", "golden", "aigc_id_params.json")   # parameter values of the reference config (data)
 
 
 def test_abi_exports_every_declared_symbol(built_lib):
@@ -121,7 +121,11 @@ def test_reference_yaml_is_drop_in(tmp_path):
     celebbasis_amd.install_ldm_alias()
     from celebbasis_amd.main import load_config
     from celebbasis_amd.ldm.util import instantiate_from_config
-    cfg = load_config([REF_YAML], ["data.params.batch_size=1"])
+    import json
+    import yaml
+    ref_yaml = tmp_path / "aigc_id.yaml"                     # the config as a YAML file again, as the CLI would receive it
+    ref_yaml.write_text(yaml.safe_dump(json.load(open(REF_PARAMS))))
+    cfg = load_config([str(ref_yaml)], ["data.params.batch_size=1"])
     assert cfg["model"]["target"] == "ldm.models.diffusion.ddpm.LatentDiffusion"
     m = instantiate_from_config(cfg["model"])
     assert type(m).__name__ == "LatentDiffusion" and type(m.embedding_manager).__name__ == "EmbeddingManagerId"
