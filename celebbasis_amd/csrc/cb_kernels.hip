@@ -396,7 +396,12 @@ void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gam
     float* chn = ws + (size_t)N * nchunk * G * 2;
     (void)L.count(3);
     if (L.dry) return;
-    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? "groupnorm_silu_fwd" : "groupnorm_fwd", 0.0, 3.0 * N * HW * (double)C * 4, L.stream);
+    // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
+    // launch-latency bound and would otherwise drown the achieved-bandwidth figure
+    const bool big = (double)N * HW * C * 4 >= 64e6;
+    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_fwd[>=64MB]" : "groupnorm_silu_fwd[<64MB]")
+                                                                   : (big ? "groupnorm_fwd[>=64MB]" : "groupnorm_fwd[<64MB]"),
+                                                             0.0, 3.0 * N * HW * (double)C * 4, L.stream);
     hipLaunchKernelGGL(gn_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, HW, C, G, nchunk, rpb);
     hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, x, gamma, beta, N, HW, C, G, nchunk, eps);
     long nquads = (long)N * HW * (C / 4);
@@ -504,7 +509,10 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
     float* gs = chn + (size_t)N * C * 4;
     (void)L.count(chn_valid ? 3 : 4);
     if (L.dry) return;
-    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? "groupnorm_silu_bwd" : "groupnorm_bwd", 0.0, 5.0 * N * HW * (double)C * 4, L.stream);
+    const bool big = (double)N * HW * C * 4 >= 64e6;
+    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_bwd[>=64MB]" : "groupnorm_silu_bwd[<64MB]")
+                                                                   : (big ? "groupnorm_bwd[>=64MB]" : "groupnorm_bwd[<64MB]"),
+                                                             0.0, 5.0 * N * HW * (double)C * 4, L.stream);
     // chn_valid: `ws` is the forward call's workspace and still holds its per-channel constants (the tape's case)
     if (!chn_valid) hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
     hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, dy, chn, HW, C, G,
