@@ -413,8 +413,15 @@ class VAEDecoder(_Handle):
         f = 2 ** (self.cfg.n_mult - 1)
         out = torch.empty((B, self.cfg.in_channels, h * f, w * f), dtype=torch.float32, device=z.device)
         dry = self.ctx.dry
-        check(load().cb_vae_decode(self.h, None if dry else ptr(z), B, h, w, C.c_float(scale_factor), C.c_int(1 if to01 else 0),
-                                   None if dry else ptr(out)))
+        # images are independent: decode in chunks so that every activation stays below 2 GiB (the 16-byte buffer-load
+        # kernels address an operand with 32-bit offsets; beyond that the scalar loaders would take over)
+        per = max(1, int((2 ** 31 - 2 ** 20) // max(1, h * f * w * f * self.cfg.ch * 2 * 4)))
+        for s0 in range(0, B, per):
+            n = min(per, B - s0)
+            zc = z[s0:s0 + n].contiguous()
+            keep_alive(zc)
+            check(load().cb_vae_decode(self.h, None if dry else ptr(zc), n, h, w, C.c_float(scale_factor),
+                                       C.c_int(1 if to01 else 0), None if dry else C.c_void_p(out[s0:s0 + n].data_ptr())))
         return out
 
 
