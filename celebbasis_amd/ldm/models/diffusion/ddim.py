@@ -4,8 +4,8 @@ Drop-in at the API level: same constructor, the same attribute names after `make
 keywords, so `scripts/stable_txt2img.py:330-340` runs unchanged. What differs is where the work happens: the schedule is a
 handful of host scalars, and the S-step loop — the batch-2n classifier-free-guidance UNet pass plus the x_{t-1} update — runs
 inside libcelebbasis_hip.so (`cb_unet_ddim_sample`) without returning to Python between steps. Per-step hooks (`callback`,
-`img_callback`, `mask`/`x0` blending, `score_corrector`, `noise_dropout`) use a step-by-step loop over the same native ops
-(`apply_model` + `cb_ddim_update`). `quantize_x0` (VQ first stages) is outside the CelebBasis path.
+`img_callback`, `score_corrector`, `noise_dropout`) use a step-by-step loop over the same native ops (`apply_model` +
+`cb_ddim_update`). `quantize_x0` (VQ first stages) and inpainting masks are outside the CelebBasis path.
 """
 import numpy as np
 import torch
@@ -107,6 +107,8 @@ class DDIMSampler(object):
         """ddim.py:113-163"""
         if quantize_denoised:
             raise NotImplementedError("quantize_x0 needs a VQ first stage; the CelebBasis first stage is AutoencoderKL")
+        if mask is not None:
+            raise NotImplementedError("inpainting masks (mask / x0) are outside the CelebBasis path")
         device = self.model.device
         x = torch.randn(shape, device=device) if x_T is None else x_T.to(device).float()
         if ddim_use_original_steps:
@@ -135,9 +137,6 @@ class DDIMSampler(object):
         for i in range(S):
             index = S - 1 - i
             ts = torch.full((shape[0],), int(seq[index]), device=device, dtype=torch.long)
-            if mask is not None:
-                assert x0 is not None
-                x = self.model.q_sample(x0, ts) * mask + (1. - mask) * x
             x, pred = self.p_sample_ddim(x, cond, ts, index=index, use_original_steps=ddim_use_original_steps, temperature=temperature,
                                          noise_dropout=noise_dropout, score_corrector=score_corrector, corrector_kwargs=corrector_kwargs,
                                          unconditional_guidance_scale=unconditional_guidance_scale,

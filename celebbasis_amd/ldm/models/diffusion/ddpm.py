@@ -101,11 +101,9 @@ class LatentDiffusion:
         return self.first_stage_model.decode(z, scale_factor=self.scale_factor)
 
     def q_sample(self, x_start, t, noise=None):
-        """ddpm.py:289-292 (host-side convenience for masks in DDIMSampler; elementwise on the caller's device)"""
-        noise = torch.randn_like(x_start) if noise is None else noise
-        a = self.sqrt_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)
-        b = self.sqrt_one_minus_alphas_cumprod.to(x_start.device)[t].reshape(-1, 1, 1, 1)
-        return a * x_start + b * noise
+        """ddpm.py:289-292. Inside training_step the forward diffusion runs natively (cb_q_sample, fused into cb_trainer_step); a
+        stand-alone call is only made by DDIMSampler's inpainting-mask blending, which is not part of the CelebBasis flow."""
+        raise NotImplementedError("stand-alone q_sample (inpainting masks) is outside the CelebBasis path")
 
     def train(self, mode=True):
         self.training = mode
