@@ -31,11 +31,20 @@ const char* cb_last_error(void) { return g_err.c_str(); }
 int cb_version(void) { return 100; }
 
 // ------------------------------------------------------------------ context
-int cb_ctx_create(int device, void* hip_stream, cb_ctx** out) {
+int cb_ctx_create(int device, void* hip_stream, cb_ctx** out) { return cb_ctx_create_dtype(device, hip_stream, CB_DTYPE_F32, out); }
+int cb_ctx_dtype(cb_ctx* ctx, int* dtype) {
+    CB_TRY
+    require(ctx, "ctx"); require(dtype, "dtype");
+    *dtype = (int)ctx->c.dtype;
+    CB_END
+}
+int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
     CB_TRY
     require(out, "out");
+    CB_CHECK(dtype == CB_DTYPE_F32 || dtype == CB_DTYPE_BF16, CB_ERR_ARG, "unknown dtype %d (0 = f32, 1 = bf16)", dtype);
     std::unique_ptr<cb_ctx> h(new cb_ctx());
     Ctx& c = h->c;
+    c.dtype = c.load_dt = (DType)dtype;
     c.device = device;
     c.dry = device < 0;
     c.arena.dry = c.dry; c.pool.dry = c.dry;
@@ -95,11 +104,17 @@ int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems
     require(ctx, "ctx"); require(name, "name");
     auto it = ctx->c.taps.find(name);
     CB_CHECK(it != ctx->c.taps.end(), CB_ERR_MISSING, "no tap named '%s'", name);
-    if (numel) *numel = it->second.second;
+    if (numel) *numel = it->second.n;
     if (host_dst && !ctx->c.dry) {
-        int64_t n = std::min<int64_t>(max_elems, it->second.second);
+        int64_t n = std::min<int64_t>(max_elems, it->second.n);
         CB_HIP(hipStreamSynchronize(ctx->c.stream));
-        CB_HIP(hipMemcpy(host_dst, it->second.first, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        if (it->second.dt == DT_BF16) {        // taps are always handed out as fp32
+            std::vector<uint16_t> tmp((size_t)n);
+            CB_HIP(hipMemcpy(tmp.data(), it->second.p, (size_t)n * 2, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i) { uint32_t u = (uint32_t)tmp[(size_t)i] << 16; memcpy(host_dst + i, &u, 4); }
+        } else {
+            CB_HIP(hipMemcpy(host_dst, it->second.p, (size_t)n * sizeof(float), hipMemcpyDeviceToHost));
+        }
     }
     CB_END
 }
@@ -168,7 +183,9 @@ int cb_wtab_destroy(cb_wtab* wt) {
 int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d) {
     CB_TRY
     require(ctx, "ctx"); require(d, "desc");
+    CB_CHECK(d->dtype == CB_DTYPE_F32 || d->dtype == CB_DTYPE_BF16, CB_ERR_ARG, "gemm: unknown desc.dtype %d", d->dtype);
     GemmArgs a;
+    a.dt = (DType)d->dtype;
     a.A = d->A; a.B = d->B; a.C = d->C; a.M = d->M; a.N = d->N; a.K = d->K;
     a.lda = d->lda; a.ldb = d->ldb; a.ldc = d->ldc;
     a.a_kind = d->a_layout == CB_LD_COL ? LD_COL : LD_ROW;
@@ -180,95 +197,101 @@ int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d) {
     Ctx* c = &ctx->c;
     plan_and_run(c, [&]() {
         Launch L = c->launch();
-        size_t wsb = gemm_ws_bytes(a);
+        const bool bf = a.dt == DT_BF16;
+        size_t wsb = bf ? gemm_bf16_ws_bytes(a) : gemm_ws_bytes(a);
         float* ws = wsb ? static_cast<float*>(c->arena.alloc(wsb)) : nullptr;
-        gemm(L, a, ws, wsb);
+        if (bf) gemm_bf16(L, a, ws, wsb); else gemm(L, a, ws, wsb);
     });
     CB_END
 }
-int cb_pack_conv_weight(cb_ctx* ctx, const float* w, float* out, int O, int I, int ks, int dgrad) {
+static int pad8c(DType dt, int c) { return dt == DT_BF16 ? (c + 7) / 8 * 8 : c; }
+int cb_pack_conv_weight(cb_ctx* ctx, const float* w, void* out, int O, int I, int ks, int dgrad) {
     CB_TRY
     require(ctx, "ctx");
     Launch L = ctx->c.launch();
-    if (dgrad) k_pack_conv_dgrad(L, out, w, O, I, ks); else k_pack_conv(L, out, w, O, I, ks);
+    const DType dt = ctx->c.dtype;
+    if (dgrad) k_pack_conv_dgrad(L, dt, out, w, O, I, ks, pad8c(dt, O)); else k_pack_conv(L, dt, out, w, O, I, ks, pad8c(dt, I));
     CB_END
 }
-int cb_conv2d_fwd(cb_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* rowbias,
-                  const float* residual, float* y, int N, int H, int W, int Cin, int Cout, int ks, int mode) {
+int cb_conv2d_fwd(cb_ctx* ctx, const void* x, const void* w_packed, const float* bias, const void* rowbias,
+                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int ks, int mode) {
     CB_TRY
     require(ctx, "ctx");
     Ctx* c = &ctx->c;
-    Conv cv; cv.w = const_cast<float*>(w_packed); cv.b = const_cast<float*>(bias); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    const DType dt = c->dtype;
+    Conv cv; cv.w = const_cast<void*>(w_packed); cv.b = const_cast<float*>(bias); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    cv.dt = dt; cv.cin_p = pad8c(dt, Cin); cv.cout_p = pad8c(dt, Cout);
     plan_and_run(c, [&]() {
         Graph G(c);
-        Ten* xt = G.wrap(const_cast<float*>(x), N, H, W, Cin);
+        Ten* xt = G.wrap(x, N, H, W, Cin, false, dt);
         int Ho, Wo; ConvGeom g;
         conv_out_dims(cv, (ConvMode)mode, H, W, &Ho, &Wo, &g);
-        Ten* rb = rowbias ? G.wrap(const_cast<float*>(rowbias), N, 1, 1, Cout) : nullptr;
-        Ten* rs = residual ? G.wrap(const_cast<float*>(residual), N, Ho, Wo, Cout) : nullptr;
+        Ten* rb = rowbias ? G.wrap(rowbias, N, 1, 1, Cout, false, dt) : nullptr;
+        Ten* rs = residual ? G.wrap(residual, N, Ho, Wo, Cout, false, dt) : nullptr;
         Ten* o = G.conv(xt, cv, (ConvMode)mode, rb, rs);
-        k_axpby(G.L, y, o->p, o->numel(), 1.f, 0.f);
+        k_axpby(G.L, dt, y, o->p, o->numel(), 1.f, 0.f);
     });
     CB_END
 }
-int cb_conv2d_dgrad(cb_ctx* ctx, const float* dy, const float* wd, float* dx, int N, int H, int W, int Cin, int Cout, int ks,
+int cb_conv2d_dgrad(cb_ctx* ctx, const void* dy, const void* wd, void* dx, int N, int H, int W, int Cin, int Cout, int ks,
                     int mode, float beta) {
     CB_TRY
     require(ctx, "ctx");
     Ctx* c = &ctx->c;
-    Conv cv; cv.wd = const_cast<float*>(wd); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    Conv cv; cv.wd = const_cast<void*>(wd); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    cv.dt = c->dtype; cv.cin_p = pad8c(cv.dt, Cin); cv.cout_p = pad8c(cv.dt, Cout);
     plan_and_run(c, [&]() {
         Graph G(c);
         conv_dgrad(&G, dy, cv, (ConvMode)mode, N, H, W, dx, beta);
     });
     CB_END
 }
-int cb_groupnorm_silu_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats, int N,
+int cb_groupnorm_silu_fwd(cb_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats, int N,
                           int HW, int C, float eps, int silu) {
     CB_TRY
     require(ctx, "ctx");
     Ctx* c = &ctx->c;
     plan_and_run(c, [&]() {
         float* ws = c->arena.allocf(gn_ws_floats(N, HW, C, 32) + (size_t)N * 64);
-        k_groupnorm_fwd(c->launch(), y, x, gamma, beta, stats, ws, N, HW, C, 32, eps, silu);
+        k_groupnorm_fwd(c->launch(), c->dtype, y, x, gamma, beta, stats, ws, N, HW, C, 32, eps, silu);
     });
     CB_END
 }
-int cb_groupnorm_silu_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* beta,
-                          const float* stats, float* dx, int N, int HW, int C, int silu, float acc_beta) {
+int cb_groupnorm_silu_bwd(cb_ctx* ctx, const void* x, const void* dy, const float* gamma, const float* beta,
+                          const float* stats, void* dx, int N, int HW, int C, int silu, float acc_beta) {
     CB_TRY
     require(ctx, "ctx");
     Ctx* c = &ctx->c;
     plan_and_run(c, [&]() {
         float* ws = c->arena.allocf(gn_ws_floats(N, HW, C, 32) + (size_t)N * 64);
-        k_groupnorm_bwd(c->launch(), dx, x, dy, gamma, beta, stats, ws, N, HW, C, 32, silu, acc_beta);
+        k_groupnorm_bwd(c->launch(), c->dtype, dx, x, dy, gamma, beta, stats, ws, N, HW, C, 32, silu, acc_beta);
     });
     CB_END
 }
-int cb_layernorm_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats, int64_t rows,
+int cb_layernorm_fwd(cb_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats, int64_t rows,
                      int C, float eps) {
     CB_TRY
     require(ctx, "ctx");
-    k_layernorm_fwd(ctx->c.launch(), y, x, gamma, beta, stats, rows, C, eps);
+    k_layernorm_fwd(ctx->c.launch(), ctx->c.dtype, y, x, gamma, beta, stats, rows, C, eps);
     CB_END
 }
-int cb_layernorm_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* stats, float* dx,
+int cb_layernorm_bwd(cb_ctx* ctx, const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
                      int64_t rows, int C, float acc_beta) {
     CB_TRY
     require(ctx, "ctx");
-    k_layernorm_bwd(ctx->c.launch(), dx, x, dy, gamma, stats, rows, C, acc_beta);
+    k_layernorm_bwd(ctx->c.launch(), ctx->c.dtype, dx, x, dy, gamma, stats, rows, C, acc_beta);
     CB_END
 }
-int cb_geglu_fwd(cb_ctx* ctx, const float* x, float* y, int64_t M, int D) {
+int cb_geglu_fwd(cb_ctx* ctx, const void* x, void* y, int64_t M, int D) {
     CB_TRY
     require(ctx, "ctx");
-    k_geglu_fwd(ctx->c.launch(), y, x, M, D);
+    k_geglu_fwd(ctx->c.launch(), ctx->c.dtype, y, x, M, D);
     CB_END
 }
-int cb_geglu_bwd(cb_ctx* ctx, const float* x, const float* dy, float* dx, int64_t M, int D) {
+int cb_geglu_bwd(cb_ctx* ctx, const void* x, const void* dy, void* dx, int64_t M, int D) {
     CB_TRY
     require(ctx, "ctx");
-    k_geglu_bwd(ctx->c.launch(), dx, x, dy, M, D);
+    k_geglu_bwd(ctx->c.launch(), ctx->c.dtype, dx, x, dy, M, D);
     CB_END
 }
 int cb_attention(cb_ctx* ctx, const cb_attention_desc* d) {
@@ -277,15 +300,17 @@ int cb_attention(cb_ctx* ctx, const cb_attention_desc* d) {
     Ctx* c = &ctx->c;
     const bool bwd = d->dout != nullptr;
     if (bwd) CB_CHECK(d->dqbuf && d->dkvbuf, CB_ERR_ARG, "attention: backward needs dqbuf and dkvbuf");
+    CB_CHECK(d->dtype == CB_DTYPE_F32 || d->dtype == CB_DTYPE_BF16, CB_ERR_ARG, "attention: unknown desc.dtype %d", d->dtype);
+    const DType dt = (DType)d->dtype;
     plan_and_run(c, [&]() {
         Graph G(c);
-        Ten* qt = G.wrap(const_cast<float*>(d->qbuf), d->B, d->Nq, 1, (int)d->ldq, bwd);
-        Ten* kt = (d->kvbuf == d->qbuf) ? qt : G.wrap(const_cast<float*>(d->kvbuf), d->B, d->Nk, 1, (int)d->ldkv, bwd);
+        Ten* qt = G.wrap(d->qbuf, d->B, d->Nq, 1, (int)d->ldq, bwd, dt);
+        Ten* kt = (d->kvbuf == d->qbuf) ? qt : G.wrap(d->kvbuf, d->B, d->Nk, 1, (int)d->ldkv, bwd, dt);
         Ten* o = G.attention(qt, d->q_off, kt, d->k_off, d->v_off, d->C, d->heads, d->scale, d->causal != 0);
-        k_axpby(G.L, d->out, o->p, o->numel(), 1.f, 0.f);
+        k_axpby(G.L, dt, d->out, o->p, o->numel(), 1.f, 0.f);
         if (bwd) {
-            float beta; float* go = G.grad(o, &beta);
-            k_axpby(G.L, go, d->dout, o->numel(), 1.f, 0.f);
+            float beta; void* go = G.grad(o, &beta);
+            k_axpby(G.L, dt, go, d->dout, o->numel(), 1.f, 0.f);
             qt->g = d->dqbuf;
             if (kt != qt) kt->g = d->dkvbuf;
             G.backward();
@@ -293,23 +318,23 @@ int cb_attention(cb_ctx* ctx, const cb_attention_desc* d) {
     });
     CB_END
 }
-int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, float* out, int B, int dim) {
+int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, void* out, int B, int dim) {
     CB_TRY
     require(ctx, "ctx");
-    k_timestep_embedding(ctx->c.launch(), out, t, B, dim);
+    k_timestep_embedding(ctx->c.launch(), ctx->c.dtype, out, t, B, dim);
     CB_END
 }
-int cb_q_sample(cb_ctx* ctx, const float* x0, const float* eps, const int64_t* t, const float* sa, const float* sb, float* xt, int B,
+int cb_q_sample(cb_ctx* ctx, const void* x0, const float* eps, const int64_t* t, const float* sa, const float* sb, void* xt, int B,
                 int C, int HW) {
     CB_TRY
     require(ctx, "ctx");
-    k_qsample(ctx->c.launch(), xt, x0, eps, t, sa, sb, B, C, HW);
+    k_qsample(ctx->c.launch(), ctx->c.dtype, xt, x0, eps, t, sa, sb, B, C, HW);
     CB_END
 }
-int cb_mse_loss(cb_ctx* ctx, const float* pred, const float* target, float* loss, float* dpred, int B, int C, int HW) {
+int cb_mse_loss(cb_ctx* ctx, const void* pred, const float* target, float* loss, void* dpred, int B, int C, int HW) {
     CB_TRY
     require(ctx, "ctx");
-    k_mse_loss(ctx->c.launch(), loss, dpred, pred, target, B, C, HW);
+    k_mse_loss(ctx->c.launch(), ctx->c.dtype, loss, dpred, pred, target, B, C, HW);
     CB_END
 }
 int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size) {
@@ -333,13 +358,13 @@ int cb_celeb_head_forward(cb_ctx* ctx, const float* feat, const float* W, const 
     plan_and_run(c, [&]() {
         Graph G(c);
         const int O = es * K;
-        Ten* v = G.make(N, 1, 1, I);
-        k_l2norm_fwd(G.L, v->p, nullptr, feat, N, I);
+        Ten* v = G.make(N, 1, 1, I, false, DT_F32);
+        k_l2norm_fwd(G.L, v->pf(), nullptr, feat, N, I);
         Lin head; head.w = const_cast<float*>(W); head.b = const_cast<float*>(b); head.in = I; head.out = O;
         Ten* pre = G.linear(v, head);
-        Ten* act = G.make(N, 1, 1, O);
-        k_leakyrelu_fwd(G.L, act->p, pre->p, act->numel(), 0.2f);
-        k_l2norm_fwd(G.L, coef, nullptr, act->p, (long)N * es, K);
+        Ten* act = G.make(N, 1, 1, O, false, DT_F32);
+        k_leakyrelu_fwd(G.L, act->pf(), pre->pf(), act->numel(), 0.2f);
+        k_l2norm_fwd(G.L, coef, nullptr, act->pf(), (long)N * es, K);
         k_basis_fwd(G.L, z, coef, basis, N, es, K, Wd);
     });
     CB_END
@@ -384,16 +409,16 @@ int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int
     k_adamw(L, p, m, v, g, n, step_dev, lr, b1, b2, eps, wd);
     CB_END
 }
-int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W) {
+int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, void* dst, int N, int C, int H, int W) {
     CB_TRY
     require(ctx, "ctx");
-    k_nchw_to_nhwc(ctx->c.launch(), dst, src, N, C, H, W);
+    k_nchw_to_nhwc(ctx->c.launch(), ctx->c.dtype, dst, src, N, C, H, W);
     CB_END
 }
-int cb_nhwc_to_nchw(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W) {
+int cb_nhwc_to_nchw(cb_ctx* ctx, const void* src, float* dst, int N, int C, int H, int W) {
     CB_TRY
     require(ctx, "ctx");
-    k_nhwc_to_nchw(ctx->c.launch(), dst, src, N, C, H, W);
+    k_nhwc_to_nchw(ctx->c.launch(), ctx->c.dtype, dst, src, N, C, H, W);
     CB_END
 }
 
@@ -443,11 +468,12 @@ int cb_unet_forward(cb_unet* u, const float* x_nchw, const int64_t* t, const flo
     plan_and_run(c, [&]() {
         u->G.reset(new Graph(c));
         Graph& G = *u->G;
-        Ten* x = G.make(B, H, W, u->U.cfg.in_channels);
-        k_nchw_to_nhwc(G.L, x->p, x_nchw, B, u->U.cfg.in_channels, H, W);
-        Ten* cx = G.wrap(const_cast<float*>(context), B, L, 1, u->U.cfg.context_dim, need_grad != 0);
-        Ten* o = unet_forward(G, u->U, x, t, cx);
-        k_nhwc_to_nchw(G.L, eps_nchw, o->p, B, u->U.cfg.out_channels, H, W);
+        const DType dt = u->U.dt;
+        Ten* x = G.make(B, H, W, u->U.cfg.in_channels, false, dt);
+        k_nchw_to_nhwc(G.L, dt, x->p, x_nchw, B, u->U.cfg.in_channels, H, W);
+        Ten* cx = G.wrap(context, B, L, 1, u->U.cfg.context_dim, need_grad != 0, DT_F32);      // the public context is fp32
+        Ten* o = unet_forward(G, u->U, x, t, G.cast(cx, dt));
+        k_nhwc_to_nchw(G.L, dt, eps_nchw, o->p, B, u->U.cfg.out_channels, H, W);
         u->out = o; u->context = cx;
         if (c->dry && need_grad) { float beta; G.grad(o, &beta); G.backward(); }   // size the arena for the backward as well
     });
@@ -458,11 +484,11 @@ int cb_unet_backward_context(cb_unet* u, const float* deps_nchw, float* dcontext
     require(u, "unet");
     CB_CHECK(u->G && u->out && u->context && u->context->rg, CB_ERR_STATE, "unet backward: call cb_unet_forward(need_grad=1) first");
     Graph& G = *u->G;
-    float beta; float* go = G.grad(u->out, &beta);
-    k_nchw_to_nhwc(G.L, go, deps_nchw, u->B, u->U.cfg.out_channels, u->H, u->W);
+    float beta; void* go = G.grad(u->out, &beta);
+    k_nchw_to_nhwc(G.L, u->out->dt, go, deps_nchw, u->B, u->U.cfg.out_channels, u->H, u->W);
     G.backward();
     if (!u->ctx->dry) CB_CHECK(u->context->ginit, CB_ERR_STATE, "unet backward: no gradient reached the context");
-    if (u->context->g) k_axpby(G.L, dcontext, u->context->g, u->context->numel(), 1.f, 0.f);
+    if (u->context->g) k_axpby(G.L, dcontext, static_cast<const float*>(u->context->g), u->context->numel(), 1.f, 0.f);
     CB_END
 }
 
@@ -488,7 +514,7 @@ int cb_ddim_update(cb_ctx* ctx, float* x_nchw, const float* eps_nchw, const floa
     Launch L = ctx->c.launch();
     DdimCoef k = ddim_coef(a_t, a_prev, sigma_t);
     // elementwise, so the NCHW buffers can be walked linearly (C=1 decode keeps the noise index identical)
-    k_ddim_update(L, x_nchw, pred_x0_nchw, eps_nchw, noise_nchw, n, 1, C * HW, cfg_rows != 0, guidance_scale, sqrt_one_minus_at,
+    k_ddim_update(L, DT_F32, x_nchw, pred_x0_nchw, eps_nchw, noise_nchw, n, 1, C * HW, cfg_rows != 0, guidance_scale, sqrt_one_minus_at,
                   k.sqrt_at, k.sqrt_aprev, k.dir, sigma_t);
     CB_END
 }
@@ -508,40 +534,42 @@ int cb_unet_ddim_sample(cb_unet* u, float* x_nchw, const float* cond, const floa
     const int Bn = cfg ? 2 * n : n;
     const long per = (long)n * H * W * Cx;
     // loop-carried buffers live at the bottom of the step arena; every iteration rewinds the arena to `mark`
+    // the sampler state x (and pred_x0) stays fp32 across the steps; the UNet input / context / output are in the UNet's dtype
+    const DType dt = u->U.dt;
     Ten X, XIN, CIN, P0;
     Ten *x = &X, *xin = &XIN, *cin = &CIN, *p0 = &P0;
-    auto shape = [](Ten* t, int n_, int h_, int w_, int c_) { t->n = n_; t->h = h_; t->w = w_; t->c = c_; };
-    shape(x, n, H, W, Cx); shape(xin, Bn, H, W, Cx); shape(p0, n, H, W, Cx); shape(cin, Bn, L, 1, D);
+    auto shape = [](Ten* t, int n_, int h_, int w_, int c_, DType d_) { t->n = n_; t->h = h_; t->w = w_; t->c = c_; t->dt = d_; };
+    shape(x, n, H, W, Cx, DT_F32); shape(xin, Bn, H, W, Cx, dt); shape(p0, n, H, W, Cx, DT_F32); shape(cin, Bn, L, 1, D, dt);
     int64_t* tin = nullptr;
     size_t mark = 0;
     auto iteration = [&](int i) {
         const int index = S - 1 - i;                                       // ddim.py:141
         Graph G(c);
         k_fill_i64(G.L, tin, Bn, timesteps[index]);
-        k_axpby(G.L, xin->p, x->p, per, 1.f, 0.f);
-        if (cfg) k_axpby(G.L, xin->p + per, x->p, per, 1.f, 0.f);
+        k_convert(G.L, xin->p, dt, Cx, x->p, DT_F32, Cx, per / Cx);
+        if (cfg) k_convert(G.L, xin->at(per), dt, Cx, x->p, DT_F32, Cx, per / Cx);
         Ten* e = unet_forward(G, u->U, xin, tin, cin);
         DdimCoef k = ddim_coef(alphas[index], alphas_prev[index], sigmas[index]);
         const float* nz = (noise_nchw && sigmas[index] != 0.f) ? noise_nchw + (long)i * per : nullptr;
-        k_ddim_update(G.L, x->p, (pred_x0_nchw && i == S - 1) ? p0->p : nullptr, e->p, nz, n, Cx, H * W, cfg, guidance_scale,
+        k_ddim_update(G.L, dt, x->pf(), (pred_x0_nchw && i == S - 1) ? p0->pf() : nullptr, e->p, nz, n, Cx, H * W, cfg, guidance_scale,
                       sqrt_one_minus_alphas[index], k.sqrt_at, k.sqrt_aprev, k.dir, sigmas[index]);
     };
     plan_and_run(c, [&]() {
         Launch L0 = c->launch();
-        x->p = c->arena.allocf((size_t)x->numel()); xin->p = c->arena.allocf((size_t)xin->numel());
-        p0->p = c->arena.allocf((size_t)p0->numel()); cin->p = c->arena.allocf((size_t)cin->numel());
+        x->p = c->arena.alloc(x->bytes()); xin->p = c->arena.alloc(xin->bytes());
+        p0->p = c->arena.alloc(p0->bytes()); cin->p = c->arena.alloc(cin->bytes());
         tin = static_cast<int64_t*>(c->arena.alloc(sizeof(int64_t) * (size_t)Bn));
-        k_nchw_to_nhwc(L0, x->p, x_nchw, n, Cx, H, W);
+        k_nchw_to_nhwc(L0, DT_F32, x->p, x_nchw, n, Cx, H, W);
         const long cn = (long)n * L * D;
-        if (cfg) { k_axpby(L0, cin->p, uncond, cn, 1.f, 0.f); k_axpby(L0, cin->p + cn, cond, cn, 1.f, 0.f); }   // cat([uc, c])
-        else k_axpby(L0, cin->p, cond, cn, 1.f, 0.f);
+        if (cfg) { k_convert(L0, cin->p, dt, D, uncond, DT_F32, D, cn / D); k_convert(L0, cin->at(cn), dt, D, cond, DT_F32, D, cn / D); }   // cat([uc, c])
+        else k_convert(L0, cin->p, dt, D, cond, DT_F32, D, cn / D);
         mark = c->arena.off;
         iteration(0);
     });
     for (int i = 1; i < S; ++i) { c->arena.off = mark; iteration(i); }
     Launch Lx = c->launch();
-    k_nhwc_to_nchw(Lx, x_nchw, x->p, n, Cx, H, W);
-    if (pred_x0_nchw) k_nhwc_to_nchw(Lx, pred_x0_nchw, p0->p, n, Cx, H, W);
+    k_nhwc_to_nchw(Lx, DT_F32, x_nchw, x->p, n, Cx, H, W);
+    if (pred_x0_nchw) k_nhwc_to_nchw(Lx, DT_F32, pred_x0_nchw, p0->p, n, Cx, H, W);
     CB_END
 }
 
@@ -567,14 +595,15 @@ int cb_vae_encode(cb_vae* v, const float* image, const float* post_noise, int B,
     Ctx* c = v->ctx;
     plan_and_run(c, [&]() {
         Graph G(c);
-        Ten* img = G.wrap(const_cast<float*>(image), B, H, W, v->V.cfg.in_channels);
+        const DType dt = v->V.dt;
+        Ten* img = G.cast(G.wrap(image, B, H, W, v->V.cfg.in_channels, false, DT_F32), dt);      // the dataset image is fp32 HWC
         Ten* mom = vae_encode_moments(G, v->V, img);
         const int zc = v->V.cfg.z_channels;
-        if (moments) k_axpby(G.L, moments, mom->p, mom->numel(), 1.f, 0.f);
+        if (moments) k_convert(G.L, moments, DT_F32, mom->c, mom->p, dt, mom->c, mom->rows());
         if (z_nchw) {
-            Ten* z = G.make(B, mom->h, mom->w, zc);
-            k_vae_sample(G.L, z->p, mom->p, post_noise, B, mom->h * mom->w, zc, scale);
-            k_nhwc_to_nchw(G.L, z_nchw, z->p, B, zc, mom->h, mom->w);
+            Ten* z = G.make(B, mom->h, mom->w, zc, false, dt);
+            k_vae_sample(G.L, dt, z->p, mom->p, post_noise, B, mom->h * mom->w, zc, scale);
+            k_nhwc_to_nchw(G.L, dt, z_nchw, z->p, B, zc, mom->h, mom->w);
         }
     });
     CB_END
@@ -603,11 +632,11 @@ int cb_vae_decode(cb_vae_dec* v, const float* z_nchw, int B, int h, int w, float
     plan_and_run(c, [&]() {
         Graph G(c);
         const int zc = v->V.cfg.z_channels;
-        Ten* z = G.make(B, h, w, zc);
-        k_nchw_to_nhwc(G.L, z->p, z_nchw, B, zc, h, w);
-        k_axpby(G.L, z->p, z->p, z->numel(), 1.f / scale_factor, 0.f);        // ddpm.py:772 z = 1/scale_factor * z
-        Ten* img = vae_decode(G, v->V, z);
-        k_image_out(G.L, image_nchw, img->p, B, img->c, img->h * img->w, to01);
+        Ten* z32 = G.make(B, h, w, zc, false, DT_F32);
+        k_nchw_to_nhwc(G.L, DT_F32, z32->p, z_nchw, B, zc, h, w);
+        k_axpby(G.L, z32->pf(), z32->pf(), z32->numel(), 1.f / scale_factor, 0.f);        // ddpm.py:772 z = 1/scale_factor * z
+        Ten* img = vae_decode(G, v->V, G.cast(z32, v->V.dt));
+        k_image_out(G.L, img->dt, image_nchw, img->p, B, img->c, img->h * img->w, to01);
     });
     CB_END
 }
@@ -640,9 +669,9 @@ int cb_clip_forward(cb_clip* k, const float* embedded, int B, int L, float* hidd
     plan_and_run(c, [&]() {
         k->G.reset(new Graph(c));
         Graph& G = *k->G;
-        Ten* e = G.wrap(const_cast<float*>(embedded), B, L, 1, k->C.cfg.width, need_grad != 0);
+        Ten* e = G.wrap(embedded, B, L, 1, k->C.cfg.width, need_grad != 0, DT_F32);
         Ten* o = clip_encode(G, k->C, e);
-        k_axpby(G.L, hidden, o->p, o->numel(), 1.f, 0.f);
+        k_convert(G.L, hidden, DT_F32, o->c, o->p, o->dt, o->c, o->rows());
         k->out = o; k->in = e;
         if (c->dry && need_grad) { float beta; G.grad(o, &beta); G.backward(); }
     });
@@ -653,10 +682,10 @@ int cb_clip_backward_embeds(cb_clip* k, const float* dhidden, float* dembedded) 
     require(k, "clip");
     CB_CHECK(k->G && k->out && k->in && k->in->rg, CB_ERR_STATE, "clip backward: call cb_clip_forward(need_grad=1) first");
     Graph& G = *k->G;
-    float beta; float* go = G.grad(k->out, &beta);
-    k_axpby(G.L, go, dhidden, k->out->numel(), 1.f, 0.f);
+    float beta; void* go = G.grad(k->out, &beta);
+    k_convert(G.L, go, k->out->dt, k->out->c, dhidden, DT_F32, k->out->c, k->out->rows());
     G.backward();
-    if (k->in->g) k_axpby(G.L, dembedded, k->in->g, k->in->numel(), 1.f, 0.f);
+    if (k->in->g) k_axpby(G.L, dembedded, static_cast<const float*>(k->in->g), k->in->numel(), 1.f, 0.f);
     CB_END
 }
 
@@ -680,12 +709,12 @@ int cb_frnet_forward(cb_frnet* f, const float* img, int N, float* features) {
     CB_TRY
     require(f, "frnet");
     Ctx* c = f->ctx;
-    CB_CHECK(N >= 1 && N <= 8, CB_ERR_ARG, "frnet: N=%d must be in 1..8", N);
+    CB_CHECK(N >= 1 && N <= 16, CB_ERR_ARG, "frnet: N=%d must be in 1..16", N);
     plan_and_run(c, [&]() {
         Graph G(c);
-        Ten* x = G.wrap(const_cast<float*>(img), N, f->F.in_size, f->F.in_size, 3);
+        Ten* x = G.wrap(img, N, f->F.in_size, f->F.in_size, 3, false, DT_F32);
         Ten* o = frnet_forward(G, f->F, x);
-        k_axpby(G.L, features, o->p, o->numel(), 1.f, 0.f);
+        k_axpby(G.L, features, o->pf(), o->numel(), 1.f, 0.f);
     });
     CB_END
 }
@@ -710,6 +739,7 @@ int cb_trainer_cfg_default(cb_trainer_cfg* cfg) {
     cfg->momentum = 0.99f; cfg->scale_factor = 0.18215f; cfg->linear_start = 0.00085f; cfg->linear_end = 0.012f; cfg->timesteps = 1000;
     cfg->placeholder_token = 48136;
     cfg->adam_b1 = 0.9f; cfg->adam_b2 = 0.999f; cfg->adam_eps = 1e-8f; cfg->weight_decay = 1e-2f;
+    cfg->dtype = CB_DTYPE_F32;
     CB_END
 }
 int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg, cb_trainer** out) {
@@ -725,6 +755,8 @@ int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg,
     tc.adam_b1 = cfg->adam_b1; tc.adam_b2 = cfg->adam_b2; tc.adam_eps = cfg->adam_eps; tc.weight_decay = cfg->weight_decay;
     CB_CHECK(tc.image_size % 8 == 0 && tc.es >= 1 && tc.inner_dim >= 1 && tc.max_ids >= 1 && tc.timesteps >= 1, CB_ERR_ARG,
              "trainer cfg: bad sizes");
+    CB_CHECK(cfg->dtype == (int)ctx->c.dtype, CB_ERR_ARG, "trainer cfg: dtype %d differs from the context's %d (create the context with "
+             "cb_ctx_create_dtype)", cfg->dtype, (int)ctx->c.dtype);
     std::unique_ptr<cb_trainer> t(new cb_trainer());
     t->ctx = &ctx->c;
     trainer_load(&ctx->c, wt->t, tc, &t->T);

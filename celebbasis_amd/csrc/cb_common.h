@@ -31,6 +31,16 @@ inline void fail(int code, const char* fmt, ...) {
 #define CB_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) \
     ::cb::fail(::cb::CB_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
+// ---------------------------------------------------------------- element types
+// Activations and frozen weights of UNet / VAE / CLIP are stored either as fp32 (BASELINE config 2: the reference's own
+// arithmetic) or as bf16 (config 3: bf16 storage + bf16 MFMA with fp32 accumulation; normalisation statistics, softmax, the
+// coefficient head, its gradient and AdamW stay fp32). A tensor's element type travels with it (Ten::dt, GemmArgs::dt, ...).
+enum DType { DT_F32 = 0, DT_BF16 = 1 };
+typedef __bf16 bf16_t;
+inline size_t dt_size(DType d) { return d == DT_BF16 ? 2 : 4; }
+inline void* ptr_off(void* p, DType dt, long elems) { return static_cast<char*>(p) + elems * (long)dt_size(dt); }
+inline const void* ptr_off(const void* p, DType dt, long elems) { return static_cast<const char*>(p) + elems * (long)dt_size(dt); }
+
 // ---------------------------------------------------------------- launch context
 // Every kernel launcher takes a Launch. In dry mode (no device) launchers only do shape checks and
 // accounting: this is how the host-side graph logic is tested on a box without a GPU.
@@ -86,7 +96,8 @@ struct ConvGeom {
 // ---------------------------------------------------------------- GEMM arguments
 enum { LD_ROW = 0, LD_COL = 1, LD_CONV = 2, LD_CONVF = 3 /* kernel-internal: conv with the scalar tap walk (cb_gemm.hip) */ };
 struct GemmArgs {
-    const float* A = nullptr; const float* B = nullptr; float* C = nullptr;
+    DType dt = DT_F32;          // element type of A, B, C, R and rowbias (bias is always fp32; split-K partials are fp32)
+    const void* A = nullptr; const void* B = nullptr; void* C = nullptr;
     int M = 0, N = 0, K = 0;
     long lda = 0, ldb = 0, ldc = 0;
     int a_kind = LD_ROW, b_kind = LD_ROW;
@@ -95,81 +106,96 @@ struct GemmArgs {
     long sAb = 0, sAh = 0, sBb = 0, sBh = 0, sCb = 0, sCh = 0;
     // epilogue: C = alpha*acc + bias[n] + rowbias[m / rows_per_img][n] + R[m][n] + beta*C
     const float* bias = nullptr;
-    const float* rowbias = nullptr; int rows_per_img = 1; long ld_rowbias = 0;   // ld 0 = N
-    const float* R = nullptr; long ldr = 0; long sRb = 0, sRh = 0;
+    const void* rowbias = nullptr; int rows_per_img = 1; long ld_rowbias = 0;   // ld 0 = N
+    const void* R = nullptr; long ldr = 0; long sRb = 0, sRh = 0;
     float alpha = 1.f, beta = 0.f;
     ConvGeom g;
 };
 
 void gemm(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
 size_t gemm_ws_bytes(const GemmArgs& a);
+// bf16 twin (cb_gemm_bf16.hip): k-contiguous operands only (ROW / CONV x ROW), 16-byte aligned, K % 8 == 0
+void gemm_bf16(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
+size_t gemm_bf16_ws_bytes(const GemmArgs& a);
 
 // ---------------------------------------------------------------- fused attention (cb_flash.hip)
 struct FlashArgs {
-    const float* q = nullptr; long ldq = 0, sqb = 0, sqh = 0;
-    const float* k = nullptr; const float* v = nullptr; long ldk = 0, skb = 0, skh = 0;
-    float* o = nullptr; long ldo = 0, sob = 0, soh = 0;
+    DType dt = DT_F32;               // element type of q, k, v, o, dout, dq, dk, dv (lse, dvec and the workspace are fp32)
+    const void* q = nullptr; long ldq = 0, sqb = 0, sqh = 0;
+    const void* k = nullptr; const void* v = nullptr; long ldk = 0, skb = 0, skh = 0;
+    void* o = nullptr; long ldo = 0, sob = 0, soh = 0;
     float* lse = nullptr;            // [B*H][Nq]
     int H = 1, Nq = 0, Nk = 0, d = 0;
     float scale = 1.f; int causal = 0;
-    const float* dout = nullptr;     // layout of o
+    const void* dout = nullptr;      // layout of o
     float* dvec = nullptr;           // [B*H][Nq]  rowsum(dO * O)
-    float* dq = nullptr; float beta_q = 0.f;                      // layout of q
-    float* dk = nullptr; float* dv = nullptr; float beta_kv = 0.f; // layout of k / v
+    void* dq = nullptr; float beta_q = 0.f;                      // layout of q
+    void* dk = nullptr; void* dv = nullptr; float beta_kv = 0.f; // layout of k / v
     float* ws = nullptr; int nsplit = 1;   // dK/dV query-split partials [2][nsplit][B*H][Nk][d] (cross-attention: few keys, many queries)
 };
 size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
 bool flash_supported(int d, const FlashArgs& a);
 void flash_forward(const Launch& L, const FlashArgs& a, int B);
 void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv);
+// bf16 twins (cb_flash_bf16.hip): d % 8 == 0, d <= 160
+size_t flash_bf16_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
+bool flash_bf16_supported(int d, const FlashArgs& a);
+void flash_bf16_forward(const Launch& L, const FlashArgs& a, int B);
+void flash_bf16_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv);
 
 // ---------------------------------------------------------------- other kernels (cb_kernels.hip)
-void k_fill(const Launch& L, float* p, long n, float v);
-void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b);          // dst = a*src + b*dst
-void k_add(const Launch& L, float* dst, const float* x, const float* y, long n);
-void k_copy2d(const Launch& L, float* dst, long ldd, const float* src, long lds, long rows, int cols, float beta);
-void k_silu(const Launch& L, float* dst, const float* src, long n);
-void k_geglu_fwd(const Launch& L, float* y, const float* x, long M, int D);
-void k_geglu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long M, int D);
-void k_quickgelu_fwd(const Launch& L, float* y, const float* x, long n);
-void k_quickgelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float beta);
+// Launchers whose tensors are activations take the element type `dt` of those tensors (void pointers); parameters, statistics,
+// workspaces, losses and everything of the coefficient head are fp32 and keep typed pointers.
+void k_fill(const Launch& L, DType dt, void* p, long n, float v);
+void k_axpby(const Launch& L, DType dt, void* dst, const void* src, long n, float a, float b);          // dst = a*src + b*dst
+void k_copy2d(const Launch& L, DType dt, void* dst, long ldd, const void* src, long lds, long rows, int cols, float beta);
+// dst[rows][cols_dst] = src[rows][cols_src] (+ zero columns) with a change of element type: fp32 <-> bf16 casts at the edges of
+// the bf16 graph, and the channel padding (3 or 4 -> 8) that gives the first convolutions 16-byte rows
+void k_convert(const Launch& L, void* dst, DType ddt, int cols_dst, const void* src, DType sdt, int cols_src, long rows, float beta = 0.f);
+void k_transpose(const Launch& L, DType dt, void* dst, const void* src, int batch, int rows, int cols, long ld_src, long sb_src);  // dst[b][cols][rows]
+void k_silu(const Launch& L, DType dt, void* dst, const void* src, long n);
+void k_geglu_fwd(const Launch& L, DType dt, void* y, const void* x, long M, int D);
+void k_geglu_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, long M, int D);
+void k_quickgelu_fwd(const Launch& L, DType dt, void* y, const void* x, long n);
+void k_quickgelu_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, long n, float beta);
 void k_leakyrelu_fwd(const Launch& L, float* y, const float* x, long n, float slope);
 void k_leakyrelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float slope);
-void k_nchw_to_nhwc(const Launch& L, float* dst, const float* src, int N, int C, int H, int W);
-void k_nhwc_to_nchw(const Launch& L, float* dst, const float* src, int N, int C, int H, int W);
+void k_nchw_to_nhwc(const Launch& L, DType ddt, void* dst, const float* src, int N, int C, int H, int W);   // public NCHW tensors are fp32
+void k_nhwc_to_nchw(const Launch& L, DType sdt, float* dst, const void* src, int N, int C, int H, int W);
 void k_channel_affine(const Launch& L, float* y, const float* x, const float* scale, const float* shift,
                       const float* prelu, long rows, int C);
-void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H, int W, int C, float beta);
+void k_upsample2x_bwd(const Launch& L, DType dt, void* dx, const void* dy, int N, int H, int W, int C, float beta);
 
-// GroupNorm (NHWC, G groups). stats = [N][G][2] (mean, rstd). partial ws sized gn_ws_floats().
+// GroupNorm (NHWC, G groups). stats = [N][G][2] (mean, rstd). partial ws sized gn_ws_floats(). x, y, dy, dx are `dt`.
 size_t gn_ws_floats(int N, int HW, int C, int G);
-void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
+void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta,
                      float* stats, float* ws, int N, int HW, int C, int G, float eps, int silu);
-void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
+void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma, const float* beta,
                      const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta, bool chn_valid = false);
 // LayerNorm over last dim C; stats = [rows][2]
-void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta,
+void k_layernorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta,
                      float* stats, long rows, int C, float eps);
-void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma,
+void k_layernorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma,
                      const float* stats, long rows, int C, float acc_beta);
 // softmax over rows of length n (leading dim ld), in place. causal: row i (mod rows_per_mat) sees cols <= i.
-void k_softmax_fwd(const Launch& L, float* S, long rows, int n, int ld, int causal, int rows_per_mat);
-// dS = scale * P * (dP - sum(dP*P)), in place in dP
+void k_softmax_fwd(const Launch& L, DType dt, void* S, long rows, int n, int ld, int causal, int rows_per_mat);
+// dS = scale * P * (dP - sum(dP*P)), in place in dP (fp32 materialised path only)
 void k_softmax_bwd(const Launch& L, float* dP, const float* P, long rows, int n, int ld, float scale);
 
 // diffusion-specific
-void k_timestep_embedding(const Launch& L, float* out, const int64_t* t, int B, int dim);
-void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nchw, const int64_t* t,
+void k_timestep_embedding(const Launch& L, DType dt, void* out, const int64_t* t, int B, int dim);
+void k_qsample(const Launch& L, DType dt, void* xt, const void* x0, const float* eps_nchw, const int64_t* t,
                const float* sqrt_ac, const float* sqrt_1mac, int B, int C, int HW);
-void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw,
+void k_mse_loss(const Launch& L, DType dt, float* loss, void* dpred, const void* pred, const float* target_nchw,
                 int B, int C, int HW);
-void k_ddim_update(const Launch& L, float* x, float* pred_x0, const float* eps, const float* noise_nchw, int n, int C, int HW,
+// x and pred_x0 are the fp32 sampler state; eps is the UNet output (`dt`)
+void k_ddim_update(const Launch& L, DType dt, float* x, float* pred_x0, const void* eps, const float* noise_nchw, int n, int C, int HW,
                    int cfg, float scale, float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma);
 void k_fill_i64(const Launch& L, int64_t* p, long n, int64_t v);
-void k_image_out(const Launch& L, float* dst_nchw, const float* src_nhwc, int N, int C, int HW, int to01);
-void k_vae_sample(const Launch& L, float* z, const float* moments, const float* noise_nchw, int B, int HW, int Cz, float scale);
+void k_image_out(const Launch& L, DType sdt, float* dst_nchw, const void* src_nhwc, int N, int C, int HW, int to01);
+void k_vae_sample(const Launch& L, DType dt, void* z, const void* moments, const float* noise_nchw, int B, int HW, int Cz, float scale);
 void k_gather_rows(const Launch& L, float* out, const float* table, const int64_t* idx, long rows, int C, long table_rows);
-void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* pos, long rows, int period, int C);
+void k_add_rowbcast(const Launch& L, DType dt, void* dst, const void* x, const float* pos, long rows, int period, int C);
 // face pre-processing (meta_net.py:250-260)
 void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* theta);
 void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C);
@@ -177,7 +203,7 @@ void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, i
 size_t face_augment_ws_floats(int B);
 void k_face_augment(const Launch& L, float* out, const float* in, const float* params_dev, float* ws, int B, int S);
 void k_paste_bg(const Launch& L, float* out, const float* img, const int* geom_dev, int B, int S, int C);
-// manager
+// manager (fp32)
 void k_l2norm_fwd(const Launch& L, float* y, float* norms, const float* x, long rows, int D);
 void k_l2norm_bwd(const Launch& L, float* dx, const float* y, const float* norms, const float* dy, long rows, int D);
 void k_basis_fwd(const Launch& L, float* z, const float* coef, const float* basis, int R, int E, int Kc, int Cz);
@@ -193,14 +219,19 @@ void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, cons
 void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step,
              float lr, float b1, float b2, float eps, float wd);
 void k_step_inc(const Launch& L, int* step);
-void k_gemv(const Launch& L, float* y, const float* x, const float* W, const float* bias, int M, int N, int K);
-// weight packing
-void k_pack_conv(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);          // -> [O][ky][kx][I]
-void k_pack_conv_dgrad(const Launch& L, float* out, const float* w_oihw, int O, int I, int ks);    // -> [I][ky'][kx'][O], flipped
+// y[M][N] = x[M][K] . W[N][K]^T + bias, M <= 8 (x, W, y are `dt`; bias fp32)
+void k_gemv(const Launch& L, DType dt, void* y, const void* x, const void* W, const float* bias, int M, int N, int K);
+// weight packing (source: the fp32 state-dict tensor; packs are `dt` with the channel counts padded to Ip / Op >= I / O)
+void k_pack_conv(const Launch& L, DType dt, void* out, const float* w_oihw, int O, int I, int ks, int Ip);          // -> [O][ky][kx][Ip]
+void k_pack_conv_dgrad(const Launch& L, DType dt, void* out, const float* w_oihw, int O, int I, int ks, int Op);   // -> [I][ky'][kx'][Op], flipped
 void k_pack_fc_nhwc(const Launch& L, float* out, const float* w, int O, int C, int HW);            // [O][C*HW] -> [O][HW*C]
 void k_fold_bn(const Launch& L, float* w_packed, float* bias_out, const float* bn_w, const float* bn_b,
                const float* bn_m, const float* bn_v, float eps, int O, long per_o);
 void k_bn_to_affine(const Launch& L, float* scale, float* shift, const float* w, const float* b, const float* m,
                     const float* v, float eps, int C);
+
+// fp32 conveniences for the coefficient head, the FR-net and the weight loaders
+inline void k_fill(const Launch& L, float* p, long n, float v) { k_fill(L, DT_F32, p, n, v); }
+inline void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b) { k_axpby(L, DT_F32, dst, src, n, a, b); }
 
 }  // namespace cb

@@ -67,27 +67,45 @@ struct Ctx {
     Stats stats;
     Profiler prof;
     bool debug_taps = false;
-    std::map<std::string, std::pair<const float*, long>> taps;
+    struct Tap { const void* p; long n; DType dt; };
+    std::map<std::string, Tap> taps;
+    // element type of the activations and frozen weights of the UNet / VAE / CLIP handles created on this context (fixed at
+    // creation: cb_ctx_create_dtype). The FR-net, the coefficient head, its gradient and AdamW are always fp32.
+    DType dtype = DT_F32;
+    DType load_dt = DT_F32;      // element type the weight loaders currently pack to (set by the *_load functions)
     Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; return L; }
     void ensure_arena(size_t bytes);
-    // upload a table entry to the device (raw copy); dims are checked against `expect` (-1 = any)
+    // upload a table entry to the device (raw fp32 copy); dims are checked against `expect` (-1 = any)
     float* upload(const WTab& wt, const std::string& name, std::initializer_list<int64_t> expect);
+    // a GEMM operand in load_dt made from a device fp32 matrix [rows][cols], columns zero-padded to cols_p
+    void* operand(const float* src, long rows, int cols, int cols_p);
     ~Ctx();
 };
 
 // ---------------------------------------------------------------- tensors and tape
 struct Ten {
-    float* p = nullptr;
-    float* g = nullptr;
+    void* p = nullptr;
+    void* g = nullptr;
     int n = 1, h = 1, w = 1, c = 1;   // NHWC; sequences are (n=B, h=L, w=1, c)
     bool rg = false;                  // requires grad
     bool ginit = false;               // g holds a value (first writer uses beta=0)
+    DType dt = DT_F32;                // element type of p and g
     long rows() const { return (long)n * h * w; }
     long numel() const { return rows() * c; }
+    float* pf() const { return static_cast<float*>(p); }             // fp32 tensors only
+    void* at(long elem) const { return ptr_off(p, dt, elem); }       // element offset into p
+    void* gat(long elem) const { return ptr_off(g, dt, elem); }
+    size_t bytes() const { return (size_t)numel() * dt_size(dt); }
 };
 
-struct Conv { float* w = nullptr; float* wd = nullptr; float* b = nullptr; int cin = 0, cout = 0, ks = 3; };
-struct Lin { float* w = nullptr; float* b = nullptr; int in = 0, out = 0; };
+// Frozen weights. `dt` is the element type of the GEMM operands (w, wd, wT); biases and norm parameters are always fp32.
+// bf16 operands must be 16-byte chunks of 8 channels: the packs of a conv whose channel count is not a multiple of 8 (the RGB /
+// latent ends of the networks) are zero-padded to cin_p / cout_p and the op pads the activation to match.
+struct Conv { void* w = nullptr; void* wd = nullptr; float* b = nullptr; int cin = 0, cout = 0, ks = 3;
+              DType dt = DT_F32; int cin_p = 0, cout_p = 0; };
+struct Lin { void* w = nullptr; float* b = nullptr; int in = 0, out = 0;
+             DType dt = DT_F32; int in_p = 0;
+             void* wT = nullptr; /* [in][out]: bf16 dgrad operand (the bf16 GEMM takes k-contiguous operands only) */ };
 struct Norm { float* g = nullptr; float* b = nullptr; int c = 0; float eps = 1e-5f; };
 
 enum ConvMode { CONV_SAME = 0, CONV_DOWN = 1, CONV_DOWN_ASYM = 2, CONV_UP = 3, CONV_S2_1x1 = 4 };
@@ -99,9 +117,10 @@ struct Graph {
     std::vector<std::function<void()>> tape;
     explicit Graph(Ctx* c) : ctx(c), L(c->launch()) {}
 
-    Ten* make(int n, int h, int w, int c, bool rg = false);
-    Ten* wrap(float* p, int n, int h, int w, int c, bool rg = false);   // external buffer
-    float* grad(Ten* t, float* beta);      // grad buffer for a writer; *beta = 0 on first write, 1 afterwards
+    Ten* make(int n, int h, int w, int c, bool rg, DType dt);
+    Ten* wrap(const void* p, int n, int h, int w, int c, bool rg, DType dt);   // external buffer
+    void* grad(Ten* t, float* beta);       // grad buffer for a writer; *beta = 0 on first write, 1 afterwards
+    Ten* cast(Ten* x, DType dt);           // element-type change (differentiable); returns x itself when the type already matches
     void tap(const std::string& name, const Ten* t);
     void backward();
 
@@ -123,7 +142,7 @@ struct Graph {
 
 // conv geometry / dgrad shared by the tape ops and the op-level C ABI
 void conv_out_dims(const Conv& cv, ConvMode mode, int H, int W, int* Ho, int* Wo, ConvGeom* g);
-void conv_dgrad(Graph* G, const float* dy, const Conv& cv, ConvMode mode, int N, int H, int W, float* dx, float beta);
+void conv_dgrad(Graph* G, const void* dy, const Conv& cv, ConvMode mode, int N, int H, int W, void* dx, float beta);
 
 // run fn once in dry mode to size the step arena, then for real (no-op split on a dry context)
 void plan_and_run(Ctx* ctx, const std::function<void()>& fn);

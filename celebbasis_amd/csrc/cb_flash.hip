@@ -111,9 +111,9 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = blockIdx.x * FL_ROWS;
     const int qrow = q0 + wave * 16 + l15;
-    const float* Q = a.q + b * a.sqb + h * a.sqh;
-    const float* K = a.k + b * a.skb + h * a.skh;
-    const float* V = a.v + b * a.skb + h * a.skh;
+    const float* Q = static_cast<const float*>(a.q) + b * a.sqb + h * a.sqh;
+    const float* K = static_cast<const float*>(a.k) + b * a.skb + h * a.skh;
+    const float* V = static_cast<const float*>(a.v) + b * a.skb + h * a.skh;
 
     // scores are kept in the log2 domain: q is pre-scaled by scale*log2(e) so that softmax needs a bare v_exp_f32
     float qreg[C::KS];
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     }
     if (qrow < a.Nq) {
         float inv = l > 0.f ? 1.f / l : 0.f;
-        float* O = a.o + b * a.sob + h * a.soh + (long)qrow * a.ldo;
+        float* O = static_cast<float*>(a.o) + b * a.sob + h * a.soh + (long)qrow * a.ldo;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             int c = t * 16 + quarter * 4;
@@ -211,8 +211,8 @@ __global__ __launch_bounds__(256) void flash_dvec_kernel(const FlashArgs a, int 
     if (w >= (long)BH * a.Nq) return;
     int lane = threadIdx.x & 63;
     int bh = (int)(w / a.Nq), qi = (int)(w - (long)bh * a.Nq), b = bh / a.H, h = bh - b * a.H;
-    const float* O = a.o + b * a.sob + h * a.soh + (long)qi * a.ldo;
-    const float* dO = a.dout + b * a.sob + h * a.soh + (long)qi * a.ldo;
+    const float* O = static_cast<const float*>(a.o) + b * a.sob + h * a.soh + (long)qi * a.ldo;
+    const float* dO = static_cast<const float*>(a.dout) + b * a.sob + h * a.soh + (long)qi * a.ldo;
     float s = 0.f;
     for (int c = lane; c < a.d; c += 64) s += O[c] * dO[c];
 #pragma unroll
@@ -231,10 +231,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = blockIdx.x * FL_ROWS;
     const int qrow = q0 + wave * 16 + l15;
-    const float* Q = a.q + b * a.sqb + h * a.sqh;
-    const float* K = a.k + b * a.skb + h * a.skh;
-    const float* V = a.v + b * a.skb + h * a.skh;
-    const float* dO = a.dout + b * a.sob + h * a.soh;
+    const float* Q = static_cast<const float*>(a.q) + b * a.sqb + h * a.sqh;
+    const float* K = static_cast<const float*>(a.k) + b * a.skb + h * a.skh;
+    const float* V = static_cast<const float*>(a.v) + b * a.skb + h * a.skh;
+    const float* dO = static_cast<const float*>(a.dout) + b * a.sob + h * a.soh;
 
     float qreg[C::KS], dreg[C::KS];
     fl_load_rowregs<DT>(qreg, Q, a.ldq, qrow, a.Nq, a.d, quarter, a.scale * 1.4426950408889634f);
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     const float lse = qrow < a.Nq ? a.lse[(long)bh * a.Nq + qrow] : 0.f;
     float Dq = 0.f;     // D = rowsum(dO * O), computed here and published for the dK/dV kernel that runs next
     {
-        const float* O = a.o + b * a.sob + h * a.soh;
+        const float* O = static_cast<const float*>(a.o) + b * a.sob + h * a.soh;
 #pragma unroll
         for (int s_ = 0; s_ < C::KS; ++s_) {
             int c = 4 * s_ + quarter;
@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
                 }
     }
     if (qrow < a.Nq) {
-        float* G = a.dq + b * a.sqb + h * a.sqh + (long)qrow * a.ldq;
+        float* G = static_cast<float*>(a.dq) + b * a.sqb + h * a.sqh + (long)qrow * a.ldq;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             int c = t * 16 + quarter * 4;
@@ -339,10 +339,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int k0 = blockIdx.x * FL_ROWS;
     const int krow = k0 + wave * 16 + l15;
-    const float* Q = a.q + b * a.sqb + h * a.sqh;
-    const float* K = a.k + b * a.skb + h * a.skh;
-    const float* V = a.v + b * a.skb + h * a.skh;
-    const float* dO = a.dout + b * a.sob + h * a.soh;
+    const float* Q = static_cast<const float*>(a.q) + b * a.sqb + h * a.sqh;
+    const float* K = static_cast<const float*>(a.k) + b * a.skb + h * a.skh;
+    const float* V = static_cast<const float*>(a.v) + b * a.skb + h * a.skh;
+    const float* dO = static_cast<const float*>(a.dout) + b * a.sob + h * a.soh;
 
     float kreg[C::KS], vreg[C::KS];
     fl_load_rowregs<DT>(kreg, K, a.ldk, krow, a.Nk, a.d, quarter, 1.f);
@@ -433,8 +433,8 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
         return;
     }
     if (krow < a.Nk) {
-        float* GK = a.dk + b * a.skb + h * a.skh + (long)krow * a.ldk;
-        float* GV = a.dv + b * a.skb + h * a.skh + (long)krow * a.ldk;
+        float* GK = static_cast<float*>(a.dk) + b * a.skb + h * a.skh + (long)krow * a.ldk;
+        float* GV = static_cast<float*>(a.dv) + b * a.skb + h * a.skh + (long)krow * a.ldk;
 #pragma unroll
         for (int t = 0; t < DT; ++t) {
             int c = t * 16 + quarter * 4;
@@ -471,8 +471,8 @@ __global__ __launch_bounds__(256) void flash_dkv_reduce_kernel(const FlashArgs a
             sk.x += x.x; sk.y += x.y; sk.z += x.z; sk.w += x.w;
             sv.x += y.x; sv.y += y.y; sv.z += y.z; sv.w += y.w;
         }
-        float* GK = a.dk + b * a.skb + h * a.skh + (long)key * a.ldk + c;
-        float* GV = a.dv + b * a.skb + h * a.skh + (long)key * a.ldk + c;
+        float* GK = static_cast<float*>(a.dk) + b * a.skb + h * a.skh + (long)key * a.ldk + c;
+        float* GV = static_cast<float*>(a.dv) + b * a.skb + h * a.skh + (long)key * a.ldk + c;
         if (a.beta_kv != 0.f) {
             float4 ok = *reinterpret_cast<float4*>(GK), ov = *reinterpret_cast<float4*>(GV);
             sk.x += ok.x; sk.y += ok.y; sk.z += ok.z; sk.w += ok.w;

@@ -21,7 +21,7 @@
 // small-M / deep-K layers (8x8 and 16x16 UNet levels, CLIP, attention bwd). blockIdx -> tile mapping is XCD-aware
 // (bijective remap) so that tiles sharing an A row-panel land on the same XCD L2. Measurements behind these choices:
 // profiles/r01_pmc_conv.md (PMC) and profiles/README.md (per-step history, rejected experiments).
-#include "cb_common.h"
+#include "cb_gemm_tiles.h"
 #include <cstdarg>
 
 namespace cb {
@@ -29,14 +29,6 @@ namespace cb {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int BK = 16;
-
-struct KArgs {
-    GemmArgs a;
-    int tiles_m, tiles_n;
-    int splitk, k_per_split;
-    float* ws;          // split-K partials [split][batch][M][N] (null when splitk == 1)
-    int a_vec, b_vec;   // 1 when the operand may use 16-byte global loads
-};
 
 // ---- tile loaders: global -> registers -------------------------------------------------
 // ROW: element (r, k) at p[r*ld + k]  (k contiguous)   -> NV = ROWS/64 float4 per thread (4 k's of one row)
@@ -106,39 +98,9 @@ __device__ __forceinline__ float conv_fetch(const float* __restrict__ p, const C
     return p[(((long)n * g.H + iy) * g.W + ix) * g.C + ci];
 }
 
-// Per-thread conv gather state: the rows a thread loads are fixed for the whole k loop, so the row -> (image, oy, ox)
-// decode (three integer divisions) is hoisted out of it; the k -> (tap, ci) decode advances incrementally by BK.
-template <int ROWS>
-struct ConvRows {
-    int nb[ROWS / 64];    // n*H*W (pixel offset of the image), or -1 when the row is out of range
-    int vy0[ROWS / 64];   // oy*stride - pad
-    int vx0[ROWS / 64];   // ox*stride - pad
-    int tap, ci;          // decode of this thread's first k of the current tile
-    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int kfirst, int tid) {
-        const int HWo = g.Ho * g.Wo;
-#pragma unroll
-        for (int i = 0; i < ROWS / 64; ++i) {
-            int r = r0 + ((tid + i * 256) >> 2);
-            if (r < R) {
-                int n = r / HWo;
-                int rem = r - n * HWo;
-                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-                nb[i] = n * g.H * g.W; vy0[i] = oy * g.stride - g.pad; vx0[i] = ox * g.stride - g.pad;
-            } else { nb[i] = -1; vy0[i] = 0; vx0[i] = 0; }
-        }
-        int k = kfirst + ((tid & 3) << 2);
-        tap = k / g.C; ci = k - tap * g.C;
-    }
-    __device__ __forceinline__ void advance(const ConvGeom& g) {
-        ci += BK;
-        if (g.C >= BK) { bool w = ci >= g.C; ci -= w ? g.C : 0; tap += w ? 1 : 0; }   // wave-uniform, one wrap at most
-        else while (ci >= g.C) { ci -= g.C; ++tap; }
-    }
-};
-
 template <int ROWS>
 __device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float* __restrict__ p, const ConvGeom& g,
-                                          const ConvRows<ROWS>& cr, int k0, int Kend, int vec, int tid) {
+                                          const ConvRows<ROWS, 4>& cr, int k0, int Kend, int vec, int tid) {
     const int k = k0 + ((tid & 3) << 2);
     const int sh = (g.up | g.tr);
     const int Hv = g.H << sh, Wv = g.W << sh;
@@ -171,42 +133,7 @@ __device__ __forceinline__ void load_conv(float4 (&reg)[ROWS / 64], const float*
     }
 }
 
-// ---- branch-free 16-byte loaders (VEC kernels): buffer loads with hardware range checking -----------------------------
-// Preconditions checked on the host: 16-byte aligned bases/strides, every operand slice < 2 GiB, K % 4 == 0 (ROW/CONV) resp.
-// rows % 4 == 0 (COL), so a float4 is either fully inside or fully outside the operand. Each operand gets a raw buffer
-// descriptor (wave-uniform, num_records = 2 GiB); a lane whose element is out of range (row/k tail, conv padding, transposed
-// stride-2 holes) issues the load at byte offset 0xFFFFFFF0, which the hardware answers with zeros. Consequences:
-//  * no divergent branch and no select sits between the global loads and their consumers, so the prefetch of tile t+1 is
-//    issued before the MFMA block of tile t and waited for only at the LDS stores;
-//  * address math is 32-bit and the zero-fill costs no VALU (the fp32 MFMA shares issue with the vector ALU: every VALU
-//    instruction removed from the k loop is MFMA time won — PMC in profiles/r01_pmc_conv.md).
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int OOB = -16;   // 0xFFFFFFF0 >= num_records -> zeros
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const float* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000);
-}
-__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t srd, int byte_off) {
-    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, 0, 0);
-    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
-}
-// ROW operand: element (r, k) at byte (r*ld + k)*4. Per-slot row offsets are loop invariant.
-template <int ROWS>
-struct RowOffs {
-    int off[ROWS / 64];     // (r*ld + kq*4)*4 or OOB
-    __device__ __forceinline__ void init(long ld, int r0, int R, int tid) {
-#pragma unroll
-        for (int i = 0; i < ROWS / 64; ++i) {
-            int r = r0 + ((tid + i * 256) >> 2);
-            off[i] = (r < R) ? (int)(((long)r * ld + ((tid & 3) << 2)) * 4) : OOB;
-        }
-    }
-};
-template <int ROWS>
-__device__ __forceinline__ void offs_row(int (&off)[ROWS / 64], const RowOffs<ROWS>& ro, int k0, int Kend, int tid) {
-    const bool kok = (k0 + ((tid & 3) << 2)) < Kend;
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) off[i] = (kok && ro.off[i] != OOB) ? ro.off[i] + k0 * 4 : OOB;
-}
+// ---- branch-free 16-byte loaders: cb_gemm_tiles.h (shared with the bf16 kernel); the m-contiguous (COL) form is fp32 only
 // COL operand: element (r, k) at byte (k*ld + r)*4; a thread's slots differ in k
 template <int ROWS>
 __device__ __forceinline__ void offs_col(int (&off)[ROWS / 64], long ld, int r0, int R, int k0, int Kend, int tid) {
@@ -219,62 +146,6 @@ __device__ __forceinline__ void offs_col(int (&off)[ROWS / 64], long ld, int r0,
         off[i] = ((k < Kend) && (r < R)) ? (int)(((long)k * ld + r) * 4) : OOB;
     }
 }
-template <int ROWS>
-__device__ __forceinline__ void offs_conv(int (&off)[ROWS / 64], const ConvGeom& g, const ConvRows<ROWS>& cr, int k0, int Kend, int tid) {
-    const int k = k0 + ((tid & 3) << 2);
-    const int sh = (g.up | g.tr);
-    const int Hv = g.H << sh, Wv = g.W << sh;
-    const int ky = (g.ks == 3) ? ((cr.tap * 11) >> 5) : 0;
-    const int kx = cr.tap - ky * g.ks;
-    const bool kok = k < Kend;
-    const int c4 = g.C * 4, ci4 = cr.ci * 4;
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        int vy = cr.vy0[i] + ky, vx = cr.vx0[i] + kx;
-        bool ok = kok && (cr.nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
-        ok = ok && !(g.tr && ((vy | vx) & 1));
-        int pix = cr.nb[i] + (vy >> sh) * g.W + (vx >> sh);
-        off[i] = ok ? pix * c4 + ci4 : OOB;
-    }
-}
-
-// Fast conv gather (plain 1x1 / 3x3, stride 1 or 2, no upsample / transposed holes, C % BK == 0): a k-tile then lies inside
-// ONE tap for the whole workgroup, so the tap decode lives in scalar registers (uniform k0) and each lane only needs
-//   byte offset = base_off[slot] + delta(tap, ci)     valid = bit `tap` of a per-slot 9-bit mask
-// i.e. 4 VALU per 16-byte load instead of ~25 (bounds compares, shifts, 2 multiplies).
-template <int ROWS>
-struct ConvFast {
-    int base[ROWS / 64];      // ((n*H + oy*stride - pad)*W + ox*stride - pad)*C*4 + kq*16   (may be "negative": only used when valid)
-    unsigned vmask[ROWS / 64];
-    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int tid) {
-        const int HWo = g.Ho * g.Wo;
-#pragma unroll
-        for (int i = 0; i < ROWS / 64; ++i) {
-            int r = r0 + ((tid + i * 256) >> 2);
-            unsigned m = 0; int b = 0;
-            if (r < R) {
-                int n = r / HWo;
-                int rem = r - n * HWo;
-                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
-                int vy0 = oy * g.stride - g.pad, vx0 = ox * g.stride - g.pad;
-                for (int ky = 0; ky < g.ks; ++ky)
-                    for (int kx = 0; kx < g.ks; ++kx)
-                        if ((unsigned)(vy0 + ky) < (unsigned)g.H && (unsigned)(vx0 + kx) < (unsigned)g.W) m |= 1u << (ky * g.ks + kx);
-                b = (((n * g.H + vy0) * g.W + vx0) * g.C + ((tid & 3) << 2)) * 4;
-            }
-            vmask[i] = m; base[i] = b;
-        }
-    }
-};
-template <int ROWS>
-__device__ __forceinline__ void offs_conv_fast(int (&off)[ROWS / 64], const ConvFast<ROWS>& cf, int tap_u, int delta_u) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        bool ok = (cf.vmask[i] >> tap_u) & 1u;
-        off[i] = ok ? cf.base[i] + delta_u : OOB;
-    }
-}
-
 // ---- registers -> LDS (k-major tile [BK][ROWS+4]) -----------------------------------------
 template <int ROWS>
 __device__ __forceinline__ void store_kcontig(float (*T)[ROWS + 4], const float4 (&reg)[ROWS / 64], int tid, unsigned mask) {
@@ -303,29 +174,6 @@ __device__ __forceinline__ void store_rcontig(float (*T)[ROWS + 4], const float4
     }
 }
 
-// k-contiguous operand, VEC path: LDS layout [row][16 k] without padding, 16-byte chunk c of row r stored at chunk
-// c ^ ((r >> 2) & 3). Both the store (a 16-lane group = 4 rows x 4 chunks) and the MFMA fragment read (a 16-lane group =
-// 16 rows x 1 chunk) then touch 16 distinct 4-bank groups: conflict-free ds_write_b128 / ds_read_b128 with loop-invariant
-// per-lane addresses (no address arithmetic left in the k loop).
-template <int ROWS>
-__device__ __forceinline__ void store_kc(float* buf, const float4 (&reg)[ROWS / 64], int tid) {
-#pragma unroll
-    for (int i = 0; i < ROWS / 64; ++i) {
-        int idx = tid + i * 256;
-        int r = idx >> 2;
-        int c = (idx & 3) ^ ((r >> 2) & 3);
-        *reinterpret_cast<float4*>(buf + r * 16 + c * 4) = reg[i];
-    }
-}
-
-__device__ __forceinline__ int xcd_remap(int b, int n) {
-    // bijective "XCD x gets a contiguous chunk" remap (guide §5: XCD swizzle must be bijective)
-    int q = n >> 3, r = n & 7;
-    int xcd = b & 7, j = b >> 3;
-    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
-    return base + j;
-}
-
 template <int BM, int BN, int AK, int BKIND, bool VEC>
 __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4], float (*Bs)[BK][BN + 4]) {
     constexpr int TM = BM / 64, TN = BN / 64;
@@ -342,8 +190,8 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
     const int z = blockIdx.z;
     const int zb = z / a.nh, zh = z - zb * a.nh;
 
-    const float* __restrict__ Ap = a.A + zb * a.sAb + zh * a.sAh;
-    const float* __restrict__ Bp = a.B + zb * a.sBb + zh * a.sBh;
+    const float* __restrict__ Ap = static_cast<const float*>(a.A) + zb * a.sAb + zh * a.sAh;
+    const float* __restrict__ Bp = static_cast<const float*>(a.B) + zb * a.sBb + zh * a.sBh;
 
     const int kbeg = split * p.k_per_split;
     const int kend = min(a.K, kbeg + p.k_per_split);
@@ -362,15 +210,15 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
     // common kernel registers.
     constexpr bool conv_fast = (AK == LD_CONVF);
     static_assert(!conv_fast || VEC, "LD_CONVF needs the vector loaders");
-    ConvRows<BM> cr;
-    ConvFast<BM> cf;
+    ConvRows<BM, 4> cr;
+    ConvFast<BM, 4> cf;
     int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0
     if constexpr (conv_fast) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
     else if constexpr (AK == LD_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
 
     const unsigned ma = ~0u, mb = ~0u;
     __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
-    RowOffs<BM> roA; RowOffs<BN> roB;
+    RowOffs<BM, 4> roA; RowOffs<BN, 4> roB;
     if constexpr (VEC && AK == LD_ROW) roA.init(a.lda, m0, a.M, tid);
     if constexpr (VEC && BKIND == LD_ROW) roB.init(a.ldb, n0, a.N, tid);
     // VEC: all byte offsets are computed first, then the 16-byte buffer loads are issued back to back (pinned by a
@@ -379,16 +227,16 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
     auto loadAB = [&](int k0) {
         if constexpr (VEC) {
             int oa[BM / 64], ob[BN / 64];
-            if constexpr (AK == LD_ROW) offs_row<BM>(oa, roA, k0, kend, tid);
+            if constexpr (AK == LD_ROW) offs_row<BM, 4>(oa, roA, k0, kend, tid);
             else if constexpr (AK == LD_COL) offs_col<BM>(oa, a.lda, m0, a.M, k0, kend, tid);
             else if constexpr (conv_fast) {
                 const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
                 const int kx = tap_u - ky * a.g.ks;
-                offs_conv_fast<BM>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 4);
+                offs_conv_fast<BM, 4>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 4);
                 ci_u += BK;
                 if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
-            } else { offs_conv<BM>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
-            if constexpr (BKIND == LD_ROW) offs_row<BN>(ob, roB, k0, kend, tid);
+            } else { offs_conv<BM, 4>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
+            if constexpr (BKIND == LD_ROW) offs_row<BN, 4>(ob, roB, k0, kend, tid);
             else offs_col<BN>(ob, a.ldb, n0, a.N, k0, kend, tid);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -501,8 +349,9 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
             }
         return;
     }
-    float* __restrict__ Cp = a.C + zb * a.sCb + zh * a.sCh;
-    const float* __restrict__ Rp = a.R ? a.R + zb * a.sRb + zh * a.sRh : nullptr;
+    float* __restrict__ Cp = static_cast<float*>(a.C) + zb * a.sCb + zh * a.sCh;
+    const float* __restrict__ Rp = a.R ? static_cast<const float*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
+    const float* __restrict__ rowbias = static_cast<const float*>(a.rowbias);
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -515,7 +364,7 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
                 int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
                 if (row < a.M) {
                     float v = a.alpha * acc[i][j][r] + bcol;
-                    if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
+                    if (rowbias) v += rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
                     if (Rp) v += Rp[(long)row * a.ldr + col];
                     float* c = Cp + (long)row * a.ldc + col;
                     if (a.beta != 0.f) v += a.beta * (*c);
@@ -525,7 +374,6 @@ __device__ __forceinline__ void gemm_body(const KArgs& p, float (*As)[BK][BM + 4
         }
 }
 
-// split-K reduce + epilogue: one thread per output element
 template <int BM, int BN, int AK, int BKIND, bool VEC>
 __global__ __launch_bounds__(256) void gemm_kernel(const KArgs p) {
     __shared__ __attribute__((aligned(16))) float As[2][BK][BM + 4];
@@ -541,84 +389,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     gemm_body<128, 128, AK, BKIND, true>(p, As, Bs);
 }
 
-__global__ void splitk_reduce_kernel(const KArgs p) {
-    const GemmArgs& a = p.a;
-    long MN = (long)a.M * a.N;
-    long total = MN * a.batch;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int z = (int)(i / MN);
-        long rem = i - (long)z * MN;
-        int row = (int)(rem / a.N), col = (int)(rem - (long)row * a.N);
-        float s = 0.f;
-        for (int sp = 0; sp < p.splitk; ++sp) s += p.ws[((long)sp * a.batch + z) * MN + rem];
-        int zb = z / a.nh, zh = z - zb * a.nh;
-        float v = a.alpha * s;
-        if (a.bias) v += a.bias[col];
-        if (a.rowbias) v += a.rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
-        if (a.R) v += a.R[zb * a.sRb + zh * a.sRh + (long)row * a.ldr + col];
-        float* c = a.C + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col;
-        if (a.beta != 0.f) v += a.beta * (*c);
-        *c = v;
-    }
-}
-
-// ---------------------------------------------------------------- host side
-struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
-
-// Planner constants (unit = one MAC on one CU at the fp32 MFMA rate), each overridable from the environment for sweeps on the
-// GPU box (profiles/README.md, runs 26-29):
-//   CB_SPLITK_COST     fixed cost of the extra reduce launch            (0.25e6 ~ 1 us; 1e6 was 1.2 % slower per step)
-//   CB_PLAN_TRAFFIC    cost per (2*split+1) partial element moved
-//   CB_PLAN_BLOCK_OVH  per-block prologue/epilogue, in k-tiles
-//   CB_PLAN_MINK       fewest k-tiles a split may get
-//   CB_PLAN_EFF        relative MFMA efficiency of the 128x128,128x64,64x128,64x64 tiles
-struct PlanKnobs { double splitk_cost, traffic, block_ovh; int mink; double eff[4]; };
-static const PlanKnobs& plan_knobs() {
-    static const PlanKnobs k = [] {
-        PlanKnobs k{0.25e6, 0.41, 0.0, 4, {1.0, 0.80, 0.80, 0.58}};
-        if (const char* e = getenv("CB_SPLITK_COST")) k.splitk_cost = atof(e);
-        if (const char* e = getenv("CB_PLAN_TRAFFIC")) k.traffic = atof(e);
-        if (const char* e = getenv("CB_PLAN_BLOCK_OVH")) k.block_ovh = atof(e);
-        if (const char* e = getenv("CB_PLAN_MINK")) k.mink = atoi(e) > 0 ? atoi(e) : 1;
-        if (const char* e = getenv("CB_PLAN_EFF")) sscanf(e, "%lf,%lf,%lf,%lf", &k.eff[0], &k.eff[1], &k.eff[2], &k.eff[3]);
-        return k;
-    }();
-    return k;
-}
-static Plan make_plan(const GemmArgs& a) {
-    // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
-    // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
-    // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
-    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
-    const PlanKnobs& kn = plan_knobs();
-    const double* eff = kn.eff;
-    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
-    const int ksteps = cdiv(a.K, BK);
-    double best = 1e300;
-    Plan pl{128, 128, 1, 1, 1, ksteps * BK};
-    for (int t = 0; t < 4; ++t) {
-        const int BM = tiles[t][0], BN = tiles[t][1];
-        if (BM == 128 && a.M <= 64) continue;
-        if (BN == 128 && a.N <= 64) continue;
-        const long tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
-        for (int sp : splits) {
-            if (sp > 1 && ksteps / sp < kn.mink) break;      // keep >= mink k-tiles per split
-            int kps = cdiv(ksteps, sp) * BK;
-            int split = cdiv(a.K, kps);
-            double blocks = (double)tm * tn * a.batch * split;
-            double waves = blocks / 256.0;
-            if (blocks <= 1024) waves = (double)cdiv((long)blocks, 256);
-            double tcost = waves * (double)BM * BN * (kps + kn.block_ovh * BK) / eff[t];
-            // split-K traffic: partial writes + reduce reads/writes ~ (2*split+1)*M*N*4 B at ~3 TB/s, plus one more launch
-            if (split > 1) tcost += kn.splitk_cost + kn.traffic * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
-            if (tcost < best) { best = tcost; pl = Plan{BM, BN, (int)tm, (int)tn, split, kps}; }
-        }
-    }
-    return pl;
-}
-
+// ---------------------------------------------------------------- host side (planner: cb_gemm_tiles.h)
 size_t gemm_ws_bytes(const GemmArgs& a) {
-    Plan pl = make_plan(a);
+    Plan pl = make_plan(a, BK, 1.0);
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
 }
@@ -661,7 +434,8 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         CB_CHECK(!(g.up && g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
         CB_CHECK(a.b_kind == LD_ROW, CB_ERR_ARG, "conv: packed weights must be ROW");
     }
-    Plan pl = make_plan(a);
+    CB_CHECK(a.dt == DT_F32, CB_ERR_ARG, "gemm: the fp32 kernel was handed a bf16 problem");
+    Plan pl = make_plan(a, BK, 1.0);
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
     L.count(pl.splitk > 1 ? 2 : 1);
     if (pl.splitk > 1) {
@@ -740,7 +514,7 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
             CB_HIP(hipEventCreate(&r2.e0)); CB_HIP(hipEventCreate(&r2.e1));
             CB_HIP(hipEventRecord(r2.e0, L.stream));
         }
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, L.stream, ka);
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, L.stream, ka);
         CB_HIP(hipGetLastError());
         if (prof) { CB_HIP(hipEventRecord(r2.e1, L.stream)); L.prof->recs.push_back(r2); }
     }

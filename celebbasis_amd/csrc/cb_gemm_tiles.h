@@ -1,0 +1,249 @@
+// cb_gemm_tiles.h — pieces shared by the fp32 (cb_gemm.hip) and bf16 (cb_gemm_bf16.hip) MFMA GEMM / implicit-GEMM kernels:
+// kernel arguments, the branch-free 16-byte buffer loaders for k-contiguous operands, the swizzled LDS store, the XCD-aware
+// block -> tile remap, the split-K reduce and the tile / split planner. Everything is templated on the element size ESZ
+// (bytes): a 16-byte chunk holds EPC = 16 / ESZ elements of k and a k-tile is 4 chunks per row (64 bytes), so the thread ->
+// (row, chunk) mapping, the LDS image and its XOR swizzle are the same for both element types.
+#pragma once
+#include "cb_device.h"
+
+namespace cb {
+
+struct KArgs {
+    GemmArgs a;
+    int tiles_m, tiles_n;
+    int splitk, k_per_split;
+    float* ws;          // split-K partials [split][batch][M][N] fp32 (null when splitk == 1)
+    int a_vec, b_vec;   // 1 when the operand may use 16-byte global loads
+};
+
+// ---- branch-free 16-byte loaders: buffer loads with hardware range checking ---------------------------------------------
+// Preconditions checked on the host: 16-byte aligned bases/strides, every operand slice < 2 GiB, K a multiple of the chunk
+// (ROW/CONV), so a chunk is either fully inside or fully outside the operand. Each operand gets a raw buffer descriptor
+// (wave-uniform, num_records = 2 GiB); a lane whose chunk is out of range (row/k tail, conv padding, transposed stride-2
+// holes) issues the load at byte offset 0xFFFFFFF0, which the hardware answers with zeros. Consequences:
+//  * no divergent branch and no select sits between the global loads and their consumers, so the prefetch of tile t+1 is
+//    issued before the MFMA block of tile t and waited for only at the LDS stores;
+//  * address math is 32-bit and the zero-fill costs no VALU (the fp32 MFMA shares issue with the vector ALU: every VALU
+//    instruction removed from the k loop is MFMA time won — PMC in profiles/r01_pmc_conv.md).
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int OOB = -16;   // 0xFFFFFFF0 >= num_records -> zeros
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_srd(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t srd, int byte_off) {
+    u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, byte_off, 0, 0);
+    return make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+}
+// ROW operand: element (r, k) at byte (r*ld + k)*ESZ. Per-slot row offsets are loop invariant.
+template <int ROWS, int ESZ>
+struct RowOffs {
+    int off[ROWS / 64];     // (r*ld + chunk*EPC)*ESZ or OOB
+    __device__ __forceinline__ void init(long ld, int r0, int R, int tid) {
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            off[i] = (r < R) ? (int)(((long)r * ld + (tid & 3) * (16 / ESZ)) * ESZ) : OOB;
+        }
+    }
+};
+template <int ROWS, int ESZ>
+__device__ __forceinline__ void offs_row(int (&off)[ROWS / 64], const RowOffs<ROWS, ESZ>& ro, int k0, int Kend, int tid) {
+    const bool kok = (k0 + (tid & 3) * (16 / ESZ)) < Kend;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) off[i] = (kok && ro.off[i] != OOB) ? ro.off[i] + k0 * ESZ : OOB;
+}
+
+// Per-thread conv gather state: the rows a thread loads are fixed for the whole k loop, so the row -> (image, oy, ox)
+// decode (three integer divisions) is hoisted out of it; the k -> (tap, ci) decode advances incrementally by one k-tile.
+template <int ROWS, int ESZ>
+struct ConvRows {
+    static constexpr int EPC = 16 / ESZ, BKE = 4 * EPC;
+    int nb[ROWS / 64];    // n*H*W (pixel offset of the image), or -1 when the row is out of range
+    int vy0[ROWS / 64];   // oy*stride - pad
+    int vx0[ROWS / 64];   // ox*stride - pad
+    int tap, ci;          // decode of this thread's first k of the current tile
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int kfirst, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            if (r < R) {
+                int n = r / HWo;
+                int rem = r - n * HWo;
+                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                nb[i] = n * g.H * g.W; vy0[i] = oy * g.stride - g.pad; vx0[i] = ox * g.stride - g.pad;
+            } else { nb[i] = -1; vy0[i] = 0; vx0[i] = 0; }
+        }
+        int k = kfirst + (tid & 3) * EPC;
+        tap = k / g.C; ci = k - tap * g.C;
+    }
+    __device__ __forceinline__ void advance(const ConvGeom& g) {
+        ci += BKE;
+        if (g.C >= BKE) { bool w = ci >= g.C; ci -= w ? g.C : 0; tap += w ? 1 : 0; }   // wave-uniform, one wrap at most
+        else while (ci >= g.C) { ci -= g.C; ++tap; }
+    }
+};
+template <int ROWS, int ESZ>
+__device__ __forceinline__ void offs_conv(int (&off)[ROWS / 64], const ConvGeom& g, const ConvRows<ROWS, ESZ>& cr, int k0, int Kend, int tid) {
+    const int k = k0 + (tid & 3) * (16 / ESZ);
+    const int sh = (g.up | g.tr);
+    const int Hv = g.H << sh, Wv = g.W << sh;
+    const int ky = (g.ks == 3) ? ((cr.tap * 11) >> 5) : 0;
+    const int kx = cr.tap - ky * g.ks;
+    const bool kok = k < Kend;
+    const int c4 = g.C * ESZ, ci4 = cr.ci * ESZ;
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int vy = cr.vy0[i] + ky, vx = cr.vx0[i] + kx;
+        bool ok = kok && (cr.nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
+        ok = ok && !(g.tr && ((vy | vx) & 1));
+        int pix = cr.nb[i] + (vy >> sh) * g.W + (vx >> sh);
+        off[i] = ok ? pix * c4 + ci4 : OOB;
+    }
+}
+
+// Fast conv gather (plain 1x1 / 3x3, stride 1 or 2, no upsample / transposed holes, C a multiple of the k-tile): a k-tile
+// then lies inside ONE tap for the whole workgroup, so the tap decode lives in scalar registers (uniform k0) and each lane
+// only needs    byte offset = base_off[slot] + delta(tap, ci)     valid = bit `tap` of a per-slot 9-bit mask
+// i.e. 4 VALU per 16-byte load instead of ~25 (bounds compares, shifts, 2 multiplies).
+template <int ROWS, int ESZ>
+struct ConvFast {
+    int base[ROWS / 64];      // ((n*H + oy*stride - pad)*W + ox*stride - pad)*C*ESZ + chunk*16   (may be "negative": only used when valid)
+    unsigned vmask[ROWS / 64];
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < ROWS / 64; ++i) {
+            int r = r0 + ((tid + i * 256) >> 2);
+            unsigned m = 0; int b = 0;
+            if (r < R) {
+                int n = r / HWo;
+                int rem = r - n * HWo;
+                int oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                int vy0 = oy * g.stride - g.pad, vx0 = ox * g.stride - g.pad;
+                for (int ky = 0; ky < g.ks; ++ky)
+                    for (int kx = 0; kx < g.ks; ++kx)
+                        if ((unsigned)(vy0 + ky) < (unsigned)g.H && (unsigned)(vx0 + kx) < (unsigned)g.W) m |= 1u << (ky * g.ks + kx);
+                b = (((n * g.H + vy0) * g.W + vx0) * g.C + (tid & 3) * (16 / ESZ)) * ESZ;
+            }
+            vmask[i] = m; base[i] = b;
+        }
+    }
+};
+template <int ROWS, int ESZ>
+__device__ __forceinline__ void offs_conv_fast(int (&off)[ROWS / 64], const ConvFast<ROWS, ESZ>& cf, int tap_u, int delta_u) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        bool ok = (cf.vmask[i] >> tap_u) & 1u;
+        off[i] = ok ? cf.base[i] + delta_u : OOB;
+    }
+}
+
+// k-contiguous operand: LDS layout [row][4 chunks of 16 bytes] without padding, chunk c of row r stored at chunk
+// c ^ ((r >> 2) & 3). Both the store (a 16-lane group = 4 rows x 4 chunks) and the MFMA fragment read (a 16-lane group =
+// 16 rows x 1 chunk) then touch 16 distinct 4-bank groups: conflict-free ds_write_b128 / ds_read_b128 with loop-invariant
+// per-lane addresses (no address arithmetic left in the k loop). `buf` is the tile base in floats (16 per row).
+template <int ROWS>
+__device__ __forceinline__ void store_kc(float* buf, const float4 (&reg)[ROWS / 64], int tid) {
+#pragma unroll
+    for (int i = 0; i < ROWS / 64; ++i) {
+        int idx = tid + i * 256;
+        int r = idx >> 2;
+        int c = (idx & 3) ^ ((r >> 2) & 3);
+        *reinterpret_cast<float4*>(buf + r * 16 + c * 4) = reg[i];
+    }
+}
+
+__device__ __forceinline__ int xcd_remap(int b, int n) {
+    // bijective "XCD x gets a contiguous chunk" remap (guide §5: XCD swizzle must be bijective)
+    int q = n >> 3, r = n & 7;
+    int xcd = b & 7, j = b >> 3;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + j;
+}
+
+// split-K reduce + epilogue: one thread per output element (T = element type of C, R and rowbias)
+template <typename T>
+__global__ void splitk_reduce_kernel(const KArgs p) {
+    const GemmArgs& a = p.a;
+    long MN = (long)a.M * a.N;
+    long total = MN * a.batch;
+    const T* Rb = static_cast<const T*>(a.R);
+    const T* rowbias = static_cast<const T*>(a.rowbias);
+    T* Cb = static_cast<T*>(a.C);
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int z = (int)(i / MN);
+        long rem = i - (long)z * MN;
+        int row = (int)(rem / a.N), col = (int)(rem - (long)row * a.N);
+        float s = 0.f;
+        for (int sp = 0; sp < p.splitk; ++sp) s += p.ws[((long)sp * a.batch + z) * MN + rem];
+        int zb = z / a.nh, zh = z - zb * a.nh;
+        float v = a.alpha * s;
+        if (a.bias) v += a.bias[col];
+        if (rowbias) v += ld1(rowbias + (long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col);
+        if (Rb) v += ld1(Rb + zb * a.sRb + zh * a.sRh + (long)row * a.ldr + col);
+        T* c = Cb + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col;
+        if (a.beta != 0.f) v += a.beta * ld1(c);
+        st1(c, v);
+    }
+}
+
+// ---------------------------------------------------------------- host side: tile / split-K planner
+struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
+
+// Planner constants (unit = one MAC on one CU at the fp32 MFMA rate), each overridable from the environment for sweeps on the
+// GPU box (profiles/README.md, runs 26-29):
+//   CB_SPLITK_COST     fixed cost of the extra reduce launch            (0.25e6 ~ 1 us; 1e6 was 1.2 % slower per step)
+//   CB_PLAN_TRAFFIC    cost per (2*split+1) partial element moved
+//   CB_PLAN_BLOCK_OVH  per-block prologue/epilogue, in k-tiles
+//   CB_PLAN_MINK       fewest k-tiles a split may get
+//   CB_PLAN_EFF        relative MFMA efficiency of the 128x128,128x64,64x128,64x64 tiles
+//   CB_PLAN_BF16_SPEED how many times faster than the fp32 kernel the bf16 kernel retires MACs (scales the MFMA term only)
+struct PlanKnobs { double splitk_cost, traffic, block_ovh; int mink; double eff[4]; double bf16_speed; };
+inline const PlanKnobs& plan_knobs() {
+    static const PlanKnobs k = [] {
+        PlanKnobs k{0.25e6, 0.41, 0.0, 4, {1.0, 0.80, 0.80, 0.58}, 6.0};
+        if (const char* e = getenv("CB_SPLITK_COST")) k.splitk_cost = atof(e);
+        if (const char* e = getenv("CB_PLAN_TRAFFIC")) k.traffic = atof(e);
+        if (const char* e = getenv("CB_PLAN_BLOCK_OVH")) k.block_ovh = atof(e);
+        if (const char* e = getenv("CB_PLAN_MINK")) k.mink = atoi(e) > 0 ? atoi(e) : 1;
+        if (const char* e = getenv("CB_PLAN_EFF")) sscanf(e, "%lf,%lf,%lf,%lf", &k.eff[0], &k.eff[1], &k.eff[2], &k.eff[3]);
+        if (const char* e = getenv("CB_PLAN_BF16_SPEED")) k.bf16_speed = atof(e) > 0 ? atof(e) : 6.0;
+        return k;
+    }();
+    return k;
+}
+// bke = elements of k per tile (16 for fp32, 32 for bf16); speed = MFMA rate relative to the fp32 kernel
+inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
+    // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
+    // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
+    // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
+    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    const PlanKnobs& kn = plan_knobs();
+    const double* eff = kn.eff;
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
+    const int ksteps = cdiv(a.K, bke);
+    double best = 1e300;
+    Plan pl{128, 128, 1, 1, 1, ksteps * bke};
+    for (int t = 0; t < 4; ++t) {
+        const int BM = tiles[t][0], BN = tiles[t][1];
+        if (BM == 128 && a.M <= 64) continue;
+        if (BN == 128 && a.N <= 64) continue;
+        const long tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
+        for (int sp : splits) {
+            if (sp > 1 && ksteps / sp < kn.mink) break;      // keep >= mink k-tiles per split
+            int kps = cdiv(ksteps, sp) * bke;
+            int split = cdiv(a.K, kps);
+            double blocks = (double)tm * tn * a.batch * split;
+            double waves = blocks / 256.0;
+            if (blocks <= 1024) waves = (double)cdiv((long)blocks, 256);
+            double tcost = waves * (double)BM * BN * (kps + kn.block_ovh * bke) / eff[t] / speed;
+            // split-K traffic: partial writes + reduce reads/writes ~ (2*split+1)*M*N*4 B at ~3 TB/s, plus one more launch
+            if (split > 1) tcost += kn.splitk_cost + kn.traffic * (2.0 * split + 1.0) * (double)a.M * a.N * a.batch;
+            if (tcost < best) { best = tcost; pl = Plan{BM, BN, (int)tm, (int)tn, split, kps}; }
+        }
+    }
+    return pl;
+}
+
+}  // namespace cb

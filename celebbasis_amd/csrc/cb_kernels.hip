@@ -1,9 +1,10 @@
 // cb_kernels.hip — HBM-bound kernels of the CelebBasis training step for gfx950 (MI355X):
 // GroupNorm(+SiLU), LayerNorm, softmax, GEGLU, activations, layout changes, DDPM glue (q_sample, loss),
 // face warp/resize, the CelebBasis coefficient head (L2-norm, basis contraction, row surgery, EMA),
-// AdamW, and one-time weight packing. All tensors are fp32, activations are NHWC ([tokens][channels]).
+// AdamW, and one-time weight packing. Activations are NHWC ([tokens][channels]) in fp32 or bf16 storage (kernels templated on
+// the element type, arithmetic always fp32); parameters, statistics and the coefficient head are fp32.
 // wave = 64 lanes everywhere; reductions use 64-wide shuffles.
-#include "cb_common.h"
+#include "cb_device.h"
 #include <cstdarg>
 
 namespace cb {
@@ -55,108 +56,185 @@ __device__ __forceinline__ float block_max256(float v, float* sh) {
 }
 
 // ------------------------------------------------------------------ simple elementwise
-__global__ void fill_kernel(float* p, long n, float v) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+template <typename T> __global__ void fill_kernel(T* p, long n, float v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) st1(p + i, v);
 }
-void k_fill(const Launch& L, float* p, long n, float v) { LAUNCH(fill_kernel, grid1d(n), dim3(256), L, p, n, v); }
+void k_fill(const Launch& L, DType dt, void* p, long n, float v) {
+    CB_DT_SWITCH(dt, T, LAUNCH((fill_kernel<T>), grid1d(n), dim3(256), L, (T*)p, n, v));
+}
 
-__global__ void axpby_kernel(float* __restrict__ dst, const float* __restrict__ src, long n, float a, float b) {
+// dst = a*src + b*dst ; quads when everything is 4-aligned (the common case: copies and gradient accumulation)
+template <typename T> __global__ void axpby_kernel(T* __restrict__ dst, const T* __restrict__ src, long n, float a, float b) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float v = a * src[i];
-        if (b != 0.f) v += b * dst[i];
-        dst[i] = v;
+        float v = a * ld1(src + i);
+        if (b != 0.f) v += b * ld1(dst + i);
+        st1(dst + i, v);
     }
 }
-void k_axpby(const Launch& L, float* dst, const float* src, long n, float a, float b) {
-    LAUNCH(axpby_kernel, grid1d(n), dim3(256), L, dst, src, n, a, b);
+template <typename T> __global__ void axpby4_kernel(T* __restrict__ dst, const T* __restrict__ src, long nq, float a, float b) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nq; i += (long)gridDim.x * blockDim.x) {
+        float4 v = ld4(src + i * 4);
+        v.x *= a; v.y *= a; v.z *= a; v.w *= a;
+        if (b != 0.f) { const float4 o = ld4(dst + i * 4); v.x += b * o.x; v.y += b * o.y; v.z += b * o.z; v.w += b * o.w; }
+        st4(dst + i * 4, v);
+    }
+}
+void k_axpby(const Launch& L, DType dt, void* dst, const void* src, long n, float a, float b) {
+    const bool q = (n % 4 == 0) && ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    if (q) CB_DT_SWITCH(dt, T, LAUNCH((axpby4_kernel<T>), grid1d(n / 4), dim3(256), L, (T*)dst, (const T*)src, n / 4, a, b));
+    else CB_DT_SWITCH(dt, T, LAUNCH((axpby_kernel<T>), grid1d(n), dim3(256), L, (T*)dst, (const T*)src, n, a, b));
 }
 
-__global__ void add_kernel(float* __restrict__ dst, const float* __restrict__ x, const float* __restrict__ y, long n) {
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) dst[i] = x[i] + y[i];
-}
-void k_add(const Launch& L, float* dst, const float* x, const float* y, long n) {
-    LAUNCH(add_kernel, grid1d(n), dim3(256), L, dst, x, y, n);
-}
-
-__global__ void copy2d_kernel(float* __restrict__ dst, long ldd, const float* __restrict__ src, long lds, long rows, int cols,
-                              float beta) {
+template <typename T>
+__global__ void copy2d_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int cols, float beta) {
     long total = rows * cols;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / cols;
         int c = (int)(i - r * cols);
-        float v = src[r * lds + c];
-        float* d = dst + r * ldd + c;
-        if (beta != 0.f) v += beta * (*d);
-        *d = v;
+        float v = ld1(src + r * lds + c);
+        T* d = dst + r * ldd + c;
+        if (beta != 0.f) v += beta * ld1(d);
+        st1(d, v);
     }
 }
-void k_copy2d(const Launch& L, float* dst, long ldd, const float* src, long lds, long rows, int cols, float beta) {
-    LAUNCH(copy2d_kernel, grid1d(rows * cols), dim3(256), L, dst, ldd, src, lds, rows, cols, beta);
+template <typename T>
+__global__ void copy2d4_kernel(T* __restrict__ dst, long ldd, const T* __restrict__ src, long lds, long rows, int qcols, float beta) {
+    long total = rows * qcols;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / qcols;
+        int c = (int)(i - r * qcols) * 4;
+        float4 v = ld4(src + r * lds + c);
+        T* d = dst + r * ldd + c;
+        if (beta != 0.f) { const float4 o = ld4(d); v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w; }
+        st4(d, v);
+    }
+}
+void k_copy2d(const Launch& L, DType dt, void* dst, long ldd, const void* src, long lds, long rows, int cols, float beta) {
+    const bool q = (cols % 4 == 0) && (ldd % 4 == 0) && (lds % 4 == 0) &&
+                   ((reinterpret_cast<uintptr_t>(dst) | reinterpret_cast<uintptr_t>(src)) & 15) == 0;
+    if (q) CB_DT_SWITCH(dt, T, LAUNCH((copy2d4_kernel<T>), grid1d(rows * (cols / 4)), dim3(256), L, (T*)dst, ldd, (const T*)src, lds, rows, cols / 4, beta));
+    else CB_DT_SWITCH(dt, T, LAUNCH((copy2d_kernel<T>), grid1d(rows * cols), dim3(256), L, (T*)dst, ldd, (const T*)src, lds, rows, cols, beta));
 }
 
-__global__ void silu_kernel(float* __restrict__ dst, const float* __restrict__ src, long n) {
+// element-type conversion with optional zero padding of the row (cols_dst >= cols_src)
+template <typename TD, typename TS>
+__global__ void convert_kernel(TD* __restrict__ dst, int cd, const TS* __restrict__ src, int cs, long rows, float beta) {
+    long total = rows * cd;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        long r = i / cd;
+        int c = (int)(i - r * cd);
+        float v = c < cs ? ld1(src + r * cs + c) : 0.f;
+        if (beta != 0.f) v += beta * ld1(dst + i);
+        st1(dst + i, v);
+    }
+}
+void k_convert(const Launch& L, void* dst, DType ddt, int cols_dst, const void* src, DType sdt, int cols_src, long rows, float beta) {
+    CB_CHECK(cols_dst >= cols_src && cols_src >= 1, CB_ERR_SHAPE, "convert: %d -> %d columns", cols_src, cols_dst);
+    const dim3 g = grid1d(rows * cols_dst);
+    if (ddt == DT_BF16 && sdt == DT_F32) LAUNCH((convert_kernel<bf16_t, float>), g, dim3(256), L, (bf16_t*)dst, cols_dst, (const float*)src, cols_src, rows, beta);
+    else if (ddt == DT_F32 && sdt == DT_BF16) LAUNCH((convert_kernel<float, bf16_t>), g, dim3(256), L, (float*)dst, cols_dst, (const bf16_t*)src, cols_src, rows, beta);
+    else if (ddt == DT_F32) LAUNCH((convert_kernel<float, float>), g, dim3(256), L, (float*)dst, cols_dst, (const float*)src, cols_src, rows, beta);
+    else LAUNCH((convert_kernel<bf16_t, bf16_t>), g, dim3(256), L, (bf16_t*)dst, cols_dst, (const bf16_t*)src, cols_src, rows, beta);
+}
+
+// dst[b][c][r] = src[b][r][c] through a 32x32 LDS tile (V^T for the materialised bf16 attention)
+template <typename T>
+__global__ __launch_bounds__(256) void transpose_kernel(T* __restrict__ dst, const T* __restrict__ src, int rows, int cols, long ld_src,
+                                                         long sb_src) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const T* s = src + (long)b * sb_src;
+    for (int j = ty; j < 32; j += 8) {
+        int r = r0 + j, c = c0 + tx;
+        tile[j][tx] = (r < rows && c < cols) ? ld1(s + (long)r * ld_src + c) : 0.f;
+    }
+    __syncthreads();
+    T* d = dst + (long)b * rows * cols;
+    for (int j = ty; j < 32; j += 8) {
+        int c = c0 + j, r = r0 + tx;
+        if (r < rows && c < cols) st1(d + (long)c * rows + r, tile[tx][j]);
+    }
+}
+void k_transpose(const Launch& L, DType dt, void* dst, const void* src, int batch, int rows, int cols, long ld_src, long sb_src) {
+    CB_DT_SWITCH(dt, T, LAUNCH((transpose_kernel<T>), dim3(cdiv(cols, 32), cdiv(rows, 32), batch), dim3(256), L, (T*)dst, (const T*)src, rows,
+                               cols, ld_src, sb_src));
+}
+
+template <typename T> __global__ void silu_kernel(T* __restrict__ dst, const T* __restrict__ src, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float x = src[i];
-        dst[i] = x * sigmoidf_(x);
+        float x = ld1(src + i);
+        st1(dst + i, x * sigmoidf_(x));
     }
 }
-void k_silu(const Launch& L, float* dst, const float* src, long n) { LAUNCH(silu_kernel, grid1d(n), dim3(256), L, dst, src, n); }
+void k_silu(const Launch& L, DType dt, void* dst, const void* src, long n) {
+    CB_DT_SWITCH(dt, T, LAUNCH((silu_kernel<T>), grid1d(n), dim3(256), L, (T*)dst, (const T*)src, n));
+}
 
-// GEGLU (attention.py:37-44): x[M][2D] -> y[M][D] = x[:, :D] * gelu(x[:, D:]), exact erf GELU
-__global__ void geglu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long M, int D) {
-    long total = M * D;
+// GEGLU (attention.py:37-44): x[M][2D] -> y[M][D] = x[:, :D] * gelu(x[:, D:]), exact erf GELU. D % 4 == 0: one quad per thread.
+__device__ __forceinline__ float gelu_erf(float g) { return 0.5f * g * (1.f + erff(g * 0.70710678118654752f)); }
+template <typename T> __global__ void geglu_fwd_kernel(T* __restrict__ y, const T* __restrict__ x, long M, int D) {
+    const int Q = D >> 2;
+    long total = M * Q;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / D;
-        int c = (int)(i - r * D);
-        float a = x[r * 2 * D + c];
-        float g = x[r * 2 * D + D + c];
-        float ge = 0.5f * g * (1.f + erff(g * 0.70710678118654752f));
-        y[i] = a * ge;
+        long r = i / Q;
+        int c = (int)(i - r * Q) * 4;
+        const float4 a = ld4(x + r * 2 * D + c), g = ld4(x + r * 2 * D + D + c);
+        st4(y + r * D + c, make_float4(a.x * gelu_erf(g.x), a.y * gelu_erf(g.y), a.z * gelu_erf(g.z), a.w * gelu_erf(g.w)));
     }
 }
-void k_geglu_fwd(const Launch& L, float* y, const float* x, long M, int D) {
-    LAUNCH(geglu_fwd_kernel, grid1d(M * D), dim3(256), L, y, x, M, D);
+void k_geglu_fwd(const Launch& L, DType dt, void* y, const void* x, long M, int D) {
+    CB_CHECK(D % 4 == 0, CB_ERR_SHAPE, "geglu: D=%d must be a multiple of 4", D);
+    CB_DT_SWITCH(dt, T, LAUNCH((geglu_fwd_kernel<T>), grid1d(M * (D / 4)), dim3(256), L, (T*)y, (const T*)x, M, D));
 }
-__global__ void geglu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy, long M, int D) {
-    long total = M * D;
+__device__ __forceinline__ void geglu_d(float a, float g, float d, float* da, float* dg) {
+    float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * __expf(-0.5f * g * g);
+    *da = d * g * cdf;
+    *dg = d * a * (cdf + g * pdf);
+}
+template <typename T>
+__global__ void geglu_bwd_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dy, long M, int D) {
+    const int Q = D >> 2;
+    long total = M * Q;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        long r = i / D;
-        int c = (int)(i - r * D);
-        float a = x[r * 2 * D + c];
-        float g = x[r * 2 * D + D + c];
-        float cdf = 0.5f * (1.f + erff(g * 0.70710678118654752f));
-        float pdf = 0.39894228040143268f * __expf(-0.5f * g * g);
-        float d = dy[i];
-        dx[r * 2 * D + c] = d * g * cdf;
-        dx[r * 2 * D + D + c] = d * a * (cdf + g * pdf);
+        long r = i / Q;
+        int c = (int)(i - r * Q) * 4;
+        const float4 a = ld4(x + r * 2 * D + c), g = ld4(x + r * 2 * D + D + c), d = ld4(dy + r * D + c);
+        float4 da, dg;
+        geglu_d(a.x, g.x, d.x, &da.x, &dg.x); geglu_d(a.y, g.y, d.y, &da.y, &dg.y);
+        geglu_d(a.z, g.z, d.z, &da.z, &dg.z); geglu_d(a.w, g.w, d.w, &da.w, &dg.w);
+        st4(dx + r * 2 * D + c, da);
+        st4(dx + r * 2 * D + D + c, dg);
     }
 }
-void k_geglu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long M, int D) {
-    LAUNCH(geglu_bwd_kernel, grid1d(M * D), dim3(256), L, dx, x, dy, M, D);
+void k_geglu_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, long M, int D) {
+    CB_CHECK(D % 4 == 0, CB_ERR_SHAPE, "geglu: D=%d must be a multiple of 4", D);
+    CB_DT_SWITCH(dt, T, LAUNCH((geglu_bwd_kernel<T>), grid1d(M * (D / 4)), dim3(256), L, (T*)dx, (const T*)x, (const T*)dy, M, D));
 }
 
 // quick-GELU x*sigmoid(1.702x) (transformers 4.18 activations.QuickGELUActivation)
-__global__ void quickgelu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long n) {
+template <typename T> __global__ void quickgelu_fwd_kernel(T* __restrict__ y, const T* __restrict__ x, long n) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float v = x[i];
-        y[i] = v * sigmoidf_(1.702f * v);
+        float v = ld1(x + i);
+        st1(y + i, v * sigmoidf_(1.702f * v));
     }
 }
-void k_quickgelu_fwd(const Launch& L, float* y, const float* x, long n) {
-    LAUNCH(quickgelu_fwd_kernel, grid1d(n), dim3(256), L, y, x, n);
+void k_quickgelu_fwd(const Launch& L, DType dt, void* y, const void* x, long n) {
+    CB_DT_SWITCH(dt, T, LAUNCH((quickgelu_fwd_kernel<T>), grid1d(n), dim3(256), L, (T*)y, (const T*)x, n));
 }
-__global__ void quickgelu_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x, const float* __restrict__ dy, long n,
-                                     float beta) {
+template <typename T>
+__global__ void quickgelu_bwd_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dy, long n, float beta) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        float v = x[i];
+        float v = ld1(x + i);
         float s = sigmoidf_(1.702f * v);
-        float g = dy[i] * s * (1.f + 1.702f * v * (1.f - s));
-        if (beta != 0.f) g += beta * dx[i];
-        dx[i] = g;
+        float g = ld1(dy + i) * s * (1.f + 1.702f * v * (1.f - s));
+        if (beta != 0.f) g += beta * ld1(dx + i);
+        st1(dx + i, g);
     }
 }
-void k_quickgelu_bwd(const Launch& L, float* dx, const float* x, const float* dy, long n, float beta) {
-    LAUNCH(quickgelu_bwd_kernel, grid1d(n), dim3(256), L, dx, x, dy, n, beta);
+void k_quickgelu_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, long n, float beta) {
+    CB_DT_SWITCH(dt, T, LAUNCH((quickgelu_bwd_kernel<T>), grid1d(n), dim3(256), L, (T*)dx, (const T*)x, (const T*)dy, n, beta));
 }
 
 __global__ void leakyrelu_fwd_kernel(float* __restrict__ y, const float* __restrict__ x, long n, float s) {
@@ -177,7 +255,8 @@ void k_leakyrelu_bwd(const Launch& L, float* dx, const float* x, const float* dy
     LAUNCH(leakyrelu_bwd_kernel, grid1d(n), dim3(256), L, dx, x, dy, n, s);
 }
 
-__global__ void nchw_to_nhwc_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int H, int W) {
+// layout changes at the ABI edge: the reference's public latents / noise / images are fp32 NCHW
+template <typename T> __global__ void nchw_to_nhwc_kernel(T* __restrict__ dst, const float* __restrict__ src, int N, int C, int H, int W) {
     long total = (long)N * C * H * W;
     long HW = (long)H * W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -186,13 +265,13 @@ __global__ void nchw_to_nhwc_kernel(float* __restrict__ dst, const float* __rest
         long t = i / C;
         long hw = t % HW;
         long n = t / HW;
-        dst[i] = src[(n * C + c) * HW + hw];
+        st1(dst + i, src[(n * C + c) * HW + hw]);
     }
 }
-void k_nchw_to_nhwc(const Launch& L, float* dst, const float* src, int N, int C, int H, int W) {
-    LAUNCH(nchw_to_nhwc_kernel, grid1d((long)N * C * H * W), dim3(256), L, dst, src, N, C, H, W);
+void k_nchw_to_nhwc(const Launch& L, DType ddt, void* dst, const float* src, int N, int C, int H, int W) {
+    CB_DT_SWITCH(ddt, T, LAUNCH((nchw_to_nhwc_kernel<T>), grid1d((long)N * C * H * W), dim3(256), L, (T*)dst, src, N, C, H, W));
 }
-__global__ void nhwc_to_nchw_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int H, int W) {
+template <typename T> __global__ void nhwc_to_nchw_kernel(float* __restrict__ dst, const T* __restrict__ src, int N, int C, int H, int W) {
     long total = (long)N * C * H * W;
     long HW = (long)H * W;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -201,11 +280,11 @@ __global__ void nhwc_to_nchw_kernel(float* __restrict__ dst, const float* __rest
         long t = i / HW;
         int c = (int)(t % C);
         long n = t / C;
-        dst[i] = src[(n * HW + hw) * C + c];
+        dst[i] = ld1(src + (n * HW + hw) * C + c);
     }
 }
-void k_nhwc_to_nchw(const Launch& L, float* dst, const float* src, int N, int C, int H, int W) {
-    LAUNCH(nhwc_to_nchw_kernel, grid1d((long)N * C * H * W), dim3(256), L, dst, src, N, C, H, W);
+void k_nhwc_to_nchw(const Launch& L, DType sdt, float* dst, const void* src, int N, int C, int H, int W) {
+    CB_DT_SWITCH(sdt, T, LAUNCH((nhwc_to_nchw_kernel<T>), grid1d((long)N * C * H * W), dim3(256), L, dst, (const T*)src, N, C, H, W));
 }
 
 // y = x*scale[c] + shift[c], then optional PReLU(slope[c]) (iresnet.py:44-63: eval BatchNorm + PReLU)
@@ -225,25 +304,29 @@ void k_channel_affine(const Launch& L, float* y, const float* x, const float* sc
     LAUNCH(channel_affine_kernel, grid1d(rows * C), dim3(256), L, y, x, scale, shift, prelu, rows, C);
 }
 
-// backward of nearest-2x upsample: dx[n,y,x,c] (+)= sum of the 2x2 block of dy (dy is [N,2H,2W,C])
-__global__ void upsample2x_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy, int N, int H, int W, int C,
-                                      float beta) {
-    long total = (long)N * H * W * C;
+// backward of nearest-2x upsample: dx[n,y,x,c] (+)= sum of the 2x2 block of dy (dy is [N,2H,2W,C]); C % 4 == 0: quads
+template <typename T>
+__global__ void upsample2x_bwd_kernel(T* __restrict__ dx, const T* __restrict__ dy, int N, int H, int W, int C, float beta) {
+    const int Q = C >> 2;
+    long total = (long)N * H * W * Q;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int c = (int)(i % C);
-        long t = i / C;
+        int c = (int)(i % Q) * 4;
+        long t = i / Q;
         int x = (int)(t % W);
         t /= W;
         int y = (int)(t % H);
         long n = t / H;
-        const float* p = dy + (((n * 2 * H + 2 * y) * 2 * W) + 2 * x) * (long)C + c;
-        float v = p[0] + p[C] + p[(long)2 * W * C] + p[(long)2 * W * C + C];
-        if (beta != 0.f) v += beta * dx[i];
-        dx[i] = v;
+        const T* p = dy + (((n * 2 * H + 2 * y) * 2 * W) + 2 * x) * (long)C + c;
+        const float4 a = ld4(p), b = ld4(p + C), d = ld4(p + (long)2 * W * C), e = ld4(p + (long)2 * W * C + C);
+        float4 v = make_float4(a.x + b.x + d.x + e.x, a.y + b.y + d.y + e.y, a.z + b.z + d.z + e.z, a.w + b.w + d.w + e.w);
+        T* o = dx + i * 4;
+        if (beta != 0.f) { const float4 u = ld4(o); v.x += beta * u.x; v.y += beta * u.y; v.z += beta * u.z; v.w += beta * u.w; }
+        st4(o, v);
     }
 }
-void k_upsample2x_bwd(const Launch& L, float* dx, const float* dy, int N, int H, int W, int C, float beta) {
-    LAUNCH(upsample2x_bwd_kernel, grid1d((long)N * H * W * C), dim3(256), L, dx, dy, N, H, W, C, beta);
+void k_upsample2x_bwd(const Launch& L, DType dt, void* dx, const void* dy, int N, int H, int W, int C, float beta) {
+    CB_CHECK(C % 4 == 0, CB_ERR_SHAPE, "upsample bwd: C=%d must be a multiple of 4", C);
+    CB_DT_SWITCH(dt, T, LAUNCH((upsample2x_bwd_kernel<T>), grid1d((long)N * H * W * (C / 4)), dim3(256), L, (T*)dx, (const T*)dy, N, H, W, C, beta));
 }
 
 // ------------------------------------------------------------------ GroupNorm (NHWC)
@@ -306,13 +389,14 @@ __device__ __forceinline__ void gn_block_reduce(float* __restrict__ part, float*
 }
 static size_t gn_lds_bytes(int C) { int Q = C / 4; int rif = Q <= 256 ? 256 / Q : 1; return (size_t)rif * C * 2 * sizeof(float); }
 
-__global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const float* __restrict__ x, int HW, int C,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const T* __restrict__ x, int HW, int C,
                                                           int G, int nchunk, int rpb) {
     extern __shared__ __attribute__((aligned(16))) float chs[];
     int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
     int cpg = C / G;
-    const float* xn = x + (long)n * HW * C;
+    const T* xn = x + (long)n * HW * C;
     GnMap m = gn_map(C);
     float sa[GN_MAXQ][4], sb[GN_MAXQ][4], sh[GN_MAXQ][4];
 #pragma unroll
@@ -323,13 +407,13 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ par
     for (int s = 0; s < GN_MAXQ; ++s)
         if (s < m.nq) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) sh[s][j] = xn[((m.q[s] * 4 + j) / cpg) * cpg];   // shift: row 0, first channel of the group
+            for (int j = 0; j < 4; ++j) sh[s][j] = ld1(xn + ((m.q[s] * 4 + j) / cpg) * cpg);   // shift: row 0, first channel of the group
         }
     for (int r = r0 + m.rr; r < r1; r += m.rif) {
 #pragma unroll
         for (int s = 0; s < GN_MAXQ; ++s)
             if (s < m.nq) {
-                float4 v = *reinterpret_cast<const float4*>(xn + (long)r * C + m.q[s] * 4);
+                float4 v = ld4(xn + (long)r * C + m.q[s] * 4);
                 float d0 = v.x - sh[s][0], d1 = v.y - sh[s][1], d2 = v.z - sh[s][2], d3 = v.w - sh[s][3];
                 sa[s][0] += d0; sa[s][1] += d1; sa[s][2] += d2; sa[s][3] += d3;
                 sb[s][0] += d0 * d0; sb[s][1] += d1 * d1; sb[s][2] += d2 * d2; sb[s][3] += d3 * d3;
@@ -338,8 +422,9 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ par
     gn_block_reduce(part, chs, m, sa, sb, C, G);
 }
 // one wave per (n, g): reduce chunk partials in double -> stats (mean, rstd) and per-channel {mean, rstd, gamma, beta}
+template <typename T>
 __global__ __launch_bounds__(256) void gn_final_kernel(float* __restrict__ stats, float* __restrict__ chn,
-                                                        const float* __restrict__ part, const float* __restrict__ x,
+                                                        const float* __restrict__ part, const T* __restrict__ x,
                                                         const float* __restrict__ gamma, const float* __restrict__ beta, int N, int HW,
                                                         int C, int G, int nchunk, float eps) {
     int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -353,7 +438,7 @@ __global__ __launch_bounds__(256) void gn_final_kernel(float* __restrict__ stats
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
     double cnt = (double)HW * cpg;
-    double sh = x[(long)n * HW * C + g * cpg];
+    double sh = ld1(x + (long)n * HW * C + g * cpg);
     double mloc = a / cnt;
     double var = b / cnt - mloc * mloc;
     if (var < 0) var = 0;
@@ -370,13 +455,14 @@ __global__ void gn_expand_kernel(float* __restrict__ chn, const float* __restric
     int n = i / C, c = i % C, g = c / (C / G);
     *reinterpret_cast<float4*>(chn + (long)i * 4) = make_float4(stats[(n * G + g) * 2], stats[(n * G + g) * 2 + 1], gamma[c], beta[c]);
 }
-__global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ y, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                         const float* __restrict__ chn, long nquads, int HW, int C, int silu) {
     const int Q = C >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
         int q = (int)(i % Q);
         long n = i / ((long)HW * Q);
-        float4 v = *reinterpret_cast<const float4*>(x + i * 4);
+        float4 v = ld4(x + i * 4);
         const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
         float in[4] = {v.x, v.y, v.z, v.w}, o[4];
 #pragma unroll
@@ -385,10 +471,10 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(float* __restrict__ y, co
             float t = (in[j] - kk.x) * kk.y * kk.z + kk.w;
             o[j] = silu ? t * sigmoidf_(t) : t;
         }
-        *reinterpret_cast<float4*>(y + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(y + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
-void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, float* ws,
+void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta, float* stats, float* ws,
                      int N, int HW, int C, int G, float eps, int silu) {
     CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
     int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
@@ -398,14 +484,17 @@ void k_groupnorm_fwd(const Launch& L, float* y, const float* x, const float* gam
     if (L.dry) return;
     // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
     // launch-latency bound and would otherwise drown the achieved-bandwidth figure
-    const bool big = (double)N * HW * C * 4 >= 64e6;
+    const double esz = (double)dt_size(dt);
+    const bool big = (double)N * HW * C * esz >= 64e6;
     ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_fwd[>=64MB]" : "groupnorm_silu_fwd[<64MB]")
                                                                    : (big ? "groupnorm_fwd[>=64MB]" : "groupnorm_fwd[<64MB]"),
-                                                             0.0, 3.0 * N * HW * (double)C * 4, L.stream);
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, HW, C, G, nchunk, rpb);
-    hipLaunchKernelGGL(gn_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, x, gamma, beta, N, HW, C, G, nchunk, eps);
+                                                             0.0, 3.0 * N * HW * (double)C * esz, L.stream);
     long nquads = (long)N * HW * (C / 4);
-    hipLaunchKernelGGL(gn_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, y, x, chn, nquads, HW, C, silu);
+    CB_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
+        hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+    });
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
 }
@@ -418,14 +507,15 @@ __device__ __forceinline__ float gn_dt(float xh, float gam, float bet, float dy,
     float s = sigmoidf_(t);
     return dy * s * (1.f + t * (1.f - s));
 }
-__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const float* __restrict__ x,
-                                                              const float* __restrict__ dy, const float* __restrict__ chn, int HW,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const T* __restrict__ x,
+                                                              const T* __restrict__ dy, const float* __restrict__ chn, int HW,
                                                               int C, int G, int nchunk, int rpb, int silu) {
     extern __shared__ __attribute__((aligned(16))) float chs[];
     int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
-    const float* xn = x + (long)n * HW * C;
-    const float* dn = dy + (long)n * HW * C;
+    const T* xn = x + (long)n * HW * C;
+    const T* dn = dy + (long)n * HW * C;
     GnMap m = gn_map(C);
     float sa[GN_MAXQ][4], sb[GN_MAXQ][4];
     float4 kk[GN_MAXQ][4];
@@ -443,8 +533,8 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__
 #pragma unroll
         for (int s = 0; s < GN_MAXQ; ++s)
             if (s < m.nq) {
-                float4 xv = *reinterpret_cast<const float4*>(xn + (long)r * C + m.q[s] * 4);
-                float4 dv = *reinterpret_cast<const float4*>(dn + (long)r * C + m.q[s] * 4);
+                float4 xv = ld4(xn + (long)r * C + m.q[s] * 4);
+                float4 dv = ld4(dn + (long)r * C + m.q[s] * 4);
                 float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -473,16 +563,17 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ g
     float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) { gs[((long)n * C + c) * 2] = s1; gs[((long)n * C + c) * 2 + 1] = s2; }
 }
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ dx, const float* __restrict__ x,
-                                                            const float* __restrict__ dy, const float* __restrict__ chn,
+template <typename T>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(T* __restrict__ dx, const T* __restrict__ x,
+                                                            const T* __restrict__ dy, const float* __restrict__ chn,
                                                             const float* __restrict__ gs, long nquads, int HW, int C, int silu,
                                                             float acc_beta) {
     const int Q = C >> 2;
     for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
         int q = (int)(i % Q);
         long n = i / ((long)HW * Q);
-        float4 xv = *reinterpret_cast<const float4*>(x + i * 4);
-        float4 dv = *reinterpret_cast<const float4*>(dy + i * 4);
+        float4 xv = ld4(x + i * 4);
+        float4 dv = ld4(dy + i * 4);
         const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
         const float2* s = reinterpret_cast<const float2*>(gs + (n * C + q * 4) * 2);
         float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
@@ -494,13 +585,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(float* __restrict__ d
             o[j] = kk.y * (dt - ss.x - xh * ss.y);
         }
         if (acc_beta != 0.f) {
-            float4 old = *reinterpret_cast<const float4*>(dx + i * 4);
+            float4 old = ld4(dx + i * 4);
             o[0] += acc_beta * old.x; o[1] += acc_beta * old.y; o[2] += acc_beta * old.z; o[3] += acc_beta * old.w;
         }
-        *reinterpret_cast<float4*>(dx + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+        st4(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
-void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* beta,
+void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma, const float* beta,
                      const float* stats, float* ws, int N, int HW, int C, int G, int silu, float acc_beta, bool chn_valid) {
     CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm bwd: C=%d G=%d unsupported", C, G);
     int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
@@ -509,18 +600,21 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
     float* gs = chn + (size_t)N * C * 4;
     (void)L.count(chn_valid ? 3 : 4);
     if (L.dry) return;
-    const bool big = (double)N * HW * C * 4 >= 64e6;
+    const double esz = (double)dt_size(dt);
+    const bool big = (double)N * HW * C * esz >= 64e6;
     ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_bwd[>=64MB]" : "groupnorm_silu_bwd[<64MB]")
                                                                    : (big ? "groupnorm_bwd[>=64MB]" : "groupnorm_bwd[<64MB]"),
-                                                             0.0, 5.0 * N * HW * (double)C * 4, L.stream);
+                                                             0.0, 5.0 * N * HW * (double)C * esz, L.stream);
     // chn_valid: `ws` is the forward call's workspace and still holds its per-channel constants (the tape's case)
     if (!chn_valid) hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
-    hipLaunchKernelGGL(gn_bwd_partial_kernel, dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, x, dy, chn, HW, C, G,
-                       nchunk, rpb, silu);
-    hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
     long nquads = (long)N * HW * (C / 4);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, dx, x, dy, chn, gs, nquads, HW, C, silu,
-                       acc_beta);
+    CB_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((gn_bwd_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, (const T*)dy,
+                           chn, HW, C, G, nchunk, rpb, silu);
+        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
+        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, chn,
+                           gs, nquads, HW, C, silu, acc_beta);
+    });
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
 }
@@ -528,19 +622,20 @@ void k_groupnorm_bwd(const Launch& L, float* dx, const float* x, const float* dy
 // ------------------------------------------------------------------ LayerNorm: one wave per row, row held in registers
 // attention.py:203-205 norm1..3, HF CLIP layer norms. HBM-bound: 16-byte accesses (C % 4 == 0), C <= 64*4*LN_MAXQ.
 constexpr int LN_MAXQ = 6;
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, const float* __restrict__ x,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
                                                              float* __restrict__ stats, long rows, int C, float eps) {
     long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, Q = C >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
+    const T* xr = x + row * C;
     float4 v[LN_MAXQ];
     float s = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j) {
         int q = lane + j * 64;
-        v[j] = (q < Q) ? xr[q] : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[j] = (q < Q) ? ld4(xr + q * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
         s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
     }
     const float mean = wave_sum(s) / C;
@@ -554,7 +649,7 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
     }
     const float rstd = 1.f / sqrtf(wave_sum(qd) / C + eps);
     if (lane == 0 && stats) { stats[row * 2] = mean; stats[row * 2 + 1] = rstd; }
-    float4* yr = reinterpret_cast<float4*>(y + row * C);
+    T* yr = y + row * C;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float4* b4 = reinterpret_cast<const float4*>(beta);
 #pragma unroll
@@ -562,27 +657,28 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
         int q = lane + j * 64;
         if (q < Q) {
             float4 g = g4[q], b = b4[q];
-            yr[q] = make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
-                                (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w);
+            st4(yr + q * 4, make_float4((v[j].x - mean) * rstd * g.x + b.x, (v[j].y - mean) * rstd * g.y + b.y,
+                                        (v[j].z - mean) * rstd * g.z + b.z, (v[j].w - mean) * rstd * g.w + b.w));
         }
     }
 }
-void k_layernorm_fwd(const Launch& L, float* y, const float* x, const float* gamma, const float* beta, float* stats, long rows,
+void k_layernorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta, float* stats, long rows,
                      int C, float eps) {
     CB_CHECK(C % 4 == 0 && C <= 256 * LN_MAXQ, CB_ERR_SHAPE, "layernorm: C=%d unsupported", C);
-    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_fwd", 0.0, 2.0 * rows * (double)C * 4, L.stream);
-    LAUNCH(layernorm_fwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, y, x, gamma, beta, stats, rows, C, eps);
+    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_fwd", 0.0, 2.0 * rows * (double)C * (double)dt_size(dt), L.stream);
+    CB_DT_SWITCH(dt, T, LAUNCH((layernorm_fwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), L, (T*)y, (const T*)x, gamma, beta, stats, rows, C, eps));
     if (prof) L.prof->end(&rec, L.stream);
 }
 // dx = rstd * (dy*gamma - mean(dy*gamma) - x_hat * mean(dy*gamma*x_hat))
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ x,
-                                                             const float* __restrict__ dy, const float* __restrict__ gamma,
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(T* __restrict__ dx, const T* __restrict__ x,
+                                                             const T* __restrict__ dy, const float* __restrict__ gamma,
                                                              const float* __restrict__ stats, long rows, int C, float acc_beta) {
     long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63, Q = C >> 2;
-    const float4* xr = reinterpret_cast<const float4*>(x + row * C);
-    const float4* dr = reinterpret_cast<const float4*>(dy + row * C);
+    const T* xr = x + row * C;
+    const T* dr = dy + row * C;
     const float4* g4 = reinterpret_cast<const float4*>(gamma);
     const float mean = stats[row * 2], rstd = stats[row * 2 + 1];
     float4 xh[LN_MAXQ], dg[LN_MAXQ];
@@ -591,7 +687,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
     for (int j = 0; j < LN_MAXQ; ++j) {
         int q = lane + j * 64;
         if (q < Q) {
-            float4 xv = xr[q], dv = dr[q], g = g4[q];
+            float4 xv = ld4(xr + q * 4), dv = ld4(dr + q * 4), g = g4[q];
             xh[j] = make_float4((xv.x - mean) * rstd, (xv.y - mean) * rstd, (xv.z - mean) * rstd, (xv.w - mean) * rstd);
             dg[j] = make_float4(dv.x * g.x, dv.y * g.y, dv.z * g.z, dv.w * g.w);
         } else { xh[j] = make_float4(0.f, 0.f, 0.f, 0.f); dg[j] = xh[j]; }
@@ -600,33 +696,34 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
     }
     s1 = wave_sum(s1) / C;
     s2 = wave_sum(s2) / C;
-    float4* o = reinterpret_cast<float4*>(dx + row * C);
+    T* o = dx + row * C;
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j) {
         int q = lane + j * 64;
         if (q < Q) {
             float4 r = make_float4(rstd * (dg[j].x - s1 - xh[j].x * s2), rstd * (dg[j].y - s1 - xh[j].y * s2),
                                    rstd * (dg[j].z - s1 - xh[j].z * s2), rstd * (dg[j].w - s1 - xh[j].w * s2));
-            if (acc_beta != 0.f) { float4 old = o[q]; r.x += acc_beta * old.x; r.y += acc_beta * old.y; r.z += acc_beta * old.z; r.w += acc_beta * old.w; }
-            o[q] = r;
+            if (acc_beta != 0.f) { float4 old = ld4(o + q * 4); r.x += acc_beta * old.x; r.y += acc_beta * old.y; r.z += acc_beta * old.z; r.w += acc_beta * old.w; }
+            st4(o + q * 4, r);
         }
     }
 }
-void k_layernorm_bwd(const Launch& L, float* dx, const float* x, const float* dy, const float* gamma, const float* stats,
+void k_layernorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma, const float* stats,
                      long rows, int C, float acc_beta) {
     CB_CHECK(C % 4 == 0 && C <= 256 * LN_MAXQ, CB_ERR_SHAPE, "layernorm bwd: C=%d unsupported", C);
-    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_bwd", 0.0, 3.0 * rows * (double)C * 4, L.stream);
-    LAUNCH(layernorm_bwd_kernel, dim3(cdiv(rows, 4)), dim3(256), L, dx, x, dy, gamma, stats, rows, C, acc_beta);
+    ProfRec rec; const bool prof = !L.dry && L.prof && L.prof->begin(&rec, "layernorm_bwd", 0.0, 3.0 * rows * (double)C * (double)dt_size(dt), L.stream);
+    CB_DT_SWITCH(dt, T, LAUNCH((layernorm_bwd_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), L, (T*)dx, (const T*)x, (const T*)dy, gamma, stats, rows, C, acc_beta));
     if (prof) L.prof->end(&rec, L.stream);
 }
 
 // ------------------------------------------------------------------ row softmax (materialised attention path)
 // one 256-thread block per row; n <= 256*16
 constexpr int SM_PER_T = 16;
-__global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S, int n, int ld, int causal, int rows_per_mat) {
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_kernel(T* __restrict__ S, int n, int ld, int causal, int rows_per_mat) {
     __shared__ float sh[4];
     long row = blockIdx.x;
-    float* r = S + row * ld;
+    T* r = S + row * ld;
     int lim = causal ? (int)(row % rows_per_mat) + 1 : n;  // columns [0, lim) are visible
     if (lim > n) lim = n;
     float v[SM_PER_T];
@@ -634,7 +731,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S,
 #pragma unroll
     for (int j = 0; j < SM_PER_T; ++j) {
         int c = threadIdx.x + j * 256;
-        v[j] = (c < lim) ? r[c] : -INFINITY;
+        v[j] = (c < lim) ? ld1(r + c) : -INFINITY;
         mx = fmaxf(mx, v[j]);
     }
     mx = block_max256(mx, sh);
@@ -650,17 +747,18 @@ __global__ __launch_bounds__(256) void softmax_fwd_kernel(float* __restrict__ S,
 #pragma unroll
     for (int j = 0; j < SM_PER_T; ++j) {
         int c = threadIdx.x + j * 256;
-        if (c < n) r[c] = v[j] * inv;
+        if (c < n) st1(r + c, v[j] * inv);
     }
 }
 // short rows (cross-attention ctx = 77, CLIP 77, 8x8 / 16x16 self-attention): one wave per row, 4 rows per block
 constexpr int SMW_PER_L = 8;   // n <= 512
-__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(float* __restrict__ S, long rows, int n, int ld, int causal,
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(T* __restrict__ S, long rows, int n, int ld, int causal,
                                                                 int rows_per_mat) {
     long row = blockIdx.x * 4L + (threadIdx.x >> 6);
     if (row >= rows) return;
     int lane = threadIdx.x & 63;
-    float* r = S + row * ld;
+    T* r = S + row * ld;
     int lim = causal ? (int)(row % rows_per_mat) + 1 : n;
     if (lim > n) lim = n;
     float v[SMW_PER_L];
@@ -668,7 +766,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(float* __restrict
 #pragma unroll
     for (int j = 0; j < SMW_PER_L; ++j) {
         int c = lane + j * 64;
-        v[j] = (c < lim) ? r[c] : -INFINITY;
+        v[j] = (c < lim) ? ld1(r + c) : -INFINITY;
         mx = fmaxf(mx, v[j]);
     }
     mx = wave_max(mx);
@@ -683,7 +781,7 @@ __global__ __launch_bounds__(256) void softmax_fwd_wave_kernel(float* __restrict
 #pragma unroll
     for (int j = 0; j < SMW_PER_L; ++j) {
         int c = lane + j * 64;
-        if (c < n) r[c] = v[j] * inv;
+        if (c < n) st1(r + c, v[j] * inv);
     }
 }
 __global__ __launch_bounds__(256) void softmax_bwd_wave_kernel(float* __restrict__ dP, const float* __restrict__ P, long rows, int n,
@@ -709,10 +807,10 @@ __global__ __launch_bounds__(256) void softmax_bwd_wave_kernel(float* __restrict
         if (c < n) d[c] = scale * pv[j] * (dv[j] - s);
     }
 }
-void k_softmax_fwd(const Launch& L, float* S, long rows, int n, int ld, int causal, int rows_per_mat) {
+void k_softmax_fwd(const Launch& L, DType dt, void* S, long rows, int n, int ld, int causal, int rows_per_mat) {
     CB_CHECK(n <= 256 * SM_PER_T, CB_ERR_SHAPE, "softmax: n=%d too large", n);
-    if (n <= 64 * SMW_PER_L) LAUNCH(softmax_fwd_wave_kernel, dim3(cdiv(rows, 4)), dim3(256), L, S, rows, n, ld, causal, rows_per_mat);
-    else LAUNCH(softmax_fwd_kernel, dim3((unsigned)rows), dim3(256), L, S, n, ld, causal, rows_per_mat);
+    if (n <= 64 * SMW_PER_L) CB_DT_SWITCH(dt, T, LAUNCH((softmax_fwd_wave_kernel<T>), dim3(cdiv(rows, 4)), dim3(256), L, (T*)S, rows, n, ld, causal, rows_per_mat));
+    else CB_DT_SWITCH(dt, T, LAUNCH((softmax_fwd_kernel<T>), dim3((unsigned)rows), dim3(256), L, (T*)S, n, ld, causal, rows_per_mat));
 }
 __global__ __launch_bounds__(256) void softmax_bwd_kernel(float* __restrict__ dP, const float* __restrict__ P, int n, int ld,
                                                            float scale) {
@@ -744,23 +842,24 @@ void k_softmax_bwd(const Launch& L, float* dP, const float* P, long rows, int n,
 
 // ------------------------------------------------------------------ diffusion glue
 // util.py:151-171 timestep_embedding: [cos(t*f_i) | sin(t*f_i)], f_i = exp(-ln(10000) * i / half)
-__global__ void timestep_embedding_kernel(float* __restrict__ out, const int64_t* __restrict__ t, int B, int dim) {
+template <typename T> __global__ void timestep_embedding_kernel(T* __restrict__ out, const int64_t* __restrict__ t, int B, int dim) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     int half = dim / 2;
     if (i >= B * half) return;
     int b = i / half, j = i % half;
     float freq = expf(-logf(10000.f) * (float)j / (float)half);
     float arg = (float)t[b] * freq;
-    out[(long)b * dim + j] = cosf(arg);
-    out[(long)b * dim + half + j] = sinf(arg);
-    if ((dim & 1) && j == 0) out[(long)b * dim + dim - 1] = 0.f;
+    st1(out + (long)b * dim + j, cosf(arg));
+    st1(out + (long)b * dim + half + j, sinf(arg));
+    if ((dim & 1) && j == 0) st1(out + (long)b * dim + dim - 1, 0.f);
 }
-void k_timestep_embedding(const Launch& L, float* out, const int64_t* t, int B, int dim) {
-    LAUNCH(timestep_embedding_kernel, dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), L, out, t, B, dim);
+void k_timestep_embedding(const Launch& L, DType dt, void* out, const int64_t* t, int B, int dim) {
+    CB_DT_SWITCH(dt, T, LAUNCH((timestep_embedding_kernel<T>), dim3(cdiv((long)B * (dim / 2), 256)), dim3(256), L, (T*)out, t, B, dim));
 }
 
 // ddpm.py:289-292 q_sample. x0/xt NHWC [B,HW,C]; eps is the caller's NCHW noise.
-__global__ void qsample_kernel(float* __restrict__ xt, const float* __restrict__ x0, const float* __restrict__ eps,
+template <typename T>
+__global__ void qsample_kernel(T* __restrict__ xt, const T* __restrict__ x0, const float* __restrict__ eps,
                                const int64_t* __restrict__ t, const float* __restrict__ sa, const float* __restrict__ sb, int B,
                                int C, int HW) {
     long total = (long)B * C * HW;
@@ -771,12 +870,12 @@ __global__ void qsample_kernel(float* __restrict__ xt, const float* __restrict__
         long b = r / HW;
         float e = eps[(b * C + c) * HW + hw];
         int64_t tt = t[b];
-        xt[i] = sa[tt] * x0[i] + sb[tt] * e;
+        st1(xt + i, sa[tt] * ld1(x0 + i) + sb[tt] * e);
     }
 }
-void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
+void k_qsample(const Launch& L, DType dt, void* xt, const void* x0, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
                const float* sqrt_1mac, int B, int C, int HW) {
-    LAUNCH(qsample_kernel, grid1d((long)B * C * HW), dim3(256), L, xt, x0, eps_nchw, t, sqrt_ac, sqrt_1mac, B, C, HW);
+    CB_DT_SWITCH(dt, T, LAUNCH((qsample_kernel<T>), grid1d((long)B * C * HW), dim3(256), L, (T*)xt, (const T*)x0, eps_nchw, t, sqrt_ac, sqrt_1mac, B, C, HW));
 }
 
 // ddim.py:166-204 p_sample_ddim, eps-parameterisation. x (NHWC [n,HW,C]) is updated in place; eps holds the UNet output:
@@ -785,12 +884,13 @@ void k_qsample(const Launch& L, float* xt, const float* x0, const float* eps_nch
 //   pred_x0 = (x - sqrt(1-a_t) e) / sqrt(a_t)                       (:189)
 //   x_prev  = sqrt(a_prev) pred_x0 + sqrt(1 - a_prev - sigma^2) e + sigma * noise     (:193-198)
 // The scalar coefficients are evaluated on the host in fp32 exactly as the reference's torch.full(...) tensors are.
-__global__ void ddim_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const float* __restrict__ eps,
+template <typename T>
+__global__ void ddim_update_kernel(float* __restrict__ x, float* __restrict__ pred_x0, const T* __restrict__ eps,
                                    const float* __restrict__ noise_nchw, long half, int C, int HW, int cfg, float scale,
                                    float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma) {
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < half; i += (long)gridDim.x * blockDim.x) {
-        float e = eps[cfg ? half + i : i];
-        if (cfg) { float eu = eps[i]; e = eu + scale * (e - eu); }
+        float e = ld1(eps + (cfg ? half + i : i));
+        if (cfg) { float eu = ld1(eps + i); e = eu + scale * (e - eu); }
         float xv = x[i];
         float p0 = __fdiv_rn(xv - sqrt_1m_at * e, sqrt_at);
         float dir = dir_coef * e;
@@ -805,11 +905,11 @@ __global__ void ddim_update_kernel(float* __restrict__ x, float* __restrict__ pr
         if (pred_x0) pred_x0[i] = p0;
     }
 }
-void k_ddim_update(const Launch& L, float* x, float* pred_x0, const float* eps, const float* noise_nchw, int n, int C, int HW,
+void k_ddim_update(const Launch& L, DType dt, float* x, float* pred_x0, const void* eps, const float* noise_nchw, int n, int C, int HW,
                    int cfg, float scale, float sqrt_1m_at, float sqrt_at, float sqrt_aprev, float dir_coef, float sigma) {
     long half = (long)n * C * HW;
-    LAUNCH(ddim_update_kernel, grid1d(half), dim3(256), L, x, pred_x0, eps, noise_nchw, half, C, HW, cfg, scale, sqrt_1m_at,
-           sqrt_at, sqrt_aprev, dir_coef, sigma);
+    CB_DT_SWITCH(dt, T, LAUNCH((ddim_update_kernel<T>), grid1d(half), dim3(256), L, x, pred_x0, (const T*)eps, noise_nchw, half, C, HW, cfg, scale,
+                               sqrt_1m_at, sqrt_at, sqrt_aprev, dir_coef, sigma));
 }
 __global__ void fill_i64_kernel(int64_t* p, long n, int64_t v) {
     long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
@@ -819,25 +919,26 @@ void k_fill_i64(const Launch& L, int64_t* p, long n, int64_t v) {
     LAUNCH(fill_i64_kernel, dim3(cdiv(n, 256)), dim3(256), L, p, n, v);
 }
 // stable_txt2img.py:343: clamp((x + 1) / 2, 0, 1), NHWC -> NCHW
-__global__ void image_out_kernel(float* __restrict__ dst, const float* __restrict__ src, int N, int C, int HW, int to01) {
+template <typename T> __global__ void image_out_kernel(float* __restrict__ dst, const T* __restrict__ src, int N, int C, int HW, int to01) {
     long total = (long)N * C * HW;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long hw = i % HW;
         long r = i / HW;
         int c = (int)(r % C);
         long b = r / C;
-        float v = src[(b * HW + hw) * C + c];
+        float v = ld1(src + (b * HW + hw) * C + c);
         if (to01) v = fminf(fmaxf((v + 1.0f) / 2.0f, 0.f), 1.f);
         dst[i] = v;
     }
 }
-void k_image_out(const Launch& L, float* dst_nchw, const float* src_nhwc, int N, int C, int HW, int to01) {
-    LAUNCH(image_out_kernel, grid1d((long)N * C * HW), dim3(256), L, dst_nchw, src_nhwc, N, C, HW, to01);
+void k_image_out(const Launch& L, DType sdt, float* dst_nchw, const void* src_nhwc, int N, int C, int HW, int to01) {
+    CB_DT_SWITCH(sdt, T, LAUNCH((image_out_kernel<T>), grid1d((long)N * C * HW), dim3(256), L, dst_nchw, (const T*)src_nhwc, N, C, HW, to01));
 }
 
 // ddpm.py:1069-1116 with l2 / eps-parameterisation / logvar==0: loss = mean((pred - eps)^2); dpred = 2 (pred-eps)/numel
-__global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss, float* __restrict__ dpred,
-                                                        const float* __restrict__ pred, const float* __restrict__ target, int B,
+template <typename T>
+__global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss, T* __restrict__ dpred,
+                                                        const T* __restrict__ pred, const float* __restrict__ target, int B,
                                                         int C, int HW) {
     __shared__ float sh[4];
     long total = (long)B * C * HW;
@@ -848,24 +949,26 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss,
         long r = i / C;
         long hw = r % HW;
         long b = r / HW;
-        float d = pred[i] - target[(b * C + c) * HW + hw];
+        float d = ld1(pred + i) - target[(b * C + c) * HW + hw];
         acc += d * d;
-        if (dpred) dpred[i] = 2.f * d * inv;
+        if (dpred) st1(dpred + i, 2.f * d * inv);
     }
     acc = block_sum256(acc, sh);
     if (threadIdx.x == 0) atomicAdd(loss, acc * inv);
 }
-void k_mse_loss(const Launch& L, float* loss, float* dpred, const float* pred, const float* target_nchw, int B, int C, int HW) {
-    LAUNCH(fill_kernel, dim3(1), dim3(64), L, loss, 1L, 0.f);
+void k_mse_loss(const Launch& L, DType dt, float* loss, void* dpred, const void* pred, const float* target_nchw, int B, int C, int HW) {
+    LAUNCH((fill_kernel<float>), dim3(1), dim3(64), L, loss, 1L, 0.f);
     // one block up to 256K elements (the latent of bs <= 16): the scalar is then summed in a fixed order — with several blocks
     // the float atomicAdd order, and with it the last bits of the reported loss, would vary from run to run
     const long total = (long)B * C * HW;
-    LAUNCH(mse_loss_kernel, total <= (1L << 18) ? dim3(1) : grid1d(total, 256, 64), dim3(256), L, loss, dpred, pred, target_nchw, B, C, HW);
+    CB_DT_SWITCH(dt, T, LAUNCH((mse_loss_kernel<T>), total <= (1L << 18) ? dim3(1) : grid1d(total, 256, 64), dim3(256), L, loss, (T*)dpred,
+                               (const T*)pred, target_nchw, B, C, HW));
 }
 
 // distributions.py:24-37 + ddpm.py:597: z = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale
 // moments NHWC [B,HW,2*Cz]; noise NCHW [B,Cz,HW]; z NHWC [B,HW,Cz]
-__global__ void vae_sample_kernel(float* __restrict__ z, const float* __restrict__ mom, const float* __restrict__ noise, int B,
+template <typename T>
+__global__ void vae_sample_kernel(T* __restrict__ z, const T* __restrict__ mom, const float* __restrict__ noise, int B,
                                   int HW, int Cz, float scale) {
     long total = (long)B * HW * Cz;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -873,14 +976,14 @@ __global__ void vae_sample_kernel(float* __restrict__ z, const float* __restrict
         long r = i / Cz;
         long hw = r % HW;
         long b = r / HW;
-        float mean = mom[r * 2 * Cz + c];
-        float lv = fminf(fmaxf(mom[r * 2 * Cz + Cz + c], -30.f), 20.f);
+        float mean = ld1(mom + r * 2 * Cz + c);
+        float lv = fminf(fmaxf(ld1(mom + r * 2 * Cz + Cz + c), -30.f), 20.f);
         float nz = noise ? noise[(b * Cz + c) * HW + hw] : 0.f;
-        z[i] = (mean + expf(0.5f * lv) * nz) * scale;
+        st1(z + i, (mean + expf(0.5f * lv) * nz) * scale);
     }
 }
-void k_vae_sample(const Launch& L, float* z, const float* moments, const float* noise_nchw, int B, int HW, int Cz, float scale) {
-    LAUNCH(vae_sample_kernel, grid1d((long)B * HW * Cz), dim3(256), L, z, moments, noise_nchw, B, HW, Cz, scale);
+void k_vae_sample(const Launch& L, DType dt, void* z, const void* moments, const float* noise_nchw, int B, int HW, int Cz, float scale) {
+    CB_DT_SWITCH(dt, T, LAUNCH((vae_sample_kernel<T>), grid1d((long)B * HW * Cz), dim3(256), L, (T*)z, (const T*)moments, noise_nchw, B, HW, Cz, scale));
 }
 
 __global__ void gather_rows_kernel(float* __restrict__ out, const float* __restrict__ table, const int64_t* __restrict__ idx,
@@ -897,17 +1000,18 @@ void k_gather_rows(const Launch& L, float* out, const float* table, const int64_
     LAUNCH(gather_rows_kernel, grid1d(rows * C), dim3(256), L, out, table, idx, rows, C, table_rows);
 }
 // dst[r][c] = x[r][c] + pos[r % period][c]
-__global__ void add_rowbcast_kernel(float* __restrict__ dst, const float* __restrict__ x, const float* __restrict__ pos,
+template <typename T>
+__global__ void add_rowbcast_kernel(T* __restrict__ dst, const T* __restrict__ x, const float* __restrict__ pos,
                                     long rows, int period, int C) {
     long total = rows * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         long r = i / C;
         int c = (int)(i - r * C);
-        dst[i] = x[i] + pos[(r % period) * C + c];
+        st1(dst + i, ld1(x + i) + pos[(r % period) * C + c]);
     }
 }
-void k_add_rowbcast(const Launch& L, float* dst, const float* x, const float* pos, long rows, int period, int C) {
-    LAUNCH(add_rowbcast_kernel, grid1d(rows * C), dim3(256), L, dst, x, pos, rows, period, C);
+void k_add_rowbcast(const Launch& L, DType dt, void* dst, const void* x, const float* pos, long rows, int period, int C) {
+    CB_DT_SWITCH(dt, T, LAUNCH((add_rowbcast_kernel<T>), grid1d(rows * C), dim3(256), L, (T*)dst, (const T*)x, pos, rows, period, C));
 }
 
 // ------------------------------------------------------------------ face pre-processing (meta_net.py:250-260)
@@ -1327,77 +1431,78 @@ __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x 
 void k_step_inc(const Launch& L, int* step) { LAUNCH(step_inc_kernel, dim3(1), dim3(64), L, step); }
 
 // y[m][n] = sum_k x[m][k] W[n][k] + bias[n], M <= 8: one wave per output column, weight-streaming bound
-__global__ __launch_bounds__(256) void gemv_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ W,
+template <typename T>
+__global__ __launch_bounds__(256) void gemv_kernel(T* __restrict__ y, const T* __restrict__ x, const T* __restrict__ W,
                                                     const float* __restrict__ bias, int M, int N, int K) {
     int n = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (n >= N) return;
     int lane = threadIdx.x & 63;
-    const float* w = W + (long)n * K;
+    const T* w = W + (long)n * K;
     float acc[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) acc[m] = 0.f;
     if ((K & 3) == 0) {
         for (int k = lane * 4; k < K; k += 256) {
-            float4 wv = *reinterpret_cast<const float4*>(w + k);
+            float4 wv = ld4(w + k);
 #pragma unroll
             for (int m = 0; m < 8; ++m)
                 if (m < M) {
-                    float4 xv = *reinterpret_cast<const float4*>(x + (long)m * K + k);
+                    float4 xv = ld4(x + (long)m * K + k);
                     acc[m] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
                 }
         }
     } else {
         for (int k = lane; k < K; k += 64) {
-            float wv = w[k];
+            float wv = ld1(w + k);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) if (m < M) acc[m] += wv * x[(long)m * K + k];
+            for (int m = 0; m < 8; ++m) if (m < M) acc[m] += wv * ld1(x + (long)m * K + k);
         }
     }
 #pragma unroll
     for (int m = 0; m < 8; ++m)
         if (m < M) {
             float s = wave_sum(acc[m]);
-            if (lane == 0) y[(long)m * N + n] = s + (bias ? bias[n] : 0.f);
+            if (lane == 0) st1(y + (long)m * N + n, s + (bias ? bias[n] : 0.f));
         }
 }
-void k_gemv(const Launch& L, float* y, const float* x, const float* W, const float* bias, int M, int N, int K) {
+void k_gemv(const Launch& L, DType dt, void* y, const void* x, const void* W, const float* bias, int M, int N, int K) {
     CB_CHECK(M >= 1 && M <= 8, CB_ERR_SHAPE, "gemv: M=%d must be in 1..8", M);
     if (L.stats) L.stats->gemm_flops += 2.0 * M * N * (double)K;
-    LAUNCH(gemv_kernel, dim3(cdiv(N, 4)), dim3(256), L, y, x, W, bias, M, N, K);
+    CB_DT_SWITCH(dt, T, LAUNCH((gemv_kernel<T>), dim3(cdiv(N, 4)), dim3(256), L, (T*)y, (const T*)x, (const T*)W, bias, M, N, K));
 }
 
 // ------------------------------------------------------------------ one-time weight packing
 // OIHW -> [O][ky][kx][I]  (B operand of the implicit GEMM, k = (ky*ks+kx)*I + ci)
-__global__ void pack_conv_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
-    long total = (long)O * I * ks * ks;
+template <typename T> __global__ void pack_conv_kernel(T* __restrict__ out, const float* __restrict__ w, int O, int I, int ks, int Ip) {
+    long total = (long)O * Ip * ks * ks;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int ci = (int)(i % I);
-        long r = i / I;
+        int ci = (int)(i % Ip);
+        long r = i / Ip;
         int kx = (int)(r % ks);
         r /= ks;
         int ky = (int)(r % ks);
         long o = r / ks;
-        out[i] = w[((o * I + ci) * ks + ky) * ks + kx];
+        st1(out + i, ci < I ? w[((o * I + ci) * ks + ky) * ks + kx] : 0.f);
     }
 }
-void k_pack_conv(const Launch& L, float* out, const float* w, int O, int I, int ks) {
-    LAUNCH(pack_conv_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
+void k_pack_conv(const Launch& L, DType dt, void* out, const float* w, int O, int I, int ks, int Ip) {
+    CB_DT_SWITCH(dt, T, LAUNCH((pack_conv_kernel<T>), grid1d((long)O * Ip * ks * ks), dim3(256), L, (T*)out, w, O, I, ks, Ip));
 }
 // OIHW -> [I][ky'][kx'][O] with the kernel flipped: out[ci][ky'][kx'][co] = w[co][ci][ks-1-ky'][ks-1-kx']
-__global__ void pack_conv_dgrad_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int I, int ks) {
-    long total = (long)O * I * ks * ks;
+template <typename T> __global__ void pack_conv_dgrad_kernel(T* __restrict__ out, const float* __restrict__ w, int O, int I, int ks, int Op) {
+    long total = (long)Op * I * ks * ks;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        int co = (int)(i % O);
-        long r = i / O;
+        int co = (int)(i % Op);
+        long r = i / Op;
         int kx = (int)(r % ks);
         r /= ks;
         int ky = (int)(r % ks);
         long ci = r / ks;
-        out[i] = w[(((long)co * I + ci) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)];
+        st1(out + i, co < O ? w[(((long)co * I + ci) * ks + (ks - 1 - ky)) * ks + (ks - 1 - kx)] : 0.f);
     }
 }
-void k_pack_conv_dgrad(const Launch& L, float* out, const float* w, int O, int I, int ks) {
-    LAUNCH(pack_conv_dgrad_kernel, grid1d((long)O * I * ks * ks), dim3(256), L, out, w, O, I, ks);
+void k_pack_conv_dgrad(const Launch& L, DType dt, void* out, const float* w, int O, int I, int ks, int Op) {
+    CB_DT_SWITCH(dt, T, LAUNCH((pack_conv_dgrad_kernel<T>), grid1d((long)Op * I * ks * ks), dim3(256), L, (T*)out, w, O, I, ks, Op));
 }
 // fc over torch.flatten(NCHW): w[o][c*HW + hw] -> out[o][hw*C + c]   (iresnet.py:176-179)
 __global__ void pack_fc_nhwc_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int C, int HW) {

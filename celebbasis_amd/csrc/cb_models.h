@@ -21,6 +21,7 @@ struct UBlock { bool has_res = false; ResBlockW res; bool has_xf = false; XfmrW 
                 bool has_up = false; Conv up; };
 struct UNet {
     UNetCfg cfg;
+    DType dt = DT_F32;   // element type of activations and GEMM weights (the context's dtype at load)
     Lin te0, te2;
     Conv conv_in;
     std::vector<UBlock> in_blocks;      // input_blocks[1..]
@@ -40,6 +41,7 @@ struct VaeCfg { int ch = 128; int ch_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0}; int n_m
 struct VResW { Norm n1; Conv c1; Norm n2; Conv c2; bool has_nin = false; Lin nin; };
 struct VaeEnc {
     VaeCfg cfg;
+    DType dt = DT_F32;
     Conv conv_in;
     std::vector<std::vector<VResW>> down; std::vector<Conv> downsample; std::vector<bool> has_down;
     VResW mid1, mid2; Norm attn_norm; Lin attn_qkv, attn_proj;
@@ -51,6 +53,7 @@ Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img /*[B,H,W,3]*/);   //
 // ---------------------------------------------------------------- VAE decoder (model.py:462-568, autoencoder.py:330-333) — sampling path
 struct VaeDec {
     VaeCfg cfg;
+    DType dt = DT_F32;
     Lin post_quant;
     Conv conv_in;
     VResW mid1, mid2; Norm attn_norm; Lin attn_qkv, attn_proj;
@@ -66,6 +69,7 @@ struct ClipCfg { int vocab = 49408, width = 768, layers = 12, heads = 12, ctx_le
 struct ClipLayerW { Norm ln1, ln2; Lin qkv, out, fc1, fc2; };
 struct Clip {
     ClipCfg cfg;
+    DType dt = DT_F32;
     float* tok_emb = nullptr; float* pos_emb = nullptr;
     std::vector<ClipLayerW> layers;
     Norm final_ln;
@@ -122,7 +126,7 @@ struct Trainer {
         hipStream_t stream = nullptr; hipEvent_t ready = nullptr;
         Arena arena; size_t need = 0; int planned_B = 0;
         // two result slots: prefetch(n+1) is enqueued before step(n) consumes slot n
-        struct Slot { float* z0 = nullptr; float* feat = nullptr; hipEvent_t done = nullptr;
+        struct Slot { void* z0 = nullptr; float* feat = nullptr; hipEvent_t done = nullptr;
                       const void *image = nullptr, *faces = nullptr, *post_noise = nullptr; int B = 0; bool valid = false; } slot[2];
         int next = 0;
         ~Prefetch() {

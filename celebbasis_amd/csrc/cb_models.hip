@@ -49,6 +49,7 @@ static XfmrW load_xfmr(Ctx* ctx, const WTab& wt, const std::string& p, int ch, i
 
 void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& cfg, UNet* U) {
     U->cfg = cfg;
+    ctx->load_dt = U->dt = ctx->dtype;
     const int mc = cfg.model_channels, ted = 4 * mc;
     auto in_attn = [&](int ds) { for (int i = 0; i < cfg.n_attn; ++i) if (cfg.attention_resolutions[i] == ds) return true; return false; };
     U->te0 = load_linear(ctx, wt, pre + "time_embed.0", mc, ted);
@@ -140,8 +141,9 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     const int B = x->n, mc = U.cfg.model_channels;
     CB_CHECK(x->c == U.cfg.in_channels, CB_ERR_SHAPE, "unet: input channels %d vs %d", x->c, U.cfg.in_channels);
     CB_CHECK(context->c == U.cfg.context_dim && context->n == B, CB_ERR_SHAPE, "unet: context shape");
-    Ten* temb = G.make(B, 1, 1, mc);
-    k_timestep_embedding(G.L, temb->p, t_dev, B, mc);
+    CB_CHECK(x->dt == U.dt && context->dt == U.dt, CB_ERR_ARG, "unet: inputs must have the element type of the weights");
+    Ten* temb = G.make(B, 1, 1, mc, false, U.dt);
+    k_timestep_embedding(G.L, U.dt, temb->p, t_dev, B, mc);
     Ten* e = G.linear(temb, U.te0);
     e = G.silu(e);
     Ten* emb = G.linear(e, U.te2);
@@ -150,8 +152,8 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     // zero-filled up front because the 16 layers each accumulate into their own disjoint column block.
     Ten* kv_all = G.linear(context, U.kv_all);
     if (kv_all->rg) {
-        float beta; float* g = G.grad(kv_all, &beta);
-        k_fill(G.L, g, kv_all->numel(), 0.f);
+        float beta; void* g = G.grad(kv_all, &beta);
+        k_fill(G.L, kv_all->dt, g, kv_all->numel(), 0.f);
     }
     std::vector<Ten*> hs;
     Ten* h = G.conv(x, U.conv_in, CONV_SAME);
@@ -195,6 +197,7 @@ static VResW load_vres(Ctx* ctx, const WTab& wt, const std::string& p, int cin, 
 }
 void vae_load(Ctx* ctx, const WTab& wt, const std::string& pre, const VaeCfg& cfg, VaeEnc* V) {
     V->cfg = cfg;
+    ctx->load_dt = V->dt = ctx->dtype;
     const std::string e = pre + "encoder.";
     V->conv_in = load_conv(ctx, wt, e + "conv_in", cfg.in_channels, cfg.ch, 3, false);
     int block_in = cfg.ch;
@@ -253,6 +256,7 @@ Ten* vae_encode_moments(Graph& G, const VaeEnc& V, Ten* img) {
 // ================================================================= VAE decoder (sampling path)
 void vae_dec_load(Ctx* ctx, const WTab& wt, const std::string& pre, const VaeCfg& cfg, VaeDec* V) {
     V->cfg = cfg;
+    ctx->load_dt = V->dt = ctx->dtype;
     const std::string d = pre + "decoder.";
     V->post_quant = load_conv1x1_as_linear(ctx, wt, pre + "post_quant_conv", cfg.z_channels, cfg.z_channels);
     int block_in = cfg.ch * cfg.ch_mult[cfg.n_mult - 1];
@@ -299,6 +303,10 @@ Ten* vae_decode(Graph& G, const VaeDec& V, Ten* z) {
 // ================================================================= CLIP text transformer
 void clip_load(Ctx* ctx, const WTab& wt, const std::string& pre, const ClipCfg& cfg, Clip* C) {
     C->cfg = cfg;
+    // The text transformer sits on the COEFFICIENT side of the step: the gradient of the loss reaches the two pseudo-word rows
+    // through its backward. Config 3 is "bf16 UNet + fp32 coefficient gradient" (BASELINE.json), so it stays fp32 in both modes
+    // (26 GFLOP of 2.9 TFLOP per sample, on the side stream under the VAE encode); its output is cast once for the UNet.
+    ctx->load_dt = C->dt = DT_F32;
     const int w = cfg.width;
     C->tok_emb = ctx->upload(wt, pre + "embeddings.token_embedding.weight", {cfg.vocab, w});
     C->pos_emb = ctx->upload(wt, pre + "embeddings.position_embedding.weight", {cfg.ctx_len, w});
@@ -319,14 +327,15 @@ Ten* clip_encode(Graph& G, const Clip& C, Ten* embedded) {
     const int w = C.cfg.width, L = embedded->h * embedded->w;
     CB_CHECK(embedded->c == w && L <= C.cfg.ctx_len, CB_ERR_SHAPE, "clip: embedded shape");
     // embeddings = inputs_embeds + position_embedding (modules.py:295-296)
-    Ten* x = G.make(embedded->n, embedded->h, embedded->w, w, embedded->rg);
-    k_add_rowbcast(G.L, x->p, embedded->p, C.pos_emb, embedded->rows(), L, w);
+    embedded = G.cast(embedded, C.dt);          // the manager hook and its gradient are fp32; the transformer runs in C.dt
+    Ten* x = G.make(embedded->n, embedded->h, embedded->w, w, embedded->rg, C.dt);
+    k_add_rowbcast(G.L, C.dt, x->p, embedded->p, C.pos_emb, embedded->rows(), L, w);
     if (embedded->rg) {
         Graph* g = &G;
         G.tape.push_back([g, x, embedded]() {
             if (!x->ginit) return;
-            float beta; float* ge = g->grad(embedded, &beta);
-            k_axpby(g->L, ge, x->g, x->numel(), 1.f, beta);
+            float beta; void* ge = g->grad(embedded, &beta);
+            k_axpby(g->L, x->dt, ge, x->g, x->numel(), 1.f, beta);
         });
     }
     const float scale = 1.f / sqrtf((float)(w / C.cfg.heads));
@@ -362,10 +371,11 @@ static Conv load_conv_bn(Ctx* ctx, const WTab& wt, const std::string& conv, cons
     float* m = ctx->upload(wt, bn + ".running_mean", {cout});
     float* v = ctx->upload(wt, bn + ".running_var", {cout});
     c.b = ctx->pool.allocf(cout);
-    k_fold_bn(ctx->launch(), c.w, c.b, w, bb, m, v, 1e-5f, cout, (long)ks * ks * cin);
+    k_fold_bn(ctx->launch(), static_cast<float*>(c.w), c.b, w, bb, m, v, 1e-5f, cout, (long)ks * ks * cin);
     return c;
 }
 void frnet_load(Ctx* ctx, const WTab& wt, const std::string& pre, FrNet* F, const int* layers, int width, int in_size) {
+    ctx->load_dt = DT_F32;      // the face-recognition backbone feeds the fp32 coefficient head: always fp32 (SURVEY §8 d, config 3)
     for (int i = 0; i < 4; ++i) F->layers[i] = layers[i];
     F->width = width; F->in_size = in_size;
     F->conv1 = load_conv_bn(ctx, wt, pre + "conv1", pre + "bn1", 3, width, 3);
@@ -394,8 +404,9 @@ void frnet_load(Ctx* ctx, const WTab& wt, const std::string& pre, FrNet* F, cons
     float* fcw = ctx->upload(wt, pre + "fc.weight", {F->feat, (int64_t)C * HW});
     float* fcb = ctx->upload(wt, pre + "fc.bias", {F->feat});
     F->fc.in = C * HW; F->fc.out = F->feat;
-    F->fc.w = ctx->pool.allocf((size_t)F->feat * C * HW);
-    k_pack_fc_nhwc(ctx->launch(), F->fc.w, fcw, F->feat, C, HW);
+    float* fcp = ctx->pool.allocf((size_t)F->feat * C * HW);
+    F->fc.w = fcp;
+    k_pack_fc_nhwc(ctx->launch(), fcp, fcw, F->feat, C, HW);
     // features = BatchNorm1d after fc (iresnet.py:180): y = (W x + b) * s + t
     float *fs_, *ft_;
     bn_affine(ctx, wt, pre + "features", F->feat, &fs_, &ft_);
@@ -405,7 +416,7 @@ void frnet_load(Ctx* ctx, const WTab& wt, const std::string& pre, FrNet* F, cons
         float* bb = ctx->upload(wt, pre + "features.bias", {F->feat});
         float* m = ctx->upload(wt, pre + "features.running_mean", {F->feat});
         float* v = ctx->upload(wt, pre + "features.running_var", {F->feat});
-        k_fold_bn(ctx->launch(), F->fc.w, dummy, w, bb, m, v, 1e-5f, F->feat, (long)C * HW);
+        k_fold_bn(ctx->launch(), fcp, dummy, w, bb, m, v, 1e-5f, F->feat, (long)C * HW);
     }
     F->fc.b = ctx->pool.allocf(F->feat);
     k_channel_affine(ctx->launch(), F->fc.b, fcb, fs_, ft_, nullptr, 1, F->feat);   // b*s + t
@@ -421,7 +432,7 @@ Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
         x = G.conv(o, b.c2, b.stride == 2 ? CONV_DOWN : CONV_SAME, nullptr, idn);
     }
     x = G.channel_affine(x, F.bn2_s, F.bn2_b, nullptr);
-    Ten* flat = G.wrap(x->p, x->n, 1, 1, x->h * x->w * x->c);
+    Ten* flat = G.wrap(x->p, x->n, 1, 1, x->h * x->w * x->c, false, DT_F32);
     Ten* f = G.linear(flat, F.fc);
     G.tap("frnet.features", f);
     return f;
@@ -464,6 +475,7 @@ void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     }
 }
 
+constexpr int kMaxBatch = 8;
 static const float kTheta[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f,     // meta_net.py:131-142 trans_matrix
                                 0.03625215f, 1.07695457f, -5.32134629f / 512.f};
 
@@ -478,19 +490,19 @@ struct Phase {
 static Ten* first_stage_faces(Graph& G, Trainer* T, const Batch& bt) {
     const TrainerCfg& c = T->cfg;
     const int NF = 2 * bt.B, S_ = c.image_size;
-    Ten* warped = G.make(NF, S_, S_, 3);
-    k_affine_warp(G.L, warped->p, bt.faces, bt.B, S_, 2, kTheta);
-    Ten* small = G.make(NF, c.fr_in, c.fr_in, 3);
-    k_resize_bilinear_ac(G.L, small->p, warped->p, NF, S_, S_, c.fr_in, c.fr_in, 3);
+    Ten* warped = G.make(NF, S_, S_, 3, false, DT_F32);
+    k_affine_warp(G.L, warped->pf(), bt.faces, bt.B, S_, 2, kTheta);
+    Ten* small = G.make(NF, c.fr_in, c.fr_in, 3, false, DT_F32);
+    k_resize_bilinear_ac(G.L, small->pf(), warped->pf(), NF, S_, S_, c.fr_in, c.fr_in, 3);
     return frnet_forward(G, T->fr, small);
 }
 // first stage, part B: VAE encode -> posterior sample * scale_factor (ddpm.py:702-759, 590-597), no grad -> z0 [B,h,w,zc]
 static Ten* first_stage_latent(Graph& G, Trainer* T, const Batch& bt) {
     const TrainerCfg& c = T->cfg;
-    Ten* img = G.wrap(const_cast<float*>(bt.image), bt.B, c.image_size, c.image_size, c.vae.in_channels);
+    Ten* img = G.cast(G.wrap(bt.image, bt.B, c.image_size, c.image_size, c.vae.in_channels, false, DT_F32), T->vae.dt);
     Ten* mom = vae_encode_moments(G, T->vae, img);
-    Ten* z0 = G.make(bt.B, mom->h, mom->w, c.vae.z_channels);
-    k_vae_sample(G.L, z0->p, mom->p, bt.post_noise, bt.B, mom->h * mom->w, c.vae.z_channels, c.scale_factor);
+    Ten* z0 = G.make(bt.B, mom->h, mom->w, c.vae.z_channels, false, mom->dt);
+    k_vae_sample(G.L, mom->dt, z0->p, mom->p, bt.post_noise, bt.B, mom->h * mom->w, c.vae.z_channels, c.scale_factor);
     return z0;
 }
 
@@ -500,12 +512,12 @@ static void prefetch_impl(Trainer* T, const Batch& bt, Trainer::Prefetch::Slot& 
     G.L.stream = T->pf.stream;
     Ten* feat = first_stage_faces(G, T, bt);
     Ten* z0 = first_stage_latent(G, T, bt);
-    k_axpby(G.L, sl.feat, feat->p, feat->numel(), 1.f, 0.f);
-    k_axpby(G.L, sl.z0, z0->p, z0->numel(), 1.f, 0.f);
+    k_axpby(G.L, sl.feat, feat->pf(), feat->numel(), 1.f, 0.f);
+    k_axpby(G.L, z0->dt, sl.z0, z0->p, z0->numel(), 1.f, 0.f);
 }
 void trainer_prefetch(Trainer* T, const Batch& bt) {
     Ctx* ctx = T->ctx;
-    CB_CHECK(bt.B >= 1 && bt.B <= 4, CB_ERR_ARG, "trainer: batch %d unsupported (1..4)", bt.B);
+    CB_CHECK(bt.B >= 1 && bt.B <= kMaxBatch, CB_ERR_ARG, "trainer: batch %d unsupported (1..%d)", bt.B, kMaxBatch);
     Trainer::Prefetch& pf = T->pf;
     const TrainerCfg& c = T->cfg;
     if (ctx->dry) return;
@@ -515,8 +527,8 @@ void trainer_prefetch(Trainer* T, const Batch& bt) {
         const int lat = c.image_size / (1 << (c.vae.n_mult - 1));
         for (auto& sl : pf.slot) {
             CB_HIP(hipEventCreateWithFlags(&sl.done, hipEventDisableTiming));
-            sl.z0 = ctx->pool.allocf((size_t)4 * lat * lat * c.vae.z_channels);      // sized for the largest batch (4)
-            sl.feat = ctx->pool.allocf((size_t)2 * 4 * T->fr.feat);
+            sl.z0 = ctx->pool.allocf((size_t)kMaxBatch * lat * lat * c.vae.z_channels);      // sized for the largest batch
+            sl.feat = ctx->pool.allocf((size_t)2 * kMaxBatch * T->fr.feat);
         }
     }
     Trainer::Prefetch::Slot& sl = pf.slot[pf.next];
@@ -577,33 +589,33 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         ps->valid = false;                              // consumed; the slot is rewritten no earlier than the prefetch after next
     }
     std::unique_ptr<Phase> ph_id(new Phase(L, "phase:frnet_head"));
-    Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat) : first_stage_faces(G, T, bt);
+    Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat, false, DT_F32) : first_stage_faces(G, T, bt);
     const int I = T->fr.feat, O = es * K;
-    Ten* v = G.make(NF, 1, 1, I);
-    k_l2norm_fwd(L, v->p, nullptr, feat->p, NF, I);
+    Ten* v = G.make(NF, 1, 1, I, false, DT_F32);
+    k_l2norm_fwd(L, v->pf(), nullptr, feat->pf(), NF, I);
     Lin head; head.w = T->W; head.b = T->b; head.in = I; head.out = O;
     Ten* pre = G.linear(v, head);                         // EqualLinear with lr_mul = 1 (meta_net.py:41-48)
-    Ten* act = G.make(NF, 1, 1, O);
-    k_leakyrelu_fwd(L, act->p, pre->p, act->numel(), 0.2f);
-    Ten* xn = G.make(NF * es, 1, 1, K);                   // 'b (e h d) -> b e h d', h = 1
+    Ten* act = G.make(NF, 1, 1, O, false, DT_F32);
+    k_leakyrelu_fwd(L, act->pf(), pre->pf(), act->numel(), 0.2f);
+    Ten* xn = G.make(NF * es, 1, 1, K, false, DT_F32);    // 'b (e h d) -> b e h d', h = 1
     float* cn = ctx->arena.allocf((size_t)NF * es);
-    k_l2norm_fwd(L, xn->p, cn, act->p, (long)NF * es, K);
-    Ten* zz = G.make(NF, es, 1, w);
-    k_basis_fwd(L, zz->p, xn->p, T->basis, NF, es, K, w);
+    k_l2norm_fwd(L, xn->pf(), cn, act->pf(), (long)NF * es, K);
+    Ten* zz = G.make(NF, es, 1, w, false, DT_F32);
+    k_basis_fwd(L, zz->pf(), xn->pf(), T->basis, NF, es, K, w);
     G.tap("coef", xn); G.tap("zz", zz);
     // momentum dictionaries (embedding_manager.py:484-489) use the first face chunk (meta1 / cef1)
-    k_ema_update(L, T->id_emb, T->id_coef, zz->p, xn->p, bt.ids, 2, B, es * w, es * K, c.max_ids, c.momentum);
+    k_ema_update(L, T->id_emb, T->id_coef, zz->pf(), xn->pf(), bt.ids, 2, B, es * w, es * K, c.max_ids, c.momentum);
     ph_id.reset();
 
     // (3) conditioning: token embedding -> manager hook (row surgery) -> CLIP   (modules.py:176-298, 345-404). It needs the
     // identity embedding but not the latent, so it stays on the side stream: ~200 M=77 launches hidden under the VAE encode.
     std::unique_ptr<Phase> ph_clip(new Phase(L, "phase:clip_fwd"));
-    Ten* emb0 = G.make(B, T77, 1, w);
-    k_gather_rows(L, emb0->p, T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
-    Ten* emb1 = G.make(B, T77, 1, w, true);
+    Ten* emb0 = G.make(B, T77, 1, w, false, DT_F32);
+    k_gather_rows(L, emb0->pf(), T->clip.tok_emb, bt.tokens, (long)B * T77, w, c.clip.vocab);
+    Ten* emb1 = G.make(B, T77, 1, w, true, DT_F32);
     int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
-    k_row_surgery_fwd(L, emb1->p, emb0->p, zz->p, bt.tokens, map, B, T77, w, es, c.placeholder_token);
-    Ten* cond = clip_encode(G, T->clip, emb1);
+    k_row_surgery_fwd(L, emb1->pf(), emb0->pf(), zz->pf(), bt.tokens, map, B, T77, w, es, c.placeholder_token);
+    Ten* cond = G.cast(clip_encode(G, T->clip, emb1), T->unet.dt);
     ph_clip.reset();
 
     if (fork) { CB_HIP(hipEventRecord(ctx->ev_join, ctx->aux)); G.L.stream = main_stream; }
@@ -612,7 +624,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ten* z0;
     {
         Phase ph(L, "phase:vae_encode");
-        z0 = prefetched ? G.wrap(ps->z0, B, S_ >> (c.vae.n_mult - 1), S_ >> (c.vae.n_mult - 1), zc) : first_stage_latent(G, T, bt);
+        z0 = prefetched ? G.wrap(ps->z0, B, S_ >> (c.vae.n_mult - 1), S_ >> (c.vae.n_mult - 1), zc, false, T->vae.dt) : first_stage_latent(G, T, bt);
         G.tap("z0", z0);
     }
 
@@ -620,12 +632,12 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
     std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));
-    Ten* xt = G.make(B, z0->h, z0->w, zc);
-    k_qsample(L, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
+    Ten* xt = G.make(B, z0->h, z0->w, zc, false, z0->dt);
+    k_qsample(L, z0->dt, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
     Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond);
     float beta;
-    float* deps = G.grad(eps_hat, &beta);
-    k_mse_loss(L, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);
+    void* deps = G.grad(eps_hat, &beta);
+    k_mse_loss(L, eps_hat->dt, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);
     ph_uf.reset();
 
     // (7) backward: UNet dgrad -> context -> CLIP dgrad -> rows p, p+1 -> basis^T -> norm -> LeakyReLU -> dW, db
@@ -638,14 +650,14 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());
     float* dzz = ctx->arena.allocf((size_t)NF * es * w);
     k_fill(L, dzz, (long)NF * es * w, 0.f);
-    k_row_surgery_bwd(L, dzz, emb1->g, map, B, T77, w, es);          // fills the first B samples
+    k_row_surgery_bwd(L, dzz, static_cast<float*>(emb1->g), map, B, T77, w, es);          // fills the first B samples
     float* dxn = ctx->arena.allocf((size_t)NF * es * K);
     k_basis_bwd(L, dxn, dzz, T->basis, NF, es, K, w);
     float* dact = ctx->arena.allocf((size_t)NF * O);
-    k_l2norm_bwd(L, dact, xn->p, cn, dxn, (long)NF * es, K);
+    k_l2norm_bwd(L, dact, xn->pf(), cn, dxn, (long)NF * es, K);
     float* dpre = ctx->arena.allocf((size_t)NF * O);
-    k_leakyrelu_bwd(L, dpre, pre->p, dact, (long)NF * O, 0.2f);
-    k_outer_grad(L, T->gW, T->gb, dpre, v->p, NF, O, I);
+    k_leakyrelu_bwd(L, dpre, pre->pf(), dact, (long)NF * O, 0.2f);
+    k_outer_grad(L, T->gW, T->gb, dpre, v->pf(), NF, O, I);
 
     // (8) AdamW on the 525 312 trainable floats (ddpm.py:1442-1454)
     k_step_inc(L, T->step);
@@ -655,7 +667,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
 
 void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only) {
     Ctx* ctx = T->ctx;
-    CB_CHECK(bt.B >= 1 && bt.B <= 4, CB_ERR_ARG, "trainer: batch %d unsupported (1..4)", bt.B);
+    CB_CHECK(bt.B >= 1 && bt.B <= kMaxBatch, CB_ERR_ARG, "trainer: batch %d unsupported (1..%d)", bt.B, kMaxBatch);
     if (ctx->dry || dry_only || T->arena_B != bt.B) {
         bool was_dry = ctx->dry;
         Stats saved = ctx->stats;

@@ -42,30 +42,90 @@ imagenet_templates_small = _templates()
 
 
 class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
-    def __init__(self, pickle_path=None, split="train", num_ids=1, specific_ids=None, images_per_id=1, repeats=1000, reg_ids=1000,
-                 reg_repeats=0, diff_cnt=0, size=512, flip_p=0.5, placeholder="sks", seed=23, **ignored):
-        self.size, self.flip_p, self.split, self.repeats = size, flip_p if split == "train" else 0.0, split, repeats
-        self.ids = list(specific_ids) if specific_ids else list(range(1, num_ids + 1))
-        self.placeholder = placeholder
-        self.rng = random.Random(seed)
-        self.faces = self._load(pickle_path)
+    """Same constructor keywords and identity bookkeeping as the reference (face_id.py:471-597): the pickle is a list of image
+    paths; paths are grouped by basename stem (one group = one identity, in order of first appearance); `specific_ids` are
+    0-based WALK positions over those groups; the selected identities get DENSE slots 0..num_ids-1 (`use_id`), and it is the
+    dense slot that goes into `image_ori.ids` / `id_idx` — hence into `id_coefficients[slot]` of the saved checkpoint, where
+    02_start_test.sh reads `--eval_id1 0`. `images_per_id` is 1 as in the reference (:485).
+    Build-only keywords: `only_slots` restricts the samples served to a subset of the dense slots (identity sharding across
+    ranks keeps the reference's slot numbering); `synthetic=True` replaces the pickle by seeded smooth random faces (offline
+    runs, benchmarks) — without it a missing / unreadable pickle is an error, never a silent stand-in."""
 
-    def _load(self, path):
-        faces = {}
-        try:
-            with open(path, "rb") as f:
-                items = pickle.load(f)
-            from PIL import Image
-            import numpy as np
-            for i, ident in enumerate(self.ids):
-                img = Image.open(items[(ident - 1) % len(items)]).convert("RGB").resize((self.size, self.size), Image.BICUBIC)
-                faces[ident] = torch.from_numpy(np.asarray(img)).float() / 127.5 - 1.0
-        except Exception:
-            for ident in self.ids:       # offline: a seeded smooth synthetic "face"
-                g = torch.Generator().manual_seed(1000 + ident)
-                low = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
-                faces[ident] = F.interpolate(low, size=self.size, mode="bilinear", align_corners=True)[0].permute(1, 2, 0).contiguous()
-        return faces
+    def __init__(self, pickle_path=None, num_ids=10, specific_ids=None, image_size=512, repeats=100, flip_p=0.5, split="train",
+                 diff_cnt=32, size=None, placeholder="sks", seed=23, synthetic=False, only_slots=None, **ignored):
+        if diff_cnt != 0:
+            raise NotImplementedError("diff_cnt > 0 feeds the contrastive losses, which are dead under loss_type 'none' "
+                                      "(aigc_id.yaml:31,104); the shipped configs set diff_cnt: 0")
+        if isinstance(specific_ids, str):                       # 'lo-hi' (face_id.py:493-499)
+            import re
+            if re.match(r"\d+-\d+$", specific_ids) is None:
+                raise ValueError("Specific_ids not supported.")
+            lo, hi = [int(x) for x in specific_ids.split("-")]
+            specific_ids = list(range(lo, hi))
+        self.size = int(size if size is not None else image_size)
+        self.flip_p, self.split, self.repeats = (flip_p if split == "train" else 0.0), split, repeats
+        self.num_ids, self.specific_ids, self.images_per_id = int(num_ids), (list(specific_ids) if specific_ids is not None else None), 1
+        self.placeholder, self.seed, self.synthetic = placeholder, seed, bool(synthetic)
+        self.rng = random.Random(seed)
+        self._rng_owner = None
+        self.img_dict = {}                                      # dense slot -> {'id': stem, 'images': [path]}
+        if self.synthetic:
+            for slot in range(self.num_ids):
+                walk = self.specific_ids[slot] if self.specific_ids is not None and slot < len(self.specific_ids) else slot
+                self.img_dict[slot] = {"id": f"synthetic{walk:05d}", "images": [None], "walk": walk}
+        else:
+            self._load_from_pickle(pickle_path)
+        self.ids = sorted(self.img_dict) if only_slots is None else [int(i) for i in only_slots]
+        for i in self.ids:
+            if i not in self.img_dict:
+                raise ValueError(f"only_slots: dense identity slot {i} does not exist (num_ids={self.num_ids})")
+        self.faces = {slot: self._load_face(slot) for slot in self.ids}
+
+    def _load_from_pickle(self, path):
+        """face_id.py:556-583 `_load_from_pickle` ('1. load train'; reg_ids is 0)"""
+        if not path:
+            raise ValueError("FaceIdDataset: pickle_path is required (pass synthetic=True for seeded stand-in faces)")
+        import os
+        with open(path, "rb") as handle:
+            pickle_list = pickle.load(handle)
+        groups = {}
+        for img in pickle_list:
+            groups.setdefault(os.path.basename(img).split(".")[0], []).append(img)
+        walk_id = use_id = 0
+        for stem, images in groups.items():
+            if len(self.img_dict) >= self.num_ids:
+                break
+            if len(images) >= self.images_per_id:
+                if self.specific_ids is not None and walk_id not in self.specific_ids:
+                    walk_id += 1
+                    continue
+                self.img_dict[use_id] = {"id": stem, "images": images[:self.images_per_id], "walk": walk_id}
+                walk_id += 1
+                use_id += 1
+        if use_id < self.num_ids:
+            raise ValueError("Reach last. Not enough images for num_ids=%d, only %d." % (self.num_ids, use_id))
+
+    def _load_face(self, slot):
+        entry = self.img_dict[slot]
+        if self.synthetic:                                      # a seeded smooth synthetic "face"
+            g = torch.Generator().manual_seed(1000 + entry["walk"])
+            low = torch.rand(1, 3, 16, 16, generator=g) * 2 - 1
+            return F.interpolate(low, size=self.size, mode="bilinear", align_corners=True)[0].permute(1, 2, 0).contiguous()
+        from PIL import Image
+        import numpy as np
+        img = Image.open(entry["images"][0]).convert("RGB").resize((self.size, self.size), Image.BILINEAR)   # transforms.Resize
+        return torch.from_numpy(np.asarray(img).copy()).float() / 127.5 - 1.0
+
+    def _worker_rng(self):
+        """the reference draws from the global `random` / `np.random`, which DataLoader reseeds per worker and per epoch; a
+        generator copied into every worker would replay one stream 8 times, so each worker (re)seeds its own from the
+        loader-provided seed"""
+        info = torch.utils.data.get_worker_info()
+        key = None if info is None else info.seed
+        if key != self._rng_owner and info is not None:
+            self.rng = random.Random((self.seed << 32) ^ info.seed)
+            self._rng_owner = key
+        return self.rng
 
     def __len__(self):
         return len(self.ids) * (self.repeats if self.split == "train" else 1)
@@ -115,7 +175,8 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         return [1.0 if r.random() < self.flip_p else 0.0, r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(-0.01, 0.01)]
 
     def __getitem__(self, i):
-        ident = self.ids[i % len(self.ids)]
+        self._worker_rng()
+        ident = self.ids[i % len(self.ids)]                   # dense slot = id_idx of face_id.py:650-653
         face = self.faces[ident]
         img, img3 = self._aug(face), self._aug(face)
         train_img = self._add_bg(img) if self.split == "train" else img
@@ -125,7 +186,10 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
 
 
 class FaceIdDatasetOneShot(FaceIdDatasetStyleGAN3):
-    pass
+    """face_id.py:751-757: same dataset, `pickle_path` required"""
+
+    def __init__(self, pickle_path=None, **kwargs):
+        super().__init__(pickle_path, **kwargs)
 
 
 class DeviceAugmenter:

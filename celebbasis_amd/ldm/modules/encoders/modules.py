@@ -26,7 +26,9 @@ class FrozenCLIPEmbedder(FrozenModule):
         self.celeb_txt, self.use_svd, self.rm_repeats, self.use_flatten = celeb_txt, use_svd, rm_repeats, use_flatten
         if use_sample_reduce:
             raise NotImplementedError("use_sample_reduce (off in aigc_id.yaml:111) is outside the CelebBasis path")
-        self.allow_offline_tokens = True
+        # opt-in only (main.py --synthetic, tests): without the BPE vocabulary on disk strings are an ERROR, because hashed
+        # stand-in ids would condition real SD weights on garbage and still "succeed"
+        self.allow_offline_tokens = False
         self.celeb_embeddings = None          # (es, 1+n_components, width); set by load_celeb_basis / a checkpoint
         self._tokenizer = None
         super().__init__({self.PREFIX + k: v for k, v in self.param_shapes(self.cfg).items()})
@@ -65,11 +67,11 @@ class FrozenCLIPEmbedder(FrozenModule):
         from .... import basis as _basis
         names = _basis.read_names(self.celeb_txt, self.rm_repeats)
         if tokenize is None:
-            self.allow_offline_tokens = False            # stand-in ids would silently produce a meaningless basis
+            prev, self.allow_offline_tokens = self.allow_offline_tokens, False   # stand-in ids would give a meaningless basis
             try:
                 rows = [self.tokenize(n)[0].tolist() for n in names]
             finally:
-                self.allow_offline_tokens = True
+                self.allow_offline_tokens = prev
         else:
             rows = [[49406] + list(tokenize(n)) + [49407] for n in names]
         table = self.state_dict()[self.PREFIX + "embeddings.token_embedding.weight"]
@@ -100,7 +102,8 @@ class FrozenCLIPEmbedder(FrozenModule):
             except Exception as e:  # no vocab on disk and no network
                 if not self.allow_offline_tokens:
                     raise RuntimeError("CLIP BPE vocab files are not available offline: pass pre-tokenised int64 ids [B,77] "
-                                       "(e.g. batch['tokens']) instead of strings") from e
+                                       "(e.g. batch['tokens']) instead of strings, or opt in to hashed stand-in ids for synthetic "
+                                       "runs (main.py --synthetic / cond_stage_model.allow_offline_tokens = True)") from e
                 return self._offline_tokens([text] if isinstance(text, str) else list(text))
         enc = self._tokenizer(text, truncation=True, max_length=self.max_length, return_length=True,
                               return_overflowing_tokens=False, padding="max_length", return_tensors="pt")

@@ -5,19 +5,32 @@ import torch
 from ... import lib as _lib
 
 _CTX = {}
+_PRECISION = "f32"
+
+
+def set_precision(precision):
+    """element type of the frozen UNet / VAE / CLIP built from now on: 'f32' (the reference's arithmetic, BASELINE config 2) or
+    'bf16' (config 3). The coefficient head, its gradient and AdamW are fp32 either way; public tensors stay fp32."""
+    global _PRECISION
+    _lib.dtype_code(precision)      # validates
+    _PRECISION = precision
+
+
+def get_precision():
+    return _PRECISION
 
 
 def context_for(device):
-    """one cb_ctx per (device, stream) the caller is on"""
+    """one cb_ctx per (device, stream, precision) the caller is on"""
     dev = torch.device(device)
     if dev.type != "cuda":
         raise RuntimeError("celebbasis_amd runs on an MI355X (gfx950) only: move inputs to the GPU "
                            "(there is no CPU / PyTorch-eager fallback for the hot path)")
     idx = dev.index if dev.index is not None else torch.cuda.current_device()
-    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream, _PRECISION)
     if key not in _CTX:
         with torch.cuda.device(idx):
-            _CTX[key] = _lib.Context(idx)
+            _CTX[key] = _lib.Context(idx, dtype=_PRECISION)
     return _CTX[key]
 
 

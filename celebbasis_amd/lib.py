@@ -14,6 +14,28 @@ LIB_PATH = os.path.join(_HERE, "libcelebbasis_hip.so")
 _lib = None
 
 
+# cb_dtype (include/celebbasis_hip.h): element type of a context's activations and frozen UNet / VAE / CLIP weights
+DTYPE_F32, DTYPE_BF16 = 0, 1
+_DTYPES = {"f32": DTYPE_F32, "fp32": DTYPE_F32, "float32": DTYPE_F32, torch.float32: DTYPE_F32, DTYPE_F32: DTYPE_F32,
+           "bf16": DTYPE_BF16, "bfloat16": DTYPE_BF16, torch.bfloat16: DTYPE_BF16}
+
+
+def dtype_code(dtype):
+    """'f32' | 'bf16' | torch.float32 | torch.bfloat16 | cb_dtype int -> cb_dtype int"""
+    if dtype is None:
+        return DTYPE_F32
+    if dtype == DTYPE_BF16 and not isinstance(dtype, bool):
+        return DTYPE_BF16
+    try:
+        return _DTYPES[dtype]
+    except (KeyError, TypeError):
+        raise ValueError(f"unknown dtype {dtype!r}: use 'f32' or 'bf16'")
+
+
+def torch_dtype(code):
+    return torch.bfloat16 if code == DTYPE_BF16 else torch.float32
+
+
 class CBError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"libcelebbasis_hip error {code}: {msg}")
@@ -28,7 +50,7 @@ class GemmDesc(C.Structure):
                 ("a_layout", C.c_int), ("b_layout", C.c_int), ("batch", C.c_int),
                 ("strideA", C.c_int64), ("strideB", C.c_int64), ("strideC", C.c_int64),
                 ("bias", C.c_void_p), ("R", C.c_void_p), ("ldr", C.c_int64), ("strideR", C.c_int64),
-                ("alpha", C.c_float), ("beta", C.c_float)]
+                ("alpha", C.c_float), ("beta", C.c_float), ("dtype", C.c_int)]
 
 
 class AttentionDesc(C.Structure):
@@ -36,7 +58,7 @@ class AttentionDesc(C.Structure):
                 ("kvbuf", C.c_void_p), ("ldkv", C.c_int64), ("k_off", C.c_int), ("v_off", C.c_int),
                 ("B", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("C", C.c_int), ("heads", C.c_int),
                 ("scale", C.c_float), ("causal", C.c_int),
-                ("out", C.c_void_p), ("dout", C.c_void_p), ("dqbuf", C.c_void_p), ("dkvbuf", C.c_void_p)]
+                ("out", C.c_void_p), ("dout", C.c_void_p), ("dqbuf", C.c_void_p), ("dkvbuf", C.c_void_p), ("dtype", C.c_int)]
 
 
 class UNetCfg(C.Structure):
@@ -62,7 +84,8 @@ class TrainerCfg(C.Structure):
                 ("image_size", C.c_int), ("es", C.c_int), ("inner_dim", C.c_int), ("max_ids", C.c_int),
                 ("momentum", C.c_float), ("scale_factor", C.c_float), ("linear_start", C.c_float), ("linear_end", C.c_float),
                 ("timesteps", C.c_int), ("placeholder_token", C.c_int64),
-                ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("weight_decay", C.c_float)]
+                ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("weight_decay", C.c_float),
+                ("dtype", C.c_int)]
 
 
 class Batch(C.Structure):
@@ -72,7 +95,7 @@ class Batch(C.Structure):
 
 # every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
-    "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
+    "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_create_dtype", "cb_ctx_dtype", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
     "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
@@ -88,7 +111,7 @@ ABI_SYMBOLS = [
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _ARGTYPES = {
     "cb_last_error": [], "cb_version": [],
-    "cb_ctx_create": [_I, _P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
+    "cb_ctx_create": [_I, _P, _P], "cb_ctx_create_dtype": [_I, _P, _I, _P], "cb_ctx_dtype": [_P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
     "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
     "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
     "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
@@ -168,12 +191,12 @@ def keep_alive(*tensors):
 
 
 def ptr(t, dtype=torch.float32):
-    """raw pointer of a contiguous tensor (or None)"""
+    """raw pointer of a contiguous tensor (or None); `dtype` may be a tuple of accepted types"""
     if t is None:
         return None
     if not isinstance(t, torch.Tensor):
         raise TypeError("expected a torch.Tensor")
-    if t.dtype != dtype:
+    if (t.dtype not in dtype) if isinstance(dtype, tuple) else (t.dtype != dtype):
         raise TypeError(f"expected dtype {dtype}, got {t.dtype}")
     if not t.is_contiguous():
         raise ValueError("tensor must be contiguous")
@@ -181,10 +204,14 @@ def ptr(t, dtype=torch.float32):
 
 
 class Context:
-    """cb_ctx wrapper. device=None -> current torch device + current stream; device=-1 -> dry context (no GPU)."""
+    """cb_ctx wrapper. device=None -> current torch device + current stream; device=-1 -> dry context (no GPU).
+    dtype: 'f32' (BASELINE config 2, the reference's arithmetic) or 'bf16' (config 3: bf16 storage + bf16 MFMA for the frozen
+    UNet / VAE / CLIP; statistics, the coefficient head, its gradient and AdamW stay fp32)."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, dtype="f32"):
         lib = load()
+        self.dtype = dtype_code(dtype)
+        self.act_dtype = torch_dtype(self.dtype)      # torch dtype of op-level activation tensors on this context
         self.dry = device is not None and device < 0
         if self.dry:
             dev, stream = -1, None
@@ -196,7 +223,7 @@ class Context:
             stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         self.device = dev
         self.h = C.c_void_p()
-        check(lib.cb_ctx_create(C.c_int(dev), stream, C.byref(self.h)))
+        check(lib.cb_ctx_create_dtype(C.c_int(dev), stream, C.c_int(self.dtype), C.byref(self.h)))
 
     def sync(self):
         check(load().cb_ctx_sync(self.h))
@@ -505,6 +532,7 @@ class Trainer(_Handle):
     def __init__(self, ctx, wtab, cfg=None):
         self.ctx = ctx
         self.cfg = cfg if cfg is not None else trainer_cfg_default()
+        self.cfg.dtype = ctx.dtype          # the frozen networks follow the context's element type
         self.h = C.c_void_p()
         check(load().cb_trainer_create(ctx.h, wtab.h, C.byref(self.cfg), C.byref(self.h)))
 

@@ -77,7 +77,12 @@ def get_parser():
     p.add_argument("--data_root", type=str, default=None)
     p.add_argument("--gpus", type=str, default="0,")
     p.add_argument("--max_steps", type=int, default=None)
-    p.add_argument("--synthetic", action="store_true", help="seeded random weights at the true shapes (no checkpoints needed)")
+    p.add_argument("--synthetic", action="store_true",
+                   help="seeded random weights at the true shapes, seeded stand-in faces and hashed pseudo token ids (no checkpoints, "
+                        "dataset or BPE vocabulary needed); without it missing inputs are errors")
+    p.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                   help="element type of the frozen UNet / VAE / CLIP: f32 = the reference's arithmetic (BASELINE config 2), "
+                        "bf16 = bf16 storage + bf16 MFMA with fp32 statistics / coefficient gradient / AdamW (config 3)")
     return p
 
 
@@ -95,6 +100,8 @@ def main(argv=None):
     from . import install_ldm_alias, sharding
     install_ldm_alias()
     from .ldm.util import instantiate_from_config
+    from .ldm.modules import frozen
+    frozen.set_precision(opt.precision)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     random.seed(opt.seed); torch.manual_seed(opt.seed)                      # seed_everything(opt.seed) main_id_embed.py:586
@@ -109,6 +116,7 @@ def main(argv=None):
     model = instantiate_from_config(config["model"])
     if opt.synthetic:
         from . import synthetic
+        model.cond_stage_model.allow_offline_tokens = True       # hashed pseudo ids when the BPE vocabulary is not on disk
         model.load_state_dict(synthetic.synthetic_state(synthetic.trainer_shapes(), seed=0))
     else:
         sd = load_sd_checkpoint(opt.actual_resume)
@@ -124,10 +132,22 @@ def main(argv=None):
         for split in ("train", "validation"):
             if split in data_cfg:
                 data_cfg[split]["params"]["pickle_path"] = os.path.join(opt.data_root, "ffhq.pickle")
-    # identity sharding: each rank personalises its own subset (SURVEY §8 e); the frozen weights are replicated
-    all_ids = list(data_cfg["train"]["params"].get("specific_ids") or range(1, data_cfg["train"]["params"].get("num_ids", 1) + 1))
+    if opt.synthetic:
+        for split in ("train", "validation"):
+            if split in data_cfg:
+                data_cfg[split]["params"]["synthetic"] = True
+    # identity sharding: each rank personalises its own subset of the DENSE identity slots 0..num_ids-1 the reference's dataset
+    # assigns (face_id.py:556-583), so every rank writes the same id_coefficients[slot] a single-process run would (SURVEY §8 e);
+    # the frozen weights are replicated. NOTE (documented, not emulated): the reference with num_ids > 1 trains ONE shared MLP on
+    # all identities under DDP; here every rank trains its own MLP on its own identities — N independent num_ids=1-style runs.
+    n_slots = int(data_cfg["train"]["params"].get("num_ids", 1))
+    all_ids = list(range(n_slots))
     mine = [all_ids[i] for i in sharding.identities_for_rank(len(all_ids), rank, world)]
-    data_cfg["train"]["params"]["specific_ids"] = mine or all_ids[:1]
+    if world > 1:
+        if model.embedding_manager.test_mode == "image":
+            raise SystemExit("test_mode 'image' saves the MLP itself; with identity sharding every rank holds a different MLP — "
+                             "run it on one GPU (or use test_mode 'coefficient' / 'embedding')")
+        data_cfg["train"]["params"]["only_slots"] = mine or all_ids[:1]
     data = DataModuleFromConfig(**data_cfg)
     bs, base_lr = data_cfg["batch_size"], config["model"]["base_learning_rate"]
     model.learning_rate = 1 * 1 * bs * base_lr       # accumulate_grad_batches * ngpu(per identity) * bs * base_lr
@@ -164,14 +184,18 @@ def main(argv=None):
 
 
 def save_merged(model, ckptdir, all_ids, mine, rank, world, sharding):
-    """gather every rank's identity coefficients (4 KiB each) and let rank 0 write the reference format"""
+    """gather every rank's identity blocks — coefficients (4 KiB each) and EMA embeddings (6 KiB each), so that both
+    `test_mode: coefficient` and `test_mode: embedding` checkpoints are complete — and let rank 0 write the reference format"""
     model.sync_manager_from_trainer()
     em = model.embedding_manager
     if world > 1:
-        blocks = torch.stack([em.id_coefficients[i].reshape(-1) for i in mine]) if mine else torch.zeros(0, em.num_es * em.inner_dim)
+        nc, ne = em.num_es * em.meta_heads * em.inner_dim, em.num_es * em.meta_heads * em.token_dim
+        blocks = torch.stack([torch.cat([em.id_coefficients[i].reshape(-1), em.id_embeddings[i].reshape(-1)]) for i in mine]) \
+            if mine else torch.zeros(0, nc + ne)
         merged = sharding.gather_identity_blocks(mine, blocks, em.max_ids)
         for i in all_ids:
-            em.id_coefficients[i] = merged[i].reshape(em.num_es, em.meta_heads, em.inner_dim)
+            em.id_coefficients[i] = merged[i, :nc].reshape(em.num_es, em.meta_heads, em.inner_dim)
+            em.id_embeddings[i] = merged[i, nc:].reshape(em.num_es * em.meta_heads, em.token_dim)
     if rank == 0:
         os.makedirs(ckptdir, exist_ok=True)
         em.save(os.path.join(ckptdir, "embeddings.pt"))

@@ -13,6 +13,16 @@
  *  - all tensor arguments are raw DEVICE pointers to float32 unless stated (int64 for token / id / timestep
  *    tensors, as in the reference). The caller owns every input/output buffer; the library never frees caller
  *    memory and owns only its handles, its weight copies and its per-context step arena.
+ *  - element type. A context has one ACTIVATION dtype, fixed at creation (cb_ctx_create = f32, cb_ctx_create_dtype):
+ *      CB_DTYPE_F32  — BASELINE config 2: the reference's own arithmetic (fp32 storage, exact-fp32 MFMA).
+ *      CB_DTYPE_BF16 — BASELINE config 3: bf16 storage of the UNet / VAE / CLIP activations and frozen weights, bf16 MFMA
+ *                      with fp32 accumulation; GroupNorm / LayerNorm / softmax statistics, the FR-net, the coefficient head,
+ *                      its gradient (dW, db) and AdamW stay fp32.
+ *    Op-level entry points take their activation tensors (`void*`) in the context's dtype (cb_gemm / cb_attention carry
+ *    their own `dtype` in the descriptor, so fp32 head-path products can run on a bf16 context); norm parameters, biases,
+ *    statistics, losses and everything of the coefficient head are float32 in both modes. Graph-level entry points keep
+ *    float32 for the reference's PUBLIC tensors (images, latents, noise, conditioning, features) in both modes and convert
+ *    at the boundary, so the host classes above this ABI do not change with the dtype.
  *  - work is enqueued on the context's stream (borrowed from the caller, e.g. PyTorch's current HIP stream);
  *    calls are asynchronous with respect to the host except the _create, _destroy and _get_state calls.
  *  - activation layout inside the library is NHWC ("tokens x channels"); NCHW appears only where the
@@ -31,6 +41,8 @@ extern "C" {
 typedef enum { CB_STATUS_OK = 0, CB_STATUS_ARG = -1, CB_STATUS_HIP = -2, CB_STATUS_SHAPE = -3, CB_STATUS_MISSING = -4,
                CB_STATUS_OOM = -5, CB_STATUS_STATE = -6, CB_STATUS_INTERNAL = -7 } cb_status;
 
+typedef enum { CB_DTYPE_F32 = 0, CB_DTYPE_BF16 = 1 } cb_dtype;
+
 typedef struct cb_ctx cb_ctx;
 typedef struct cb_wtab cb_wtab;
 typedef struct cb_unet cb_unet;
@@ -44,7 +56,9 @@ const char* cb_last_error(void);
 int cb_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
-int cb_ctx_create(int device, void* hip_stream, cb_ctx** out);
+int cb_ctx_create(int device, void* hip_stream, cb_ctx** out);                           /* activation dtype f32 */
+int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out);         /* dtype: cb_dtype */
+int cb_ctx_dtype(cb_ctx* ctx, int* dtype);
 int cb_ctx_destroy(cb_ctx* ctx);
 int cb_ctx_sync(cb_ctx* ctx);
 /* accounting since the last reset: sum of 2*M*N*K over GEMM-class launches, kernel launches,
@@ -72,41 +86,44 @@ typedef enum { CB_LD_ROW = 0, CB_LD_COL = 1 } cb_operand_layout;
 /* C[M,N] = alpha * A.B + bias[n] + R + beta*C, batched; ROW = K contiguous, COL = M/N contiguous.
  * Replaces nn.Linear / einsum / bmm (ldm/modules/attention.py:170-193, openaimodel.py linear()). */
 typedef struct {
-    const float* A; const float* B; float* C;
+    const void* A; const void* B; void* C;      /* element type = dtype */
     int M, N, K;
     int64_t lda, ldb, ldc;
-    int a_layout, b_layout;
+    int a_layout, b_layout;                      /* bf16: both operands must be CB_LD_ROW (K contiguous), K % 8 == 0, 16-byte aligned */
     int batch;
     int64_t strideA, strideB, strideC;
-    const float* bias;
-    const float* R; int64_t ldr; int64_t strideR;
+    const float* bias;                           /* float32 in both modes */
+    const void* R; int64_t ldr; int64_t strideR;
     float alpha, beta;
+    int dtype;                                   /* cb_dtype of A, B, C, R (descriptor-level: independent of the context's) */
 } cb_gemm_desc;
 int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
 
 /* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped. */
-int cb_pack_conv_weight(cb_ctx* ctx, const float* w_oihw, float* out, int O, int I, int ks, int dgrad);
+/* the source is the float32 state-dict tensor; the pack is in the context's dtype. bf16 packs pad the contiguous channel axis to a
+ * multiple of 8: [O][ky][kx][ceil8(I)] resp. [I][ky'][kx'][ceil8(O)] (zero filled). */
+int cb_pack_conv_weight(cb_ctx* ctx, const float* w_oihw, void* out, int O, int I, int ks, int dgrad);
 /* nn.Conv2d forward on NHWC (openaimodel.py conv_nd / model.py Conv2d), optional fused per-image row bias
  * (ResBlock emb add, openaimodel.py:262-273) and residual (skip_connection(x) + h, openaimodel.py:275). */
-int cb_conv2d_fwd(cb_ctx* ctx, const float* x, const float* w_packed, const float* bias, const float* rowbias,
-                  const float* residual, float* y, int N, int H, int W, int Cin, int Cout, int ks, int mode);
+int cb_conv2d_fwd(cb_ctx* ctx, const void* x, const void* w_packed, const float* bias, const void* rowbias,
+                  const void* residual, void* y, int N, int H, int W, int Cin, int Cout, int ks, int mode);
 /* input gradient of the same conv (autograd of F.conv2d wrt input; weights are frozen, ddpm.py:491-500) */
-int cb_conv2d_dgrad(cb_ctx* ctx, const float* dy, const float* w_packed_dgrad, float* dx, int N, int H, int W, int Cin,
+int cb_conv2d_dgrad(cb_ctx* ctx, const void* dy, const void* w_packed_dgrad, void* dx, int N, int H, int W, int Cin,
                     int Cout, int ks, int mode, float beta);
 
 /* GroupNorm(32)(+SiLU): util.py:214-216 GroupNorm32 / attention.py:76-77 Normalize + nn.SiLU. stats: [N][32][2]. */
-int cb_groupnorm_silu_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats,
+int cb_groupnorm_silu_fwd(cb_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                           int N, int HW, int C, float eps, int silu);
-int cb_groupnorm_silu_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* beta,
-                          const float* stats, float* dx, int N, int HW, int C, int silu, float acc_beta);
+int cb_groupnorm_silu_bwd(cb_ctx* ctx, const void* x, const void* dy, const float* gamma, const float* beta,
+                          const float* stats, void* dx, int N, int HW, int C, int silu, float acc_beta);
 /* nn.LayerNorm over the last dim (attention.py:203-205, HF CLIP layer norms). stats: [rows][2]. */
-int cb_layernorm_fwd(cb_ctx* ctx, const float* x, const float* gamma, const float* beta, float* y, float* stats,
+int cb_layernorm_fwd(cb_ctx* ctx, const void* x, const float* gamma, const float* beta, void* y, float* stats,
                      int64_t rows, int C, float eps);
-int cb_layernorm_bwd(cb_ctx* ctx, const float* x, const float* dy, const float* gamma, const float* stats, float* dx,
+int cb_layernorm_bwd(cb_ctx* ctx, const void* x, const void* dy, const float* gamma, const float* stats, void* dx,
                      int64_t rows, int C, float acc_beta);
 /* GEGLU (attention.py:37-44) */
-int cb_geglu_fwd(cb_ctx* ctx, const float* x, float* y, int64_t M, int D);
-int cb_geglu_bwd(cb_ctx* ctx, const float* x, const float* dy, float* dx, int64_t M, int D);
+int cb_geglu_fwd(cb_ctx* ctx, const void* x, void* y, int64_t M, int D);
+int cb_geglu_bwd(cb_ctx* ctx, const void* x, const void* dy, void* dx, int64_t M, int D);
 
 /* Multi-head attention softmax(scale * Q K^T [+causal]) V  (attention.py:170-193 CrossAttention, model.py:176-202
  * AttnBlock, HF CLIPAttention). q lives in columns [q_off, q_off+C) of `qbuf` [B,Nq,ldq]; k and v in columns
@@ -114,20 +131,21 @@ int cb_geglu_bwd(cb_ctx* ctx, const float* x, const float* dy, float* dx, int64_
  * If dout != NULL the call also runs the backward and writes dq into dqbuf (same layout as qbuf, only the q columns)
  * and dk/dv into dkvbuf (same layout as kvbuf; may equal dqbuf). */
 typedef struct {
-    const float* qbuf; int64_t ldq; int q_off;
-    const float* kvbuf; int64_t ldkv; int k_off, v_off;
+    const void* qbuf; int64_t ldq; int q_off;
+    const void* kvbuf; int64_t ldkv; int k_off, v_off;
     int B, Nq, Nk, C, heads;
     float scale; int causal;
-    float* out;
-    const float* dout; float* dqbuf; float* dkvbuf;
+    void* out;
+    const void* dout; void* dqbuf; void* dkvbuf;
+    int dtype;                                   /* cb_dtype of every tensor above (descriptor-level) */
 } cb_attention_desc;
 int cb_attention(cb_ctx* ctx, const cb_attention_desc* d);
 
 /* small ops of the step, exported for parity tests */
-int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, float* out, int B, int dim);                  /* util.py:151-171 */
-int cb_q_sample(cb_ctx* ctx, const float* x0_nhwc, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
-                const float* sqrt_1mac, float* xt_nhwc, int B, int C, int HW);                        /* ddpm.py:289-292 */
-int cb_mse_loss(cb_ctx* ctx, const float* pred_nhwc, const float* target_nchw, float* loss, float* dpred, int B, int C,
+int cb_timestep_embedding(cb_ctx* ctx, const int64_t* t, void* out, int B, int dim);                   /* util.py:151-171 */
+int cb_q_sample(cb_ctx* ctx, const void* x0_nhwc, const float* eps_nchw, const int64_t* t, const float* sqrt_ac,
+                const float* sqrt_1mac, void* xt_nhwc, int B, int C, int HW);                         /* ddpm.py:289-292 */
+int cb_mse_loss(cb_ctx* ctx, const void* pred_nhwc, const float* target_nchw, float* loss, void* dpred, int B, int C,
                 int HW);                                                                              /* ddpm.py:294-307 */
 int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* out, int B, int S, int nface, int out_size); /* meta_net.py:253-260 */
 /* MetaIdNet head after the FR backbone (meta_net.py:262-289): normalize -> EqualLinear+LeakyReLU(0.2) -> per-(e) L2 norm ->
@@ -149,8 +167,8 @@ int cb_row_surgery_multi(cb_ctx* ctx, const float* embedded, const float* z, con
                          int B, int T, int C, int reps, const int64_t* placeholders, int nph);
 int cb_adamw_step(cb_ctx* ctx, float* p, float* m, float* v, const float* g, int64_t n, int* step_dev, float lr, float b1,
                   float b2, float eps, float wd);                                                     /* ddpm.py:1454 */
-int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W);
-int cb_nhwc_to_nchw(cb_ctx* ctx, const float* src, float* dst, int N, int C, int H, int W);
+int cb_nchw_to_nhwc(cb_ctx* ctx, const float* src, void* dst, int N, int C, int H, int W);   /* public fp32 NCHW -> activation NHWC */
+int cb_nhwc_to_nchw(cb_ctx* ctx, const void* src, float* dst, int N, int C, int H, int W);
 
 /* ---- graph level --------------------------------------------------------------------------------- */
 typedef struct {
@@ -221,6 +239,7 @@ typedef struct {
     float momentum, scale_factor, linear_start, linear_end; int timesteps;
     int64_t placeholder_token;
     float adam_b1, adam_b2, adam_eps, weight_decay;
+    int dtype;            /* cb_dtype of the frozen UNet / VAE / CLIP (must equal the context's); head + AdamW are always f32 */
 } cb_trainer_cfg;
 int cb_trainer_cfg_default(cb_trainer_cfg* cfg);   /* SD v1-4 + aigc_id.yaml values */
 /* wt must hold: model.diffusion_model.*, first_stage_model.*, cond_stage_model.transformer.text_model.*,

@@ -1,0 +1,147 @@
+"""GPU parity tests of the bf16 path (BASELINE config 3: bf16 UNet / VAE / CLIP, fp32 coefficient head + gradient + AdamW),
+graph level, through the C ABI on a bf16 context, against the fp32 CPU oracle on the same seeded weights and replay stream.
+
+Tolerances. bf16 has 8 significant bits (ulp 2^-8 = 3.9e-3): every stored activation is rounded once, so an L-layer network
+accumulates ~sqrt(L) * 2^-9 relative noise. Stated per check as max|hip - ref| <= tol * max|ref|:
+  * network outputs (eps, conditioning, latents): 4e-2;
+  * loss: 2e-2 relative;
+  * the MLP gradient dW (what config 3 keeps in fp32 downstream of the bf16 networks): relative L2 error <= 6e-2 and cosine
+    similarity >= 0.995 — it passes through the whole UNet + CLIP backward in bf16;
+  * the north_star bar is unchanged: learned coefficients within 1e-3 L2 of the fp32 oracle."""
+import json
+import os
+
+import pytest
+import torch
+
+from test_gpu_models import MINI, close, dv, make_batch, trainer_cfg
+
+pytestmark = pytest.mark.gpu
+REPORT = {}
+DEV = "cuda:0"
+
+
+@pytest.fixture(scope="module")
+def cbf(built_lib):
+    from celebbasis_amd import lib
+    ctx = lib.Context(dtype="bf16")
+    yield lib, ctx
+    ctx.sync()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/bf16_models_report.json", "w") as f:
+        json.dump(REPORT, f, indent=1, sort_keys=True)
+
+
+def rel_l2(a, b):
+    a = a.detach().float().cpu().reshape(-1); b = b.detach().float().cpu().reshape(-1)
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
+def cosine(a, b):
+    a = a.detach().float().cpu().reshape(-1); b = b.detach().float().cpu().reshape(-1)
+    return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
+
+
+def run_steps_bf16(lib, ctx, m, B, steps, lr, seed, taps, per_step=True):
+    from oracle import cb_oracle as O
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = O.init_weights(shapes, seed=seed)
+    tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+    st = O.TrainState(W)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    tag = f"bf16.step[{m['image']}px,B{B}]"
+    for s in range(steps):
+        batch = make_batch(B, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"])
+        ctx.set_debug_taps(taps and s == 0)
+        dev = {k: dv(v) for k, v in batch.items()}
+        tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], lr)
+        loss_ref, aux = O.train_step(W, st, batch, lr, m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"],
+                                     placeholder=m["placeholder"], return_aux=True)
+        ctx.sync()
+        if taps and s == 0:
+            nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(-1)
+            close(tag + ".tap.z0", ctx.tap("z0"), nhwc(aux["z0"]), 4e-2)
+            # the FR-net and the coefficient head stay fp32 in config 3: fp32-class agreement
+            close(tag + ".tap.frnet.features", ctx.tap("frnet.features"), aux["feat"].reshape(-1), 2e-4)
+            close(tag + ".tap.coef", ctx.tap("coef"), aux["coef"].reshape(-1), 1e-4)
+            close(tag + ".tap.clip.cond", ctx.tap("clip.last_hidden_state"), aux["cond"].reshape(-1), 4e-2)
+            close(tag + ".tap.unet.out", ctx.tap("unet.out"), nhwc(aux["eps_hat"]), 4e-2)
+        if per_step:
+            close(tag + f".s{s}.loss", tr.get_state("loss"), loss_ref.reshape(1), 2e-2)
+            gW = tr.get_state("mlp.grad_weight")
+            e, c = rel_l2(gW, aux["gW"]), cosine(gW, aux["gW"])
+            REPORT[tag + f".s{s}.grad_weight"] = dict(rel_l2=e, cosine=c)
+            assert e <= 6e-2 and c >= 0.995, f"{tag}.s{s}: dW rel L2 {e:.3e} / cosine {c:.5f} vs the fp32 oracle"
+    coef_hip = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)
+    l2 = (coef_hip - st.id_coef).norm(dim=1).max().item()
+    REPORT[tag + f".id_coefficients.L2[{steps} steps]"] = l2
+    assert l2 <= 1e-3, f"{tag}: coefficient L2 distance {l2:.3e} exceeds the north_star bar 1e-3"
+    close(tag + ".id_embeddings", tr.get_state("id_embeddings"), st.id_emb.reshape(-1), 1e-3)
+    assert int(tr.get_state("step").item()) == steps
+    assert torch.isfinite(tr.get_state("mlp.weight")).all()
+    tr.close()
+
+
+def test_unet_mini_bf16_vs_oracle(cbf):
+    from oracle import cb_oracle as O
+    lib, ctx = cbf
+    cfg = MINI["unet"]
+    W = O.init_weights(O.unet_param_shapes(cfg), seed=3)
+    u = lib.UNet(ctx, lib.WeightTable(W), lib.unet_cfg(**cfg))
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(2, 4, 16, 16, generator=g); t = torch.tensor([417, 33]); c = torch.randn(2, 77, cfg["context_dim"], generator=g)
+    dout = torch.randn(2, 4, 16, 16, generator=g)
+    out = u.forward(dv(x), dv(t), dv(c), need_grad=True)        # public tensors stay fp32 on a bf16 context
+    dctx = u.backward_context(dv(dout))
+    ctx.sync()
+    cr = c.clone().requires_grad_(True)
+    ref = O.unet_forward(W, cfg, x, t, cr)
+    (dref,) = torch.autograd.grad((ref * dout).sum(), [cr])
+    close("bf16.unet_mini.out", out, ref, 4e-2)
+    close("bf16.unet_mini.dcontext", dctx, dref, 6e-2)
+    u.close()
+
+
+def test_train_step_mini_bf16_vs_oracle(cbf):
+    lib, ctx = cbf
+    run_steps_bf16(lib, ctx, MINI, B=2, steps=3, lr=1e-2, seed=1, taps=True)
+
+
+def test_train_40_steps_mini_bf16_coefficient_bar(cbf):
+    """config 3's parity bar over a horizon: 40 optimiser steps in bf16 keep the learned coefficients within 1e-3 L2 of the
+    fp32 oracle on the same replay stream"""
+    lib, ctx = cbf
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    run_steps_bf16(lib, ctx, MINI, B=2, steps=40, lr=5e-3, seed=7, taps=False, per_step=False)
+
+
+def test_train_step_sd14_bf16_bs4_vs_oracle(cbf):
+    """BASELINE config 3 shapes: SD v1-4, 512x512, bs=4, bf16 UNet / VAE / CLIP + fp32 coefficient gradient: one full step"""
+    from oracle import cb_oracle as O
+    lib, ctx = cbf
+    full = dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
+                placeholder=O.PLACEHOLDER_SKS)
+    torch.set_num_threads(min(64, os.cpu_count() or 1))
+    run_steps_bf16(lib, ctx, full, B=4, steps=1, lr=2e-2, seed=5, taps=True)
+
+
+def test_sampler_mini_bf16_vs_oracle(cbf):
+    """DDIM with guidance on a bf16 context (the reference samples under fp16 autocast, stable_txt2img.py:320-322): the sampler
+    state stays fp32, the UNet runs in bf16; 4 steps against the fp32 oracle"""
+    from oracle import cb_oracle as O
+    lib, ctx = cbf
+    cfg = MINI["unet"]
+    W = O.init_weights(O.unet_param_shapes(cfg), seed=11)
+    u = lib.UNet(ctx, lib.WeightTable(W), lib.unet_cfg(**cfg))
+    g = torch.Generator().manual_seed(12)
+    n = 2
+    xT = torch.randn(n, 4, 16, 16, generator=g)
+    cond = torch.randn(n, 77, cfg["context_dim"], generator=g); uncond = torch.randn(n, 77, cfg["context_dim"], generator=g)
+    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 4, 0.0)
+    x, _ = u.ddim_sample(dv(xT), dv(cond), dv(uncond), s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"],
+                         s["sqrt_one_minus_alphas"], scale=5.0)
+    ctx.sync()
+    ref = O.ddim_sample(W, cfg, xT, cond, uncond, s, scale=5.0)
+    ref = ref[0] if isinstance(ref, (tuple, list)) else ref
+    close("bf16.ddim_mini.x0", x, ref, 6e-2)
+    u.close()

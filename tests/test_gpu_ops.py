@@ -382,7 +382,7 @@ def test_feeder_augmentations_vs_oracle(cb):
     close("feeder.add_bg", pasted, refp, 2e-5)
     # batch-level feeder
     from celebbasis_amd.ldm.data.face_id import DeviceAugmenter, FaceIdDatasetOneShot
-    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=2, size=64, seed=3)
+    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=2, size=64, seed=3, diff_cnt=0, synthetic=True)
     b = DeviceAugmenter(ds, _dev()).batch([0, 1, 2])
     ctx.sync()
     assert tuple(b["image"].shape) == (3, 64, 64, 3) and tuple(b["image_ori"]["faces"].shape) == (3, 64, 64, 6)

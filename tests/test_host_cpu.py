@@ -70,6 +70,41 @@ def test_dry_training_step_accounting(built_lib):
     assert ctx.stats()["gemm_flops"] / 1e9 > 4 * 2800        # scales with the batch
 
 
+def test_dry_bf16_training_step_and_sampler(built_lib):
+    """BASELINE config 3 on a dry context (no GPU): the bf16 graph passes every shape / alignment check of the bf16 kernels
+    (k-contiguous operands, 8-element chunks, padded RGB / latent channels) at bs=4, accounts the same algorithmic FLOPs as fp32
+    (+ the padded first / last convolutions) and needs about half the activation arena; dtype mismatches are rejected"""
+    from celebbasis_amd import lib, synthetic
+    from oracle import cb_oracle as O
+    shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
+    res = {}
+    for dt in ("f32", "bf16"):
+        ctx = lib.Context(device=-1, dtype=dt)
+        tr = lib.Trainer(ctx, lib.WeightTable(shapes))
+        assert tr.cfg.dtype == ctx.dtype
+        ctx.reset_stats()
+        tr.step(4, None, None, None, None, None, None, 2e-2)
+        res[dt] = ctx.stats()
+        u = tr.unet()
+        s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 2, 0.0)
+        u.ddim_sample(torch.zeros(2, 4, 64, 64), torch.zeros(2, 77, 768), torch.zeros(2, 77, 768), s["timesteps"], s["alphas"],
+                      s["alphas_prev"], s["sigmas"], s["sqrt_one_minus_alphas"], scale=10.0)
+        lib.VAEDecoder(ctx, lib.WeightTable(shapes), lib.vae_cfg(), prefix="first_stage_model.").decode(torch.zeros(1, 4, 64, 64), 0.18215)
+    f, b = res["f32"], res["bf16"]
+    assert abs(b["gemm_flops"] / f["gemm_flops"] - 1.0) < 5e-3
+    assert b["arena_peak_bytes"] < 0.6 * f["arena_peak_bytes"]
+    ctx = lib.Context(device=-1, dtype="bf16")
+    cfg = lib.trainer_cfg_default()
+    tr = lib.Trainer.__new__(lib.Trainer)
+    with pytest.raises(lib.CBError) as e:       # a cfg that says f32 on a bf16 context
+        import ctypes as C
+        h = C.c_void_p()
+        lib.check(lib.load().cb_trainer_create(ctx.h, lib.WeightTable(shapes).h, C.byref(cfg), C.byref(h)))
+    assert "dtype" in str(e.value)
+    with pytest.raises(ValueError):
+        lib.Context(device=-1, dtype="fp8")
+
+
 def test_dry_sampler_accounting(built_lib):
     """sampling path at SD v1-4 shapes on a dry context: DDIM-50 with guidance = 50 batch-2 UNet passes (SURVEY §8 A10:
     50 x 2 x 803 GF), and the native VAE decoder graph does exactly the FLOPs torch's FlopCounter sees in the oracle"""
@@ -114,6 +149,50 @@ def test_product_tables_match_oracle_and_reference_digests(golden_dir):
     assert hashlib.sha256("\n".join(imagenet_templates_small).encode()).hexdigest() == d["imagenet_templates_small"]["sha256"]
 
 
+def _write_face_pickle(tmp_path, n, images_per_id=1):
+    """n identities as PNG files named <stem>.png (+ a second image <stem>.1.png when images_per_id > 1) and the path-list pickle
+    the reference's start_align.py / gen_pickle.py would have written"""
+    import pickle
+    import numpy as np
+    from PIL import Image
+    paths = []
+    rs = np.random.RandomState(0)
+    for i in range(n):
+        for j in range(images_per_id):
+            p = tmp_path / (f"{i:05d}.png" if j == 0 else f"{i:05d}.{j}.png")
+            Image.fromarray(rs.randint(0, 255, (40, 40, 3), dtype=np.uint8)).save(p)
+            paths.append(str(p))
+    pk = tmp_path / "ffhq.pickle"
+    with open(pk, "wb") as f:
+        pickle.dump(paths, f)
+    return str(pk)
+
+
+def test_dataset_identity_slots_follow_the_reference(tmp_path):
+    """face_id.py:556-583: images grouped by basename stem, specific_ids = walk positions, dense use_id slots in the batch;
+    a missing pickle is an error (no silent synthetic stand-in) unless synthetic=True is passed"""
+    from celebbasis_amd.ldm.data.face_id import FaceIdDatasetOneShot
+    pk = _write_face_pickle(tmp_path, 5, images_per_id=2)
+    ds = FaceIdDatasetOneShot(pk, num_ids=2, specific_ids=[1, 3], diff_cnt=0, image_size=32, repeats=3)
+    assert [ds.img_dict[k]["id"] for k in (0, 1)] == ["00001", "00003"] and len(ds) == 6
+    assert all(len(ds.img_dict[k]["images"]) == 1 for k in (0, 1))          # images_per_id = 1: the first image of each group
+    seen = {int(ds[i]["image_ori"]["ids"][0]) for i in range(len(ds))}
+    assert seen == {0, 1} and ds[0]["id_idx"] in (0, 1)
+    assert tuple(ds[0]["image"].shape) == (32, 32, 3) and tuple(ds[0]["image_ori"]["faces"].shape) == (32, 32, 6)
+    rng = FaceIdDatasetOneShot(pk, num_ids=3, specific_ids="1-4", diff_cnt=0, image_size=32)
+    assert [rng.img_dict[k]["id"] for k in (0, 1, 2)] == ["00001", "00002", "00003"]
+    shard = FaceIdDatasetOneShot(pk, num_ids=2, specific_ids=[1, 3], diff_cnt=0, image_size=32, only_slots=[1])
+    assert {int(shard[i]["image_ori"]["ids"][0]) for i in range(4)} == {1}
+    with pytest.raises(ValueError):
+        FaceIdDatasetOneShot(pk, num_ids=4, specific_ids=[1, 3], diff_cnt=0)     # "Reach last. Not enough images"
+    with pytest.raises((ValueError, FileNotFoundError)):
+        FaceIdDatasetOneShot(str(tmp_path / "missing.pickle"), num_ids=1, diff_cnt=0)
+    with pytest.raises(ValueError):
+        FaceIdDatasetOneShot(None, num_ids=1, diff_cnt=0)
+    syn = FaceIdDatasetOneShot(None, num_ids=2, specific_ids=[1, 2], diff_cnt=0, image_size=32, synthetic=True)
+    assert sorted(syn.faces) == [0, 1]
+
+
 def test_reference_yaml_is_drop_in(tmp_path):
     """the `model:` and `data:` sections of configs/stable-diffusion/aigc_id.yaml (kept as a data fixture) instantiate the
     host mirror through the reference's own target strings"""
@@ -125,7 +204,9 @@ def test_reference_yaml_is_drop_in(tmp_path):
     import yaml
     ref_yaml = tmp_path / "aigc_id.yaml"                     # the config as a YAML file again, as the CLI would receive it
     ref_yaml.write_text(yaml.safe_dump(json.load(open(REF_PARAMS))))
-    cfg = load_config([str(ref_yaml)], ["data.params.batch_size=1"])
+    pk = _write_face_pickle(tmp_path, 4)                     # 4 identities on disk; the YAML asks for walk positions [1, 2]
+    cfg = load_config([str(ref_yaml)], ["data.params.batch_size=1", f"data.params.train.params.pickle_path={pk}",
+                                         f"data.params.validation.params.pickle_path={pk}", "data.params.num_workers=0"])
     assert cfg["model"]["target"] == "ldm.models.diffusion.ddpm.LatentDiffusion"
     m = instantiate_from_config(cfg["model"])
     assert type(m).__name__ == "LatentDiffusion" and type(m.embedding_manager).__name__ == "EmbeddingManagerId"
@@ -137,6 +218,10 @@ def test_reference_yaml_is_drop_in(tmp_path):
     b = next(iter(data.train_dataloader()))
     assert tuple(b["image"].shape) == (1, 512, 512, 3) and tuple(b["image_ori"]["faces"].shape) == (1, 512, 512, 6)
     assert b["image_ori"]["ids"].dtype == torch.int64 and "sks" in b["caption"][0]
+    # identity bookkeeping of face_id.py:556-583: specific_ids [1, 2] are WALK positions, the batch carries DENSE slots 0 / 1
+    ds = data.datasets["train"]
+    assert [ds.img_dict[k]["id"] for k in sorted(ds.img_dict)] == ["00001", "00002"]
+    assert int(b["image_ori"]["ids"][0, 0]) in (0, 1) and int(b["image_ori"]["ids"][0, 0]) == int(b["image_ori"]["ids"][0, 1])
     # checkpoint format of embedding_manager.py:396-426: {"id_coefficients": [max_ids x (es, h, inner)]}
     em = m.embedding_manager
     p = tmp_path / "embeddings_gs-200.pt"
@@ -208,7 +293,7 @@ def test_feeder_draws_and_lookahead():
     one-batch lookahead used by --pipeline yields every batch exactly once, in order"""
     import random
     from celebbasis_amd.ldm.data.face_id import FaceIdDatasetOneShot
-    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=1, size=64, seed=1)
+    ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=1, size=64, seed=1, diff_cnt=0, synthetic=True)
     ds.rng = random.Random(0)
     for _ in range(200):
         flip, b, c, s, h = ds._jitter_params()
@@ -236,7 +321,7 @@ def test_argument_errors_on_a_dry_context(built_lib):
     shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
     wt = lib.WeightTable(shapes)
     tr = lib.Trainer(ctx, wt)
-    for bad in (0, 5):
+    for bad in (0, 9):
         with pytest.raises(lib.CBError) as e:
             tr.step(bad, None, None, None, None, None, None, 5e-3)
         assert "batch" in str(e.value)
