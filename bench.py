@@ -2,6 +2,7 @@
 """bench.py — CelebBasis personalization training step on MI355X (BASELINE.json metric, config 2).
 
     python bench.py --gpus 1 --steps 20 --warmup 3
+    python bench.py --gpus 8 ...            # re-executes itself under torch.distributed.run, one rank per GPU
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
 A "step" is one full personalization training step of ONE identity at SD v1-4 / 512x512 / bs=1 / fp32:
@@ -9,15 +10,25 @@ VAE encode -> FR-net + MLP + basis (+EMA) -> CLIP text (with the manager hook) -
 input-gradient backward through UNet and CLIP -> dW/db -> AdamW. Nothing is cached or skipped inside the timed region.
 Inputs (a replay stream of synthetic batches) are resident in HBM before the timed region starts.
 With N > 1 every rank personalises its own identity (SURVEY.md §8 e: independent units, no data-path collective); the only
-collective is the checkpoint-merge all_gather after the timed region. `value` = steps of all ranks / max-over-ranks time.
+collective is the checkpoint-merge all_gather after the timed region (RCCL), whose result is checked (`merged_identities == N`).
+`value` = steps of all ranks / max-over-ranks time; `identities_per_sec` = value / 800 (aigc_id.yaml:135 max_steps).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel, measured live with HIP
-events around every GEMM-class launch in a separate profiled step) and `cpu_baseline` (the CPU oracle, a from-scratch
-restatement = kind "port", timed on this box's host cores on a bounded sample).
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  `roofline`      dominant kernel of the fp32 step, measured live with HIP events around every GEMM-class launch of one extra
+                  step; the HBM-bound groups (GroupNorm / LayerNorm / split-K reduce) additionally carry the per-symbol averages of
+                  the committed rocprofv3 trace (profiles/*_bench_kernel_stats.csv): an event pair around a ~5 us kernel reads ~2.5x
+                  too long, the trace does not;
+  `cpu_baseline`  the CPU oracle (a from-scratch restatement = kind "port") timed on this box's host cores on a bounded sample;
+  `config3`       secondary measurement, N == 1 only: BASELINE config 3 (bf16 UNet / VAE + fp32 coefficient gradient, bs=4) with its
+                  own dominant-kernel roofline against the 2.5 PF dense bf16 MFMA peak. Never used for `value`.
+
+`--dry` runs the same control flow on dry contexts with the gloo backend (no GPU: launcher / sharding / merge / JSON contract
+only, computes nothing) — used by the CPU test of the N > 1 launcher path.
 """
 import argparse
 import json
 import os
+import socket
 import sys
 import time
 
@@ -27,6 +38,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_FP32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0     # same guide: v_mfma_f32_32x32x16_bf16, dense (not the 2:1-sparsity headline)
+PEAK_HBM_GBPS = 8000.0
 STEPS_PER_IDENTITY = 800           # aigc_id.yaml:135 max_steps
 
 
@@ -36,7 +49,7 @@ def pmc_traffic(kernel):
     tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Returns (bytes | None, detail)."""
     import glob
     import re
-    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "*_pmc_hbm_traffic.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
     if not files:
         return None, None
     kinds = {"ROW": 0, "COL": 1, "CONV": 2, "CONVF": 3}
@@ -60,6 +73,125 @@ def pmc_traffic(kernel):
     return round(raw), detail
 
 
+# kernel symbols behind each HBM-bound profiler group (rocprofv3 names, `cb::` stripped as tools/prof_stats.py writes them)
+HBM_GROUP_SYMBOLS = {
+    "groupnorm_fwd": ("gn_partial_kernel", "gn_final_kernel", "gn_apply_kernel"),
+    "groupnorm_bwd": ("gn_bwd_partial_kernel", "gn_bwd_final_kernel", "gn_bwd_apply_kernel"),
+    "layernorm_fwd": ("layernorm_fwd_kernel",), "layernorm_bwd": ("layernorm_bwd_kernel",),
+    "splitk_reduce_kernel": ("splitk_reduce_kernel",),
+}
+
+
+def rocprof_symbol_ms(bf16=False, prefix="r02"):
+    """per-symbol milliseconds per step of the newest committed rocprofv3 kernel trace of this bench
+    (profiles/<prefix>*_bench_kernel_stats.csv); template instances are split by element type (fp32 step vs config-3 step)"""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{prefix}*_bench_kernel_stats.csv")))
+    if not files:
+        return None, {}
+    out = {}
+    with open(files[-1]) as f:
+        rows = [r for r in f if not r.startswith("#")]
+    for r in csv.DictReader(rows):
+        base = r["name"].split("<")[0]
+        if ("bf16" in r["name"]) != bf16:
+            continue
+        out[base] = out.get(base, 0.0) + float(r["ms_per_step"])
+    return os.path.basename(files[-1]), out
+
+
+def maybe_self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher environment: become `torch.distributed.run` with N ranks"""
+    if args.gpus <= 1 or "WORLD_SIZE" in os.environ:
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.execvp(cmd[0], cmd)
+
+
+def timed_loop(run, steps, warmup, world, dist, dev, dry):
+    for i in range(warmup):
+        run(i)
+    sync = (lambda: None) if dry else torch.cuda.synchronize
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        run(warmup + i)
+    sync()
+    if world > 1:
+        dist.barrier()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    return elapsed
+
+
+def profile_step(ctx, run, peak_tflops, bf16=False):
+    """one extra step with a HIP-event pair around every GEMM-class launch -> (roofline dict, phases, stats)"""
+    ctx.reset_stats()
+    ctx.profile_begin()
+    run(0)
+    prof = ctx.profile_end()
+    st = ctx.stats()
+    phases = {p["kernel"][6:]: round(p["ms"], 3) for p in prof if p["kernel"].startswith("phase:")}
+    prof = [p for p in prof if not p["kernel"].startswith("phase:")]
+    hbm = [p for p in prof if p.get("bytes", 0) > 0 and p["flops"] == 0]    # HBM-bound groups: algorithmic bytes
+    prof = [p for p in prof if p["flops"] > 0]                             # MFMA-bound launches (GEMM family + fused attention)
+    tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
+    dom = max(prof, key=lambda p: p["ms"])
+    ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
+    src, sym_ms = rocprof_symbol_ms(bf16)
+    hb = []
+    for p in sorted(hbm, key=lambda p: -p["ms"]):
+        e = dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1), ms_events=round(p["ms"], 3),
+                 gbps_events=round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1))
+        hb.append(e)
+    # rocprofv3 view of the same groups: the trace has one duration per symbol, so a group's size classes and its SiLU / plain
+    # variants (same three GroupNorm symbols) are merged
+    groups = {}
+    for p in hbm:
+        g = p["kernel"].split("[")[0].replace("<bf16>", "").replace("groupnorm_silu_", "groupnorm_")
+        a = groups.setdefault(g, dict(bytes=0.0, launches=0))
+        a["bytes"] += p["bytes"]; a["launches"] += p["launches"]
+    rp = []
+    for g, a in groups.items():
+        syms = HBM_GROUP_SYMBOLS.get(g)
+        if not syms or not all(s in sym_ms for s in syms):
+            continue
+        ms = sum(sym_ms[s] for s in syms)
+        rp.append(dict(kernel=g, symbols=list(syms), launches=a["launches"], algorithmic_mb=round(a["bytes"] / 1e6, 1), ms_rocprof=round(ms, 3),
+                       achieved_gbps=round(a["bytes"] / (ms * 1e-3) / 1e9, 1), frac_of_8tbps=round(a["bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)))
+    roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
+                    frac=round(ach / peak_tflops, 4), traffic=None, traffic_detail=None,
+                    launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 5),
+                    algorithmic_gflop_per_step=round(dom["flops"] / 1e9, 1),
+                    algorithmic_bytes_per_launch=round(dom.get("bytes", 0) / dom["launches"]),
+                    all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
+                                          achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
+                    attention_mfma=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3),
+                                         achieved_tflops=round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2),
+                                         frac_of_peak=round(p["flops"] / (p["ms"] * 1e-3) / 1e12 / peak_tflops, 4))
+                                    for p in prof if p["kernel"].startswith("flash")],
+                    by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
+                               for p in sorted(prof, key=lambda p: -p["ms"])],
+                    hbm_bound=dict(source_rocprof=src,
+                                   note="ms_events = live HIP-event pairs (a pair around a ~5 us kernel reads ~2.5x long); rocprof = per-symbol "
+                                        "averages of the committed rocprofv3 --kernel-trace of this same command — use those for bandwidth",
+                                   rocprof=rp, events=hb))
+    return roofline, phases, st
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -67,21 +199,35 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary, cross-step-pipelined measurement")
+    ap.add_argument("--no-config3", action="store_true", help="skip the secondary bf16 bs=4 measurement (BASELINE config 3)")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=64, help="host threads for the CPU baseline (reported as `cores`)")
     ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
+    ap.add_argument("--dry", action="store_true", help="no GPU: dry contexts + gloo (launcher / sharding / merge / JSON contract only)")
     args = ap.parse_args()
+    maybe_self_launch(args)
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X; no GPU is visible")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    if world != args.gpus:
+        raise SystemExit(f"bench.py --gpus {args.gpus} was started with WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} "
+                         f"(or run `python bench.py --gpus {args.gpus}` and let it launch its own ranks)")
+    dry = args.dry
+    if not dry and not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no GPU is visible (use --dry for the launcher-only check)")
     import torch.distributed as dist
+    if dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        assert dist.get_world_size() == args.gpus, (dist.get_world_size(), args.gpus)
 
     from celebbasis_amd import build as cb_build
     if rank == 0:
@@ -92,44 +238,30 @@ def main():
 
     # ---- seeded synthetic weights at the true SD v1-4 shapes (no checkpoints offline), same on every rank
     shapes = synthetic.trainer_shapes()
-    state = synthetic.synthetic_state(shapes, seed=0)
-    ctx = lib.Context()
+    state = shapes if dry else synthetic.synthetic_state(shapes, seed=0)
+    ctx = lib.Context(device=-1) if dry else lib.Context()
     tr = lib.Trainer(ctx, lib.WeightTable(state))
-    n_params = sum(v.numel() for v in state.values())
+    n_params = sum(int(torch.Size(v).numel()) if dry else v.numel() for v in state.values())
 
-    identity = 1 + (rank % 9)
-    batches = [synthetic.synthetic_batch(1, step=s, device=dev, identity=identity, seed=23 + rank) for s in range(args.batches)]
+    identity = rank % 10            # the dense identity slot this rank personalises (max_ids = 10)
+    batches = [None if dry else synthetic.synthetic_batch(1, step=s, device=dev, identity=identity, seed=23 + rank) for s in range(args.batches)]
     lr = 5e-3       # base_learning_rate 5e-3 * bs 1 * ngpu 1 * accum 1 (main_id_embed.py:767-786)
 
     def run(i):
+        if dry:
+            tr.step(1, None, None, None, None, None, None, lr)
+            return
         b = batches[i % len(batches)]
         tr.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr)
 
-    for i in range(args.warmup):
-        run(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run(args.warmup + i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    loss = float(tr.get_state("loss")[0])
+    elapsed = timed_loop(run, args.steps, args.warmup, world, dist, dev, dry)
+    loss = None if dry else float(tr.get_state("loss")[0])
 
     # ---- secondary measurement (rank 0, not the headline `value`): the same K steps with the first stage of batch i+1
     # (VAE encode + FR backbone, no gradients) prefetched on its own stream under the UNet of batch i (cb_trainer_prefetch).
     # Every timed iteration still executes one VAE encode, one FR pass and one full step; results are bitwise identical.
     pipelined = None
-    if rank == 0 and world == 1 and not args.no_pipelined:      # N == 1 only, like the CPU baseline: keeps the N > 1 runs lean
+    if rank == 0 and world == 1 and not args.no_pipelined and not dry:      # N == 1 only, like the CPU baseline: keeps the N > 1 runs lean
         def nb(i):
             return batches[i % len(batches)]
         b0 = nb(0)
@@ -145,45 +277,25 @@ def main():
         pipelined = dict(steps_per_s=round(args.steps / el, 4), ms_per_step=round(el / args.steps * 1e3, 3),
                          note="first stage of batch i+1 overlapped with step i (opt-in cb_trainer_prefetch); not used for `value`")
 
-    # ---- checkpoint merge (outside the timed region): the one collective of the job
-    coef = tr.get_state("id_coefficients").reshape(10, -1)
+    # ---- checkpoint merge (outside the timed region): the one collective of the job. Every rank contributes the coefficient block
+    # of its own identity slot; rank 0 must end up with exactly `world` non-empty slots.
+    if dry:
+        coef = torch.zeros(10, 1024); coef[identity] = 1.0 + rank
+    else:
+        coef = tr.get_state("id_coefficients").reshape(10, -1)
     merged = sharding.gather_identity_blocks([identity], coef[identity:identity + 1], 10, device=dev)
+    merged_identities = int((merged.abs().sum(dim=1) > 0).sum().item())
+    assert merged_identities == min(world, 10), f"checkpoint merge returned {merged_identities} identities for {world} ranks"
 
     out = None
     if rank == 0:
-        # ---- live roofline: one extra step with a HIP-event pair around every GEMM-class launch
-        ctx.reset_stats()
-        ctx.profile_begin()
-        run(0)
-        prof = ctx.profile_end()
-        st = ctx.stats()
-        phases = {p["kernel"][6:]: round(p["ms"], 3) for p in prof if p["kernel"].startswith("phase:")}
-        prof = [p for p in prof if not p["kernel"].startswith("phase:")]
-        hbm = [p for p in prof if p.get("bytes", 0) > 0 and p["flops"] == 0]   # HBM-bound groups (GroupNorm / LayerNorm / split-K reduce): algorithmic bytes
-        prof = [p for p in prof if p["flops"] > 0]              # MFMA-bound launches (GEMM family + fused attention)
-        tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
-        dom = max(prof, key=lambda p: p["ms"])
-        ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-        traffic, traffic_detail = pmc_traffic(dom["kernel"])
-        roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=PEAK_FP32_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=round(ach / PEAK_FP32_MFMA_TFLOPS, 4), traffic=traffic, traffic_detail=traffic_detail,
-                        launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 5),
-                        algorithmic_gflop_per_step=round(dom["flops"] / 1e9, 1),
-                        algorithmic_bytes_per_launch=round(dom.get("bytes", 0) / dom["launches"]),
-                        all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
-                                              achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
-                        attention_mfma=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3),
-                                             achieved_tflops=round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2),
-                                             frac_of_peak=round(p["flops"] / (p["ms"] * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS, 4))
-                                        for p in prof if p["kernel"].startswith("flash")],
-                        by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
-                                   for p in sorted(prof, key=lambda p: -p["ms"])],
-                        hbm_bound=[dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1),
-                                        ms=round(p["ms"], 3), achieved_gbps=round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1),
-                                        frac_of_8tbps=round(p["bytes"] / (p["ms"] * 1e-3) / 8e12, 4))
-                                   for p in sorted(hbm, key=lambda p: -p["ms"])])
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
+        if dry:
+            roofline, phases, st = None, {}, ctx.stats()
+        else:
+            roofline, phases, st = profile_step(ctx, run, PEAK_FP32_MFMA_TFLOPS)
+            roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(roofline["kernel"])
         out = {
             "metric": "personalization train steps/sec @ SD v1-4 512x512 bs=1", "value": round(value, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -199,11 +311,34 @@ def main():
             "loss": loss,
             "phase_ms": phases,
             "pipelined": pipelined,
-            "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()),
+            "merged_identities": merged_identities,
             "roofline": roofline,
         }
+        if dry:
+            out["dry"] = True
+    # ---- secondary: BASELINE config 3 (bf16 UNet / VAE + fp32 coefficient gradient, bs=4) on its own context, N == 1 only
+    if rank == 0 and world == 1 and not args.no_config3 and not dry:
+        B3 = 4
+        ctx3 = lib.Context(dtype="bf16")
+        tr3 = lib.Trainer(ctx3, lib.WeightTable(state))
+        b3 = [synthetic.synthetic_batch(B3, step=s, device=dev, identity=identity, seed=523) for s in range(2)]
+        lr3 = 5e-3 * B3
+
+        def run3(i):
+            b = b3[i % len(b3)]
+            tr3.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr3)
+        el3 = timed_loop(run3, args.steps, args.warmup, 1, dist, dev, False)
+        rf3, ph3, st3 = profile_step(ctx3, run3, PEAK_BF16_MFMA_TFLOPS, bf16=True)
+        ms3 = el3 / args.steps * 1e3
+        out["config3"] = {"workload": "BASELINE config 3: single identity, SD v1-4 512x512, bs=4, bf16 UNet / VAE (storage + MFMA), fp32 CLIP / "
+                                      "coefficient head / gradient / AdamW, full step", "dtype": "bf16", "batch": B3,
+                          "steps_per_s": round(args.steps / el3, 4), "samples_per_s": round(B3 * args.steps / el3, 3), "ms_per_step": round(ms3, 3),
+                          "vs_config2_samples_per_s": round(B3 * args.steps / el3 / out["value"], 3),
+                          "step_tflop": round(st3["gemm_flops"] / 1e12, 4), "step_tflops_per_gpu": round(st3["gemm_flops"] / 1e12 / (ms3 * 1e-3), 2),
+                          "kernel_launches_per_step": st3["launches"], "loss": float(tr3.get_state("loss")[0]), "phase_ms": ph3, "roofline": rf3}
+        tr3.close(); ctx3.close()
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         from oracle import cb_oracle as O
         cores = min(args.cpu_threads, os.cpu_count() or 1)
         torch.set_num_threads(cores)

@@ -264,6 +264,27 @@ if r == 0:
     assert (tmp_path / "ok").read_text() == "ok"
 
 
+def test_bench_launches_its_own_ranks_and_checks_the_merge():
+    """`python bench.py --gpus 2` with no launcher environment re-executes itself under torch.distributed.run (one rank per GPU);
+    here on dry contexts with gloo: world size, identity sharding, the checkpoint-merge gather and the JSON contract of the N > 1
+    line. A launcher / --gpus mismatch is an error instead of a silently wrong `n_gpus`."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["merged_identities"] == 2 and d["scaling"] == "weak" and d["dry"] is True
+    assert d["config"]["global_batch"] == 2 and abs(d["identities_per_sec"] - d["value"] / 800) < 1e-5
+    assert d["cpu_baseline"] is None and d["steps"] == 2 and d["warmup"] == 1
+    env["WORLD_SIZE"] = "1"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
 def test_bench_line_contract_of_committed_profile():
     """the bench.py JSON line committed under profiles/ carries every field of the driver's contract (keys and types), the
     roofline and cpu_baseline objects, and internally consistent numbers"""

@@ -1,0 +1,51 @@
+#!/bin/bash
+# tools/gpurun.sh <what> [args…] — the one script that runs on the GPU box (invoked as: gpurun -- 'bash tools/gpurun.sh <what> …').
+# Everything it writes goes to gpurun_out/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
+#   tests [pytest args]       pytest -m gpu (default: the whole GPU suite)
+#   smoke                     __graft_entry__.smoke()
+#   bench [bench.py args]     python bench.py …                       -> gpurun_out/bench.json
+#   trace <tag> [bench args]  rocprofv3 --kernel-trace of bench.py + per-symbol CSV (tools/prof_stats.py)
+#                             -> gpurun_out/<tag>_bench_kernel_stats.csv
+#   pmc <tag> [bench args]    two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains other than the kernel
+#                             trace) + tools/pmc_traffic.py           -> gpurun_out/<tag>_pmc_hbm_traffic.json
+#   py <script> [args]        python <script> …                       -> gpurun_out/<script name>.log
+set -u
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+REPO=$(pwd)
+what=${1:-tests}; shift || true
+case "$what" in
+  tests)
+    if [ $# -eq 0 ]; then set -- tests -m gpu; fi
+    ( time python -m pytest "$@" -q -p no:cacheprovider --no-header ) > gpurun_out/pytest.log 2>&1
+    tail -25 gpurun_out/pytest.log ;;
+  smoke)
+    python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log ;;
+  bench)
+    python bench.py "$@" > gpurun_out/bench.log 2>&1
+    grep '^{' gpurun_out/bench.log | tail -1 > gpurun_out/bench.json; cut -c1-400 gpurun_out/bench.json ;;
+  trace)
+    tag=$1; shift
+    STEPS=6
+    cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/trace_$tag -o bench -- \
+      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined "$@" > $REPO/gpurun_out/trace_$tag.log 2>&1
+    cd $REPO
+    db=$(find gpurun_out/trace_$tag -name "*.db" | head -1)
+    # every measurement leg of bench.py runs warmup + steps + 1 profiled step of its own kernels
+    python tools/prof_stats.py "$db" gpurun_out/${tag}_bench_kernel_stats.csv $((STEPS + 3)) | head -60
+    find gpurun_out/trace_$tag -size +8M -delete ;;
+  pmc)
+    tag=$1; shift
+    cd /tmp
+    for c in FETCH_SIZE WRITE_SIZE; do
+      rocprofv3 --kernel-trace --pmc $c -d $REPO/gpurun_out/pmc_${tag}_$c -o p --output-format csv -- \
+        python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined "$@" > $REPO/gpurun_out/pmc_${tag}_$c.log 2>&1
+    done
+    cd $REPO
+    python tools/pmc_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/${tag}_pmc_hbm_traffic.json
+    find gpurun_out -name "*.csv" -size +8M -delete ;;
+  py)
+    script=$1; shift
+    python "$script" "$@" > gpurun_out/$(basename "$script" .py).log 2>&1; tail -30 gpurun_out/$(basename "$script" .py).log ;;
+  *) echo "unknown target $what"; exit 2 ;;
+esac
