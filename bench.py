@@ -55,7 +55,11 @@ def pmc_traffic(kernel):
     kinds = {"ROW": 0, "COL": 1, "CONV": 2, "CONVF": 3}
     m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+),(\w+)(,generic)?>", kernel)
     m4 = re.match(r"gemm_kernel_occ4<(\w+),(\w+)>", kernel)
-    if m:
+    mg = re.match(r"gemm_glds_kernel<(float|bf16),(\d+),(\d+),(\w+)>", kernel)       # LDS-DMA kernel: <T, BM, BN, AK, row bytes, stages>
+    if mg:
+        ak = {"ROW": 0, "CONV": 1, "CONVF": 2}[mg.group(4)]
+        sym = f"gemm_glds_kernel<{'float' if mg.group(1) == 'float' else '__bf16'}, {mg.group(2)}, {mg.group(3)}, {ak}, 128, 2>"
+    elif m:
         sym = f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
     elif m4:
         sym = f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"

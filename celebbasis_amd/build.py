@@ -13,11 +13,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcelebbasis_hip.so")
-SOURCES = ["cb_gemm.hip", "cb_gemm_bf16.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
+SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
            "cb_abi.hip"]
 HEADERS = ["cb_common.h", "cb_device.h", "cb_gemm_tiles.h", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unused-lambda-capture", "-Wno-unused-result"]
+# Attention kernels: MFMA results feed VALU (softmax) and the next MFMA's B operand directly, so the accumulators belong in
+# ordinary VGPRs. The default AGPR form costs ~100 v_accvgpr_read/write per streamed tile and 28 .. 78 extra registers
+# (flash_fwd<3> 128 -> 100, flash_bwd_dkv<3> 256 -> 178). CB_MFMA_VGPR_FORM=0 restores the default (A/B measurements).
+EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_VGPR_FORM", "1") != "0" else [])
+         for src in ("cb_flash.hip", "cb_flash_bf16.hip")}
 
 
 def _hipcc():
@@ -41,9 +46,10 @@ def build(verbose=True, force=False):
 
     def compile_one(src):
         s = os.path.join(CSRC, src)
-        o = os.path.join(BUILD, src.replace(".hip", ".o"))
+        extra = EXTRA.get(src, [])
+        o = os.path.join(BUILD, src.replace(".hip", "_x.o" if extra else ".o"))       # the flag set is part of the cache key
         if force or _newer([s] + hdrs, o):
-            cmd = [hipcc] + FLAGS + ["-c", s, "-o", o]
+            cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print("[celebbasis_amd.build]", " ".join(cmd), flush=True)
             subprocess.check_call(cmd)

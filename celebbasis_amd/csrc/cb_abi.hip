@@ -1,6 +1,7 @@
 // cb_abi.hip — extern "C" surface of libcelebbasis_hip.so (declared in include/celebbasis_hip.h).
 #include "../../include/celebbasis_hip.h"
 #include "cb_models.h"
+#include "cb_gemm_tiles.h"
 
 using namespace cb;
 
@@ -36,6 +37,12 @@ int cb_ctx_dtype(cb_ctx* ctx, int* dtype) {
     CB_TRY
     require(ctx, "ctx"); require(dtype, "dtype");
     *dtype = (int)ctx->c.dtype;
+    CB_END
+}
+int cb_ctx_aux_stream(cb_ctx* ctx, void** hip_stream) {
+    CB_TRY
+    require(ctx, "ctx"); require(hip_stream, "hip_stream");
+    *hip_stream = static_cast<void*>(ctx->c.aux);
     CB_END
 }
 int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
@@ -176,6 +183,15 @@ int cb_wtab_add(cb_wtab* wt, const char* name, const float* data, int on_device,
 int cb_wtab_destroy(cb_wtab* wt) {
     CB_TRY
     delete wt;
+    CB_END
+}
+
+// ------------------------------------------------------------------ diagnostics
+int cb_debug_force_plan(int BM, int BN, int split) {
+    CB_TRY
+    CB_CHECK((BM == 0 && BN == 0) || ((BM == 64 || BM == 128) && (BN == 64 || BN == 128)), CB_ERR_ARG, "force_plan: tile %dx%d", BM, BN);
+    PlanForce& f = plan_force();
+    f.BM = BM; f.BN = BN; f.split = split > 0 ? split : 0;
     CB_END
 }
 
@@ -753,6 +769,7 @@ int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg,
     tc.momentum = cfg->momentum; tc.scale_factor = cfg->scale_factor; tc.linear_start = cfg->linear_start;
     tc.linear_end = cfg->linear_end; tc.timesteps = cfg->timesteps; tc.placeholder_token = cfg->placeholder_token;
     tc.adam_b1 = cfg->adam_b1; tc.adam_b2 = cfg->adam_b2; tc.adam_eps = cfg->adam_eps; tc.weight_decay = cfg->weight_decay;
+    tc.use_rm_mlp = cfg->use_rm_mlp != 0;
     CB_CHECK(tc.image_size % 8 == 0 && tc.es >= 1 && tc.inner_dim >= 1 && tc.max_ids >= 1 && tc.timesteps >= 1, CB_ERR_ARG,
              "trainer cfg: bad sizes");
     CB_CHECK(cfg->dtype == (int)ctx->c.dtype, CB_ERR_ARG, "trainer cfg: dtype %d differs from the context's %d (create the context with "
@@ -811,6 +828,26 @@ int cb_trainer_prefetch(cb_trainer* t, const cb_batch* b) {
     trainer_prefetch(&t->T, bt);
     CB_END
 }
+int cb_trainer_set_prefetch_stream(cb_trainer* t, void* hip_stream) {
+    CB_TRY
+    require(t, "trainer");
+    trainer_set_prefetch_stream(&t->T, static_cast<hipStream_t>(hip_stream));
+    CB_END
+}
+int cb_trainer_prefetch_stream(cb_trainer* t, void** hip_stream) {
+    CB_TRY
+    require(t, "trainer"); require(hip_stream, "hip_stream");
+    *hip_stream = static_cast<void*>(trainer_prefetch_stream(&t->T));
+    CB_END
+}
+
+int cb_trainer_loss_to(cb_trainer* t, float* loss_dev) {
+    CB_TRY
+    require(t, "trainer");
+    if (!t->ctx->dry) require(loss_dev, "loss_dev");
+    k_axpby(t->ctx->launch(), loss_dev, t->T.loss, 1, 1.f, 0.f);
+    CB_END
+}
 
 struct StateRef { void* p; long n; bool is_int; };
 static StateRef find_state(cb_trainer* t, const char* name) {
@@ -830,6 +867,13 @@ static StateRef find_state(cb_trainer* t, const char* name) {
     if (s == "id_embeddings") return {T.id_emb, (long)c.max_ids * c.es * w, false};
     if (s == "id_coefficients") return {T.id_coef, (long)c.max_ids * O, false};
     if (s == "step") return {T.step, 1, true};
+    if (s.rfind("rm.", 0) == 0 || s == "adam.m_coef" || s == "adam.v_coef") {
+        CB_CHECK(T.coef != nullptr, CB_ERR_STATE, "trainer state '%s' exists only with use_rm_mlp", name);
+        if (s == "rm.coef") return {T.coef, (long)c.max_ids * O, false};
+        if (s == "rm.grad_coef") return {T.gC, (long)c.max_ids * O, false};
+        if (s == "adam.m_coef") return {T.mC, (long)c.max_ids * O, false};
+        if (s == "adam.v_coef") return {T.vC, (long)c.max_ids * O, false};
+    }
     fail(CB_ERR_MISSING, "unknown trainer state '%s'", name);
 }
 int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64_t max_elems, int64_t* numel) {

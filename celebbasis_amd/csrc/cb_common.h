@@ -114,9 +114,13 @@ struct GemmArgs {
 
 void gemm(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
 size_t gemm_ws_bytes(const GemmArgs& a);
-// bf16 twin (cb_gemm_bf16.hip): k-contiguous operands only (ROW / CONV x ROW), 16-byte aligned, K % 8 == 0
+// LDS-DMA kernels (cb_gemm_glds.hip): k-contiguous operands only (ROW / CONV x ROW), 16-byte aligned rows.
+// bf16: K % 8 == 0. fp32: gemm() itself routes every eligible problem there (gemm_f32_glds returns false otherwise).
 void gemm_bf16(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
 size_t gemm_bf16_ws_bytes(const GemmArgs& a);
+bool gemm_f32_glds_shape_ok(const GemmArgs& a);
+size_t gemm_f32_glds_ws_bytes(const GemmArgs& a);
+bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* splitk_ws, size_t splitk_ws_bytes);
 
 // ---------------------------------------------------------------- fused attention (cb_flash.hip)
 struct FlashArgs {
@@ -132,7 +136,12 @@ struct FlashArgs {
     void* dq = nullptr; float beta_q = 0.f;                      // layout of q
     void* dk = nullptr; void* dv = nullptr; float beta_kv = 0.f; // layout of k / v
     float* ws = nullptr; int nsplit = 1;   // dK/dV query-split partials [2][nsplit][B*H][Nk][d] (cross-attention: few keys, many queries)
+    // key-split of the forward / dQ kernels when Nq/64 * B*H blocks cannot fill the chip (the 32x32 .. 8x8 levels): blockIdx.z owns
+    // a key range; forward partials [ksplit][B*H][Nq][d] (unnormalised O) + [ksplit][B*H][Nq][2] (max, sum), dQ partials
+    // [ksplit][B*H][Nq][d]; one small combine kernel each (fp32 kernels only)
+    float* wsk = nullptr; int ksplit = 1;
 };
+size_t flash_ksplit_ws_floats(const FlashArgs& a, int B, bool forward, int* ksplit);
 size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
 bool flash_supported(int d, const FlashArgs& a);
 void flash_forward(const Launch& L, const FlashArgs& a, int B);
@@ -215,6 +224,10 @@ void k_row_surgery_multi(const Launch& L, float* out, const float* in, const flo
 void k_row_surgery_bwd(const Launch& L, float* dz, const float* dout, const int32_t* map, int B, int T, int C, int reps);
 void k_ema_update(const Launch& L, float* id_emb, float* id_coef, const float* z, const float* coef,
                   const int64_t* ids, int ids_stride, int B, int embN, int coefN, int max_ids, float m);
+// use_rm_mlp (meta_net.py:272-273): out[f*B + b][:] = coef[ids[b][f]][:] ; gcoef = dense index-backward of the same gather
+void k_coef_gather(const Launch& L, float* out, const float* coef, const int64_t* ids, int ids_stride, int B, int nface, int D, int max_ids);
+void k_coef_scatter_grad(const Launch& L, float* gcoef, const float* dout, const int64_t* ids, int ids_stride, int B, int nface, int D,
+                         int max_ids);
 void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, const float* v, int R, int O, int I);
 void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step,
              float lr, float b1, float b2, float eps, float wd);

@@ -98,11 +98,19 @@ void* Ctx::operand(const float* src, long rows, int cols, int cols_p) {
     return d;
 }
 // finish a Lin whose fp32 [out][in] weight already sits on the device: fp32 graphs use it as it is; bf16 graphs get a bf16 copy
-// (rows padded to 8 columns) and, for the input gradient, its transpose [in][out]
+// (rows padded to 8 columns). Both keep its transpose [in][out] for the input gradient dx = dy . W: with it that GEMM has two
+// k-contiguous operands and runs on the LDS-DMA kernel (cb_gemm_glds.hip) instead of an m-contiguous register-staged loader.
 static void finish_linear(Ctx* ctx, Lin* l, float* w32) {
     l->dt = ctx->load_dt;
     l->in_p = pad8(l->dt, l->in);
-    if (l->dt == DT_F32) { l->w = w32; return; }
+    if (l->dt == DT_F32) {
+        l->w = w32;
+        if (l->in % 4 == 0 && l->out % 4 == 0) {
+            l->wT = ctx->pool.alloc((size_t)l->in * l->out * sizeof(float));
+            k_transpose(ctx->launch(), DT_F32, l->wT, l->w, 1, l->out, l->in, l->in, 0);
+        }
+        return;
+    }
     l->w = ctx->operand(w32, l->out, l->in, l->in_p);
     if (l->in_p == l->in && l->out % 8 == 0) {
         l->wT = ctx->pool.alloc((size_t)l->in * l->out * dt_size(l->dt));
@@ -366,7 +374,7 @@ Ten* Graph::linear(Ten* x, const Lin& l, Ten* residual) {
             GemmArgs d;   // dx[rows,in] = dy[rows,out] . W[out,in]
             d.dt = x->dt;
             d.A = y->g; d.lda = lc.out; d.a_kind = LD_ROW;
-            if (x->dt == DT_BF16) { d.B = lc.wT; d.ldb = lc.out; d.b_kind = LD_ROW; }     // W^T [in][out]: k = out contiguous
+            if (lc.wT) { d.B = lc.wT; d.ldb = lc.out; d.b_kind = LD_ROW; }                // W^T [in][out]: k = out contiguous
             else { d.B = lc.w; d.ldb = lc.in; d.b_kind = LD_COL; }
             d.M = (int)rows; d.N = lc.in; d.K = lc.out; d.ldc = lc.in;
             float beta; d.C = grad(x, &beta); d.beta = beta;
@@ -434,6 +442,7 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
     f.o = o->p;
     if (use_flash && (bf ? flash_bf16_supported(d, f) : flash_supported(d, f))) {
         f.lse = ctx->arena.allocf((size_t)B * heads * Nq);
+        if (!bf) { size_t wf = flash_ksplit_ws_floats(f, B, true, &f.ksplit); if (wf) f.wsk = ctx->arena.allocf(wf); }
         if (bf) flash_bf16_forward(L, f, B); else flash_forward(L, f, B);
         if (rg) {
             tape.push_back([this, f, o, qt, kt, qoff, koff, voff, B, Nq, bf]() mutable {
@@ -444,6 +453,8 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
                 if (qt->rg) gq = grad(qt, &bq);
                 if (kt->rg) { if (kt == qt) { gk = gq; bk = bq; } else gk = grad(kt, &bk); }
                 if (gq) { f.dq = ptr_off(gq, f.dt, qoff); f.beta_q = bq; }
+                f.ksplit = 1; f.wsk = nullptr;
+                if (gq && !bf) { size_t wq = flash_ksplit_ws_floats(f, B, false, &f.ksplit); if (wq) f.wsk = ctx->arena.allocf(wq); }
                 if (gk) {
                     f.dk = ptr_off(gk, f.dt, koff); f.dv = ptr_off(gk, f.dt, voff); f.beta_kv = bk;
                     size_t wsf = bf ? flash_bf16_bwd_ws_floats(f, B, &f.nsplit) : flash_bwd_ws_floats(f, B, &f.nsplit);

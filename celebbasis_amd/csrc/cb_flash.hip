@@ -30,7 +30,8 @@ __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64);
 
 template <int DT> struct FlCfg {
     static constexpr int DP = DT * 16;                          // padded head dim
-    static constexpr int KS = DT * 4;                           // MFMA k-steps over the head dim
+    static constexpr int KS = (DT == 3) ? 10 : DT * 4;          // MFMA k-steps (4 wide) over the head dim; DT = 3 serves d <= 40
+                                                                // (SD's 64x64 attention): 10 steps, not 12 (the dispatcher sends 40 < d <= 48 to DT = 4)
     static constexpr int S2 = ((DP + 31) / 32) * 32 + 2;        // LDS row stride, = 2 (mod 32), >= DP
     static constexpr int TK = (DT >= 8) ? 32 : 64;              // rows of the streamed tile
     static constexpr int NT = TK / 16;                          // 16-row sub-tiles of the streamed tile
@@ -123,14 +124,18 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     for (int t = 0; t < DT; ++t) o[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float m = -INFINITY, l = 0.f;
 
-    int kend = a.Nk;
+    int kbeg = 0, kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);      // keys beyond the last query of the block are fully masked
+    if (a.ksplit > 1) {                                // blockIdx.z owns a key range (never combined with causal)
+        const int kchunk = ((a.Nk + a.ksplit - 1) / a.ksplit + C::TK - 1) / C::TK * C::TK;
+        kbeg = blockIdx.z * kchunk; kend = min(a.Nk, kbeg + kchunk);
+    }
     const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
     FlStream<DT> st; st.init(a.ldk, a.d);
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, srdK, st, 0, a.Nk, a.ldk);
-    fl_prefetch<DT>(pv, srdV, st, 0, a.Nk, a.ldk);
-    for (int k0 = 0; k0 < kend; k0 += C::TK) {
+    fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
+    fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
+    for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
         __syncthreads();
         fl_store<DT>(Ks, pk, st);
         fl_store<DT>(Vs, pv, st);
@@ -193,6 +198,22 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
                     o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[kt][r], o[t], 0, 0, 0);
                 }
     }
+    if (a.ksplit > 1) {                                // partial: unnormalised O relative to the running max m, and (m, l)
+        if (qrow < a.Nq) {
+            const long BHN = (long)gridDim.y * a.Nq, row = (long)bh * a.Nq + qrow;
+            float* W = a.wsk + ((long)blockIdx.z * BHN + row) * a.d;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                int c = t * 16 + quarter * 4;
+                if (c < a.d) *reinterpret_cast<float4*>(W + c) = make_float4(o[t][0], o[t][1], o[t][2], o[t][3]);
+            }
+            if (quarter == 0) {
+                float* ML = a.wsk + (long)a.ksplit * BHN * a.d + ((long)blockIdx.z * BHN + row) * 2;
+                ML[0] = m; ML[1] = l;
+            }
+        }
+        return;
+    }
     if (qrow < a.Nq) {
         float inv = l > 0.f ? 1.f / l : 0.f;
         float* O = static_cast<float*>(a.o) + b * a.sob + h * a.soh + (long)qrow * a.ldo;
@@ -250,20 +271,24 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
             Dq += ov * dreg[s_];
         }
         Dq = quad_sum(Dq);
-        if (quarter == 0 && qrow < a.Nq) a.dvec[(long)bh * a.Nq + qrow] = Dq;
+        if (quarter == 0 && qrow < a.Nq && blockIdx.z == 0) a.dvec[(long)bh * a.Nq + qrow] = Dq;
     }
     f32x4 g[DT];
 #pragma unroll
     for (int t = 0; t < DT; ++t) g[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    int kend = a.Nk;
+    int kbeg = 0, kend = a.Nk;
     if (a.causal) kend = min(a.Nk, q0 + FL_ROWS);
+    if (a.ksplit > 1) {
+        const int kchunk = ((a.Nk + a.ksplit - 1) / a.ksplit + C::TK - 1) / C::TK * C::TK;
+        kbeg = blockIdx.z * kchunk; kend = min(a.Nk, kbeg + kchunk);
+    }
     const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
     FlStream<DT> st; st.init(a.ldk, a.d);
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, srdK, st, 0, a.Nk, a.ldk);
-    fl_prefetch<DT>(pv, srdV, st, 0, a.Nk, a.ldk);
-    for (int k0 = 0; k0 < kend; k0 += C::TK) {
+    fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
+    fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
+    for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
         __syncthreads();
         fl_store<DT>(Ks, pk, st);
         fl_store<DT>(Vs, pv, st);
@@ -307,6 +332,17 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
                     float ak = Ks[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
                     g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, s[kt][r], g[t], 0, 0, 0);
                 }
+    }
+    if (a.ksplit > 1) {
+        if (qrow < a.Nq) {
+            float* W = a.wsk + ((long)blockIdx.z * gridDim.y * a.Nq + (long)bh * a.Nq + qrow) * a.d;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) {
+                int c = t * 16 + quarter * 4;
+                if (c < a.d) *reinterpret_cast<float4*>(W + c) = make_float4(g[t][0], g[t][1], g[t][2], g[t][3]);
+            }
+        }
+        return;
     }
     if (qrow < a.Nq) {
         float* G = static_cast<float*>(a.dq) + b * a.sqb + h * a.sqh + (long)qrow * a.ldq;
@@ -483,14 +519,78 @@ __global__ __launch_bounds__(256) void flash_dkv_reduce_kernel(const FlashArgs a
     }
 }
 
+// key-split combines: one thread per (bh, query, 4 head-dim columns).
+// forward: O = sum_i O_i 2^(m_i - M) / sum_i l_i 2^(m_i - M), lse = M + log2(sum)   (log2 domain, like the unsplit kernel)
+__global__ __launch_bounds__(256) void flash_fwd_combine_kernel(const FlashArgs a, int BH) {
+    const int dq4 = a.d / 4;
+    const long BHN = (long)BH * a.Nq, total = BHN * dq4;
+    const float* MLs = a.wsk + (long)a.ksplit * BHN * a.d;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % dq4) * 4;
+        const long row = i / dq4;
+        float M = -INFINITY;
+        for (int sp = 0; sp < a.ksplit; ++sp) M = fmaxf(M, MLs[(sp * BHN + row) * 2]);
+        const float Mu = (M == -INFINITY) ? 0.f : M;
+        float Lsum = 0.f; float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < a.ksplit; ++sp) {
+            const float* ml = MLs + (sp * BHN + row) * 2;
+            const float w = __builtin_amdgcn_exp2f(ml[0] - Mu);             // m_i = -inf (empty range) -> 0
+            Lsum += ml[1] * w;
+            const float4 x = *reinterpret_cast<const float4*>(a.wsk + (sp * BHN + row) * a.d + c);
+            acc.x += x.x * w; acc.y += x.y * w; acc.z += x.z * w; acc.w += x.w * w;
+        }
+        const float inv = Lsum > 0.f ? 1.f / Lsum : 0.f;
+        const int bh = (int)(row / a.Nq), qi = (int)(row - (long)bh * a.Nq), b = bh / a.H, h = bh - b * a.H;
+        float* O = static_cast<float*>(a.o) + b * a.sob + h * a.soh + (long)qi * a.ldo + c;
+        *reinterpret_cast<float4*>(O) = make_float4(acc.x * inv, acc.y * inv, acc.z * inv, acc.w * inv);
+        if (c == 0 && a.lse) a.lse[row] = M + __builtin_amdgcn_logf(Lsum);
+    }
+}
+__global__ __launch_bounds__(256) void flash_dq_combine_kernel(const FlashArgs a, int BH) {
+    const int dq4 = a.d / 4;
+    const long BHN = (long)BH * a.Nq, total = BHN * dq4;
+    for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % dq4) * 4;
+        const long row = i / dq4;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int sp = 0; sp < a.ksplit; ++sp) {
+            const float4 x = *reinterpret_cast<const float4*>(a.wsk + (sp * BHN + row) * a.d + c);
+            acc.x += x.x; acc.y += x.y; acc.z += x.z; acc.w += x.w;
+        }
+        const int bh = (int)(row / a.Nq), qi = (int)(row - (long)bh * a.Nq), b = bh / a.H, h = bh - b * a.H;
+        float* G = static_cast<float*>(a.dq) + b * a.sqb + h * a.sqh + (long)qi * a.ldq + c;
+        if (a.beta_q != 0.f) { float4 old = *reinterpret_cast<float4*>(G); acc.x += old.x; acc.y += old.y; acc.z += old.z; acc.w += old.w; }
+        *reinterpret_cast<float4*>(G) = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------- host
+static int fl_tk(int d) { return d > 80 ? 32 : 64; }           // FlCfg<DT>::TK of the variant fl_dt(d) picks
+// key split of the forward / dQ kernels: aim at ~2 blocks per CU, every split at least two streamed tiles
+size_t flash_ksplit_ws_floats(const FlashArgs& a, int B, bool forward, int* ksplit) {
+    const int BH = B * a.H;
+    const long blocks0 = (long)cdiv(a.Nq, FL_ROWS) * BH;
+    int ks = 1;
+    if (blocks0 < 256 && !a.causal) {
+        ks = (int)((512 + blocks0 - 1) / blocks0);
+        const int maxs = a.Nk / (2 * fl_tk(a.d));
+        if (ks > maxs) ks = maxs;
+        if (ks > 16) ks = 16;
+        if (ks < 1) ks = 1;
+    }
+    if (getenv("CB_FLASH_KSPLIT")) ks = std::max(1, std::min(atoi(getenv("CB_FLASH_KSPLIT")), std::max(1, a.Nk / fl_tk(a.d))));
+    if (a.causal) ks = 1;
+    *ksplit = ks;
+    return ks > 1 ? (size_t)ks * BH * a.Nq * (a.d + (forward ? 2 : 0)) : 0;
+}
+
 size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit) {
     const int BH = B * a.H;
     long blocks0 = (long)cdiv(a.Nk, FL_ROWS) * BH;
     int ns = 1;
-    if (blocks0 < 128 && a.Nq >= 512 && !a.causal) {
-        ns = (int)((256 + blocks0 - 1) / blocks0);
-        int maxs = a.Nq / 128;                      // at least two 64-query tiles per split
+    if (blocks0 < 256 && a.Nq >= 128 && !a.causal) {
+        ns = (int)((512 + blocks0 - 1) / blocks0);
+        int maxs = a.Nq / 64;                       // at least one 64-query tile (two 32-query tiles) per split
         if (ns > maxs) ns = maxs;
         if (ns < 1) ns = 1;
     }
@@ -522,7 +622,7 @@ template <int DT> static size_t fl_lds_bytes(bool dkv) {
         default: hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), LDSB(10), L.stream, __VA_ARGS__); break;            \
     }
 
-static int fl_dt(int d) { int dt = (d + 15) / 16; return dt <= 5 ? dt : 10; }
+static int fl_dt(int d) { int dt = (d + 15) / 16; if (dt == 3 && d > 40) dt = 4; return dt <= 5 ? dt : 10; }
 
 static size_t lds_fwd(int dt) {
     switch (dt) { case 1: return fl_lds_bytes<1>(false); case 2: return fl_lds_bytes<2>(false); case 3: return fl_lds_bytes<3>(false);
@@ -536,9 +636,10 @@ static size_t lds_dkv(int dt) {
 void flash_forward(const Launch& L, const FlashArgs& a, int B) {
     const int BH = B * a.H, dt = fl_dt(a.d);
     if (L.stats) { L.stats->gemm_flops += 4.0 * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count();
+    L.count(a.ksplit > 1 ? 2 : 1);
     if (L.dry) return;
-    dim3 grid(cdiv(a.Nq, FL_ROWS), BH);
+    CB_CHECK(a.ksplit == 1 || a.wsk, CB_ERR_STATE, "flash forward: key-split workspace missing");
+    dim3 grid(cdiv(a.Nq, FL_ROWS), BH, a.ksplit);
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
         rec.variant = L.prof->id_of("flash_fwd_kernel"); rec.flops = 4.0 * BH * (double)a.Nq * a.Nk * a.d;
@@ -546,6 +647,10 @@ void flash_forward(const Launch& L, const FlashArgs& a, int B) {
     }
 #define LDSF(x) lds_fwd(x)
     FL_DISPATCH(dt, flash_fwd_kernel, grid, LDSF, a)
+    if (a.ksplit > 1) {
+        long total = (long)BH * a.Nq * (a.d / 4);
+        hipLaunchKernelGGL(flash_fwd_combine_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, L.stream, a, BH);
+    }
     CB_HIP(hipGetLastError());
     if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
 }
@@ -555,7 +660,7 @@ void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bo
     // algorithmic (reference-equivalent) work: dP, dQ | dK, dV — the recomputation of S inside both kernels is not counted
     double fl = 2.0 + (need_dq ? 2.0 : 0.0) + (need_dkv ? 4.0 : 0.0);
     if (L.stats) { L.stats->gemm_flops += fl * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count(1 + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
+    L.count(1 + (need_dq && a.ksplit > 1 ? 1 : 0) + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
     if (L.dry) return;
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
@@ -564,8 +669,13 @@ void flash_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bo
     }
     if (!need_dq) hipLaunchKernelGGL(flash_dvec_kernel, dim3(cdiv((long)BH * a.Nq, 4)), dim3(256), 0, L.stream, a, BH);
     if (need_dq) {
-        dim3 grid(cdiv(a.Nq, FL_ROWS), BH);
+        CB_CHECK(a.ksplit == 1 || a.wsk, CB_ERR_STATE, "flash backward: key-split workspace missing");
+        dim3 grid(cdiv(a.Nq, FL_ROWS), BH, a.ksplit);
         FL_DISPATCH(dt, flash_bwd_dq_kernel, grid, LDSF, a)
+        if (a.ksplit > 1) {
+            long total = (long)BH * a.Nq * (a.d / 4);
+            hipLaunchKernelGGL(flash_dq_combine_kernel, dim3((unsigned)std::min<long>((total + 255) / 256, 2048)), dim3(256), 0, L.stream, a, BH);
+        }
     }
     if (need_dkv) {
         CB_CHECK(a.nsplit == 1 || a.ws, CB_ERR_STATE, "flash backward: query-split workspace missing");

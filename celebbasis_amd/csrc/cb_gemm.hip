@@ -392,8 +392,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 // ---------------------------------------------------------------- host side (planner: cb_gemm_tiles.h)
 size_t gemm_ws_bytes(const GemmArgs& a) {
     Plan pl = make_plan(a, BK, 1.0);
-    if (pl.splitk <= 1) return 0;
-    return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+    size_t own = pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+    // a shape-eligible problem normally runs on the LDS-DMA kernel (its own plan); a misaligned op-level pointer sends it back here
+    return gemm_f32_glds_shape_ok(a) ? std::max(own, gemm_f32_glds_ws_bytes(a)) : own;
 }
 
 template <int AK, int BKIND, bool VEC>
@@ -435,6 +436,7 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         CB_CHECK(a.b_kind == LD_ROW, CB_ERR_ARG, "conv: packed weights must be ROW");
     }
     CB_CHECK(a.dt == DT_F32, CB_ERR_ARG, "gemm: the fp32 kernel was handed a bf16 problem");
+    if (gemm_f32_glds(L, a, ws, ws_bytes)) return;          // k-contiguous operands: the LDS-DMA kernel (cb_gemm_glds.hip)
     Plan pl = make_plan(a, BK, 1.0);
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
     L.count(pl.splitk > 1 ? 2 : 1);

@@ -1,0 +1,752 @@
+// cb_gemm_glds.hip — the LDS-DMA MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X), bf16 (BASELINE config 3) and fp32
+// (config 2: every k-contiguous problem, i.e. all convolutions and Linear forwards), plus the register-staged bf16 kernel it replaced.
+//
+//   C[M,N] = alpha * A[M,K] . B[N,K]^T + bias[n] + rowbias[img(m)][n] + R[m][n] + beta * C[m][n]
+//
+// A, B, C, R and rowbias are bf16 in HBM, the accumulator is fp32 (v_mfma_f32_32x32x16_bf16: 2.5 PF dense chip peak), bias
+// and the split-K partials are fp32. Both operands are k-contiguous (activations / conv gathers as A, [out][in] weights as B:
+// the host keeps a transposed copy of a Linear weight for its input gradient instead of an m-contiguous loader), 16-byte
+// aligned with K % 8 == 0, so every load is one branch-free `buffer_load_dwordx4` with hardware zero fill (cb_gemm_tiles.h).
+//
+// Structure = the fp32 kernel's (cb_gemm.hip): 256 threads = 4 wave64 in 2x2, each wave a (BM/2)x(BN/2) sub-tile of 32x32
+// MFMA tiles; a k-tile is 64 bytes per row = 32 bf16 (BK = 32); LDS image [row][4 x 16-byte chunks] XOR-swizzled by
+// (row >> 2) & 3, one conflict-free ds_write_b128 per global load and one conflict-free ds_read_b128 per MFMA operand.
+// A lane (row = lane & 31, kl = lane >> 5) owns the chunks 2*kl and 2*kl+1 of its row; MFMA step `half` feeds chunk 2*kl + half,
+// i.e. the 8 k-slots of half-wave kl hold k = 16*kl + 8*half .. +7 — any assignment of k to MFMA k-slots is a valid contraction
+// as long as A and B use the same one, and they do by construction.
+// What differs from fp32 is the balance: one k-tile is 2 x TM x TN MFMAs of 32 cycles (fp32: 8 x TM x TN of 64), so the kernel
+// is bound by the global->LDS staging, not by the matrix pipe; profiles/README.md (round 2) has the measurements.
+#include "cb_gemm_tiles.h"
+
+namespace cb {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int BKE = 32;          // k elements per tile
+constexpr int ROWB = 64;         // bytes per LDS row
+
+enum { AK_ROW = 0, AK_CONV = 1, AK_CONVF = 2 };
+
+// ---- epilogue shared by both variants. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+template <int BM, int BN>
+__device__ __forceinline__ void gemm_bf16_epilogue(const KArgs& p, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0, int wm, int wn, int ml,
+                                                   int kl, int split, int z, int zb, int zh) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const GemmArgs& a = p.a;
+    if (p.splitk > 1) {
+        float* W = p.ws + ((long)split * a.batch + z) * (long)a.M * a.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                int col = n0 + wn * (BN / 2) + j * 32 + ml;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                    if (row < a.M && col < a.N) W[(long)row * a.N + col] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    bf16_t* __restrict__ Cp = static_cast<bf16_t*>(a.C) + zb * a.sCb + zh * a.sCh;
+    const bf16_t* __restrict__ Rp = a.R ? static_cast<const bf16_t*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
+    const bf16_t* __restrict__ rowbias = static_cast<const bf16_t*>(a.rowbias);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            int col = n0 + wn * (BN / 2) + j * 32 + ml;
+            if (col >= a.N) continue;
+            float bcol = a.bias ? a.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
+                if (row < a.M) {
+                    float v = a.alpha * acc[i][j][r] + bcol;
+                    if (rowbias) v += (float)rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
+                    if (Rp) v += (float)Rp[(long)row * a.ldr + col];
+                    bf16_t* c = Cp + (long)row * a.ldc + col;
+                    if (a.beta != 0.f) v += a.beta * (float)(*c);
+                    *c = (bf16_t)v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, int AK>
+__device__ __forceinline__ void gemm_bf16_body(const KArgs& p, char* lds) {
+    constexpr int TM = BM / 64, TN = BN / 64;
+    const GemmArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y;
+    const int z = blockIdx.z;
+    const int zb = z / a.nh, zh = z - zb * a.nh;
+
+    const bf16_t* __restrict__ Ap = static_cast<const bf16_t*>(a.A) + zb * a.sAb + zh * a.sAh;
+    const bf16_t* __restrict__ Bp = static_cast<const bf16_t*>(a.B) + zb * a.sBb + zh * a.sBh;
+
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(a.K, kbeg + p.k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 64], rb[BN / 64];
+    ConvRows<BM, 2> cr;
+    ConvFast<BM, 2> cf;
+    int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0 (AK_CONVF)
+    if constexpr (AK == AK_CONVF) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
+    else if constexpr (AK == AK_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
+
+    __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    RowOffs<BM, 2> roA; RowOffs<BN, 2> roB;
+    if constexpr (AK == AK_ROW) roA.init(a.lda, m0, a.M, tid);
+    roB.init(a.ldb, n0, a.N, tid);
+    auto loadAB = [&](int k0) {
+        int oa[BM / 64], ob[BN / 64];
+        if constexpr (AK == AK_ROW) offs_row<BM, 2>(oa, roA, k0, kend, tid);
+        else if constexpr (AK == AK_CONVF) {
+            const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
+            const int kx = tap_u - ky * a.g.ks;
+            offs_conv_fast<BM, 2>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 2);
+            ci_u += BKE;
+            if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
+        } else { offs_conv<BM, 2>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
+        offs_row<BN, 2>(ob, roB, k0, kend, tid);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int i = 0; i < BM / 64; ++i) ra[i] = buf_ld4(srdA, oa[i]);
+#pragma unroll
+        for (int i = 0; i < BN / 64; ++i) rb[i] = buf_ld4(srdB, ob[i]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    constexpr int A_BUF = BM * ROWB, B_BUF = BN * ROWB;            // bytes per buffer
+    char* const As = lds;
+    char* const Bs = lds + 2 * A_BUF;
+
+    if (kbeg < kend) {
+        loadAB(kbeg);
+        store_kc<BM>(reinterpret_cast<float*>(As), ra, tid);
+        store_kc<BN>(reinterpret_cast<float*>(Bs), rb, tid);
+    }
+    __syncthreads();
+
+    int cur = 0;
+    const int kl = lane >> 5, ml = lane & 31;
+    const int swz = (ml >> 2) & 3;                                           // == ((row >> 2) & 3): sub-tile bases are multiples of 32
+    const int clo = ((2 * kl) ^ swz) * 16, chi = ((2 * kl + 1) ^ swz) * 16;  // byte offsets of the lane's two chunks
+    for (int k0 = kbeg; k0 < kend; k0 += BKE) {
+        const bool more = (k0 + BKE) < kend;
+        if (more) loadAB(k0 + BKE);
+
+        const char* arow = As + cur * A_BUF + (wm * (BM / 2) + ml) * ROWB;
+        const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * ROWB;
+        bf16x8_t av[2][TM], bv[2][TN];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[half][i] = *reinterpret_cast<const bf16x8_t*>(arow + i * 32 * ROWB + (half ? chi : clo));
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[half][j] = *reinterpret_cast<const bf16x8_t*>(brow + j * 32 * ROWB + (half ? chi : clo));
+        }
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[half][i], bv[half][j], acc[i][j], 0, 0, 0);
+
+        if (more) {
+            store_kc<BM>(reinterpret_cast<float*>(As + (cur ^ 1) * A_BUF), ra, tid);
+            store_kc<BN>(reinterpret_cast<float*>(Bs + (cur ^ 1) * B_BUF), rb, tid);
+        }
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    gemm_bf16_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, ml, kl, split, z, zb, zh);
+}
+
+template <int BM, int BN, int AK>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(const KArgs p) {
+    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
+    gemm_bf16_body<BM, BN, AK>(p, lds);
+}
+
+// ================================================================= LDS-DMA variant (the default; bf16 AND fp32)
+// Same tiles, different staging: `buffer_load_dwordx4 ... lds` writes the 16-byte chunks of a k-tile straight into LDS (no VGPR
+// staging, no ds_write pass — at bf16 MFMA rates the VGPR->LDS store pass of the register-staged kernel above costs more
+// LDS-pipe time than the MFMAs it feeds; at fp32 rates it removes the ~45 VALU + 16 ds_write per k-tile that compete with the
+// MFMAs for issue slots, profiles/r01_pmc_conv.md), and a k-tile is one 128-byte row per tile row: 64 bf16 or 32 fp32.
+// An LDS-DMA instruction writes wave-uniform base + lane * 16, i.e. the LDS image is lane-linear: thread slot idx = tid + i*256
+// owns LDS chunk idx (row = idx >> 3, physical chunk = idx & 7). The XOR swizzle therefore goes on the SOURCE address: the lane
+// fetches logical chunk (idx & 7) ^ ((row >> 1) & 7) of its row. With that, the 16-lane groups of the MFMA operand read
+// (ds_read_b128: rows {0-3,12-15,20-27} / {4-11,16-19,28-31} of a 32-row block at one logical chunk) hit 16 distinct 16-byte
+// bank quads. Out-of-range lanes (row / k tails, conv padding, stride-2 holes) use offset 0xFFFFFFF0: the DMA then writes zeros
+// (tools/probes/probe_glds.hip).
+// Element type T: one 16-byte chunk per lane and k-group feeds ONE v_mfma_f32_32x32x16_bf16 (8 bf16 = the lane's 8 k-slots) or
+// FOUR v_mfma_f32_32x32x2_f32 (float e of the chunk is the lane's k-slot of step e: the contraction visits k in the order
+// {4c + e} x {half-wave}, the same for A and B — any assignment of k to MFMA k-slots is valid when both operands agree).
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+template <typename T> struct El;
+template <> struct El<bf16_t> { static constexpr int ESZ = 2, EPC = 8; typedef bf16x8_t Frag; };
+template <> struct El<float> { static constexpr int ESZ = 4, EPC = 4; typedef f32x4_t Frag; };
+
+// geometry of the LDS-DMA image: rows of RB bytes = CPR 16-byte chunks; thread slot idx = tid + i*256 owns LDS chunk idx
+template <int RB, int ESZ> struct GGeo {
+    static constexpr int CPR = RB / 16;              // chunks per row: 4 (64-byte rows) or 8 (128-byte rows)
+    static constexpr int LOG = CPR == 4 ? 2 : 3;
+    static constexpr int BK = RB / ESZ;              // k elements per tile
+    static constexpr int EPC = 16 / ESZ;             // elements per chunk
+    __device__ static __forceinline__ int row(int idx) { return idx >> LOG; }
+    __device__ static __forceinline__ int swz(int row) { return CPR == 4 ? ((row >> 2) & 3) : ((row >> 1) & 7); }
+    __device__ static __forceinline__ int chunk(int idx) { return (idx & (CPR - 1)) ^ swz(idx >> LOG); }   // logical chunk fetched by slot idx
+};
+
+template <int ROWS, int RB, int ESZ> struct GRows {        // ROW operand: per-slot byte offset of (row, swizzled chunk) or OOB
+    using G = GGeo<RB, ESZ>;
+    static constexpr int N = ROWS * G::CPR / 256;
+    int off[N];
+    __device__ __forceinline__ void init(long ld, int r0, int R, int tid) {
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = tid + i * 256, row = G::row(idx);
+            off[i] = (r0 + row < R) ? (int)(((long)(r0 + row) * ld + G::chunk(idx) * G::EPC) * ESZ) : OOB;
+        }
+    }
+};
+template <int ROWS, int RB, int ESZ> struct GConvFast {   // plain conv, C % BK == 0: a k-tile lies inside one tap (scalar tap walk)
+    using G = GGeo<RB, ESZ>;
+    static constexpr int N = ROWS * G::CPR / 256;
+    int base[N]; unsigned vmask[N];
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = tid + i * 256, r = r0 + G::row(idx);
+            unsigned m = 0; int b = 0;
+            if (r < R) {
+                int n = r / HWo, rem = r - n * HWo, oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                int vy0 = oy * g.stride - g.pad, vx0 = ox * g.stride - g.pad;
+                if (g.ks == 3) {                                 // validity of the 9 taps = (3 row bits) x (3 column bits)
+                    unsigned xb = 0;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) xb |= ((unsigned)(vx0 + kx) < (unsigned)g.W) ? (1u << kx) : 0u;
+#pragma unroll
+                    for (int ky = 0; ky < 3; ++ky) m |= ((unsigned)(vy0 + ky) < (unsigned)g.H) ? (xb << (3 * ky)) : 0u;
+                } else m = ((unsigned)vy0 < (unsigned)g.H && (unsigned)vx0 < (unsigned)g.W) ? 1u : 0u;
+                b = (((n * g.H + vy0) * g.W + vx0) * g.C + G::chunk(idx) * G::EPC) * ESZ;
+            }
+            vmask[i] = m; base[i] = b;
+        }
+    }
+};
+template <int ROWS, int RB, int ESZ> struct GConvGen {    // general gather: per-slot (tap, channel) walk
+    using G = GGeo<RB, ESZ>;
+    static constexpr int N = ROWS * G::CPR / 256;
+    int nb[N], vy0[N], vx0[N], tap[N], ci[N];
+    __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int kfirst, int tid) {
+        const int HWo = g.Ho * g.Wo;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int idx = tid + i * 256, r = r0 + G::row(idx);
+            if (r < R) {
+                int n = r / HWo, rem = r - n * HWo, oy = rem / g.Wo, ox = rem - oy * g.Wo;
+                nb[i] = n * g.H * g.W; vy0[i] = oy * g.stride - g.pad; vx0[i] = ox * g.stride - g.pad;
+            } else { nb[i] = -1; vy0[i] = 0; vx0[i] = 0; }
+            const int k = kfirst + G::chunk(idx) * G::EPC;
+            tap[i] = k / g.C; ci[i] = k - tap[i] * g.C;
+        }
+    }
+    __device__ __forceinline__ void offs(int (&off)[N], const ConvGeom& g, int k0, int Kend, int tid) {
+        const int sh = (g.up | g.tr), Hv = g.H << sh, Wv = g.W << sh;
+#pragma unroll
+        for (int i = 0; i < N; ++i) {
+            const int k = k0 + G::chunk(tid + i * 256) * G::EPC;
+            const int ky = (g.ks == 3) ? ((tap[i] * 11) >> 5) : 0, kx = tap[i] - ky * g.ks;
+            const int vy = vy0[i] + ky, vx = vx0[i] + kx;
+            bool ok = (k < Kend) && (nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
+            ok = ok && !(g.tr && ((vy | vx) & 1));
+            off[i] = ok ? ((nb[i] + (vy >> sh) * g.W + (vx >> sh)) * g.C + ci[i]) * ESZ : OOB;
+            ci[i] += G::BK;                                   // advance to the next k-tile
+            while (ci[i] >= g.C) { ci[i] -= g.C; ++tap[i]; }
+        }
+    }
+};
+
+// ---- LDS-staged epilogue. The MFMA C layout gives a lane ONE column and 16 scattered rows: written straight to HBM that is 64
+// narrow stores per lane in 64/128-byte row pieces, which at K = 320 (the 16 384-row Linear layers) costs more than the whole
+// k loop. Each wave therefore parks its (BM/2)x(BN/2) fp32 sub-tile in its own slice of the (now idle) tile ring — conflict-free
+// ds_write_b32, lanes = consecutive columns — and reads it back as 8-column pieces: a lane then owns 8 consecutive outputs of
+// one row, adds bias / per-image row bias / residual / beta*C with 16- and 32-byte loads, rounds ONCE to T and issues one
+// (bf16) or two (fp32) 16-byte stores; 8 / 4 lanes cover a whole 128-byte line of C.
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8_t*>(p) = o;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+template <typename T, int BM, int BN>
+__device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds, int m0, int n0, int wm,
+                                                   int wn, int lane, int wave, int split, int z, int zb, int zh) {
+    constexpr int TM = BM / 64, TN = BN / 64, WR = BM / 2, WC = BN / 2, CPRW = WC / 8, RPP = 64 / CPRW;
+    const GemmArgs& a = p.a;
+    const int kl = lane >> 5, ml = lane & 31;
+    float* S = reinterpret_cast<float*>(lds) + wave * (WR * WC);
+    __syncthreads();                                   // every wave is done reading the tile ring (and all DMAs have landed)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                S[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl) * WC + j * 32 + ml] = acc[i][j][r];
+    __syncthreads();
+    const int rsub = lane / CPRW, cc = (lane - rsub * CPRW) * 8;
+    const int col = n0 + wn * WC + cc;
+    const bool vec = (col + 8 <= a.N);
+    float bcol[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bcol[e] = (a.bias && col + e < a.N) ? a.bias[col + e] : 0.f;
+    const T* __restrict__ rowbias = static_cast<const T*>(a.rowbias);
+    const long ldrb = a.ld_rowbias ? a.ld_rowbias : a.N;
+    if (p.splitk > 1) {
+        float* W = p.ws + ((long)split * a.batch + z) * (long)a.M * a.N;
+        const bool v4 = vec && (a.N % 4 == 0);
+#pragma unroll
+        for (int ps = 0; ps < WR / RPP; ++ps) {
+            const int rl = ps * RPP + rsub, row = m0 + wm * WR + rl;
+            if (row >= a.M || col >= a.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(S + rl * WC + cc), v1 = *reinterpret_cast<const float4*>(S + rl * WC + cc + 4);
+            float* w = W + (long)row * a.N + col;
+            if (v4) { *reinterpret_cast<float4*>(w) = v0; *reinterpret_cast<float4*>(w + 4) = v1; }
+            else {
+                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                for (int e = 0; e < 8 && col + e < a.N; ++e) w[e] = v[e];
+            }
+        }
+        return;
+    }
+    T* __restrict__ Cp = static_cast<T*>(a.C) + zb * a.sCb + zh * a.sCh;
+    const T* __restrict__ Rp = a.R ? static_cast<const T*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+#pragma unroll
+    for (int ps = 0; ps < WR / RPP; ++ps) {
+        const int rl = ps * RPP + rsub, row = m0 + wm * WR + rl;
+        if (row >= a.M || col >= a.N) continue;
+        const float4 v0 = *reinterpret_cast<const float4*>(S + rl * WC + cc), v1 = *reinterpret_cast<const float4*>(S + rl * WC + cc + 4);
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = a.alpha * v[e] + bcol[e];
+        T* c = Cp + (long)row * a.ldc + col;
+        const T* rb = rowbias ? rowbias + (long)(row / a.rows_per_img) * ldrb + col : nullptr;
+        const T* rr = Rp ? Rp + (long)row * a.ldr + col : nullptr;
+        if (vec && al16(c) && (!rb || al16(rb)) && (!rr || al16(rr))) {
+            float t[8];
+            if (rb) { ld8(rb, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+            if (rr) { ld8(rr, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+            if (a.beta != 0.f) { ld8(c, t);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
+            st8(c, v);
+        } else {
+            for (int e = 0; e < 8 && col + e < a.N; ++e) {
+                float x = v[e];
+                if (rb) x += (float)rb[e];
+                if (rr) x += (float)rr[e];
+                if (a.beta != 0.f) x += a.beta * (float)c[e];
+                c[e] = (T)x;
+            }
+        }
+    }
+}
+
+// Pipeline: a ring of STAGES tile buffers with STAGES-1 tiles in flight. The LDS-DMA round trip (issue -> landed) is ~1.1 us on
+// MI355X (MI355X_MICROARCH.md, ldsdma-fill) while the MFMAs of one 128x128 k-tile take 0.21 us (bf16, 64 k) or 1.9 us (fp32, 32 k:
+// the fp32 kernel hides the whole round trip behind one tile's MFMAs with two stages). Every iteration issues exactly
+// one tile (past the end of K the lanes are out of range and the DMA writes zeros into a slot nobody reads), so the number of
+// outstanding DMA instructions is constant and "tile t has landed" is the counted wait vmcnt((STAGES-2) * loads per tile)
+// followed by a raw s_barrier (a __syncthreads() would drain the whole queue with vmcnt(0)).
+template <typename T, int BM, int BN, int AK, int RB, int STAGES>
+__device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
+    constexpr int ESZ = El<T>::ESZ;
+    using G = GGeo<RB, ESZ>;
+    using Frag = typename El<T>::Frag;
+    constexpr int TM = BM / 64, TN = BN / 64, NA = BM * G::CPR / 256, NB = BN * G::CPR / 256, BKT = G::BK;
+    const GemmArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int split = blockIdx.y, z = blockIdx.z;
+    const int zb = z / a.nh, zh = z - zb * a.nh;
+    const T* __restrict__ Ap = static_cast<const T*>(a.A) + zb * a.sAb + zh * a.sAh;
+    const T* __restrict__ Bp = static_cast<const T*>(a.B) + zb * a.sBb + zh * a.sBh;
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(a.K, kbeg + p.k_per_split);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    GRows<BM, RB, ESZ> ra; GRows<BN, RB, ESZ> rb; GConvFast<BM, RB, ESZ> cf; GConvGen<BM, RB, ESZ> cg;
+    int tap_u = 0, ci_u = 0;
+    if constexpr (AK == AK_ROW) ra.init(a.lda, m0, a.M, tid);
+    else if constexpr (AK == AK_CONVF) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
+    else cg.init(a.g, m0, a.M, kbeg, tid);
+    rb.init(a.ldb, n0, a.N, tid);
+    // per-slot k offset of the fetched chunk (loop invariant): the K tail test is one compare per slot
+    int kca[NA], kcb[NB];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) kca[i] = G::chunk(tid + i * 256) * G::EPC;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) kcb[i] = G::chunk(tid + i * 256) * G::EPC;
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    constexpr int A_BUF = BM * RB, B_BUF = BN * RB;
+    char* const As = lds;
+    char* const Bs = lds + STAGES * A_BUF;
+    // this wave's LDS-DMA destination of slot i: chunks (i*256 + 64*wave) .. +63 of the tile image
+    const int wbase = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
+
+    auto issue = [&](int k0, int buf) {
+        int oa[NA], ob[NB];
+        if constexpr (AK == AK_ROW) {
+#pragma unroll
+            for (int i = 0; i < NA; ++i) oa[i] = (ra.off[i] != OOB && k0 + kca[i] < kend) ? ra.off[i] + k0 * ESZ : OOB;
+        } else if constexpr (AK == AK_CONVF) {
+            const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0, kx = tap_u - ky * a.g.ks;
+            const int delta = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
+            const bool in_k = k0 < kend;                       // C % BK == 0 and K = taps * C: a tile is entirely inside or outside K
+#pragma unroll
+            for (int i = 0; i < NA; ++i) oa[i] = (in_k && ((cf.vmask[i] >> tap_u) & 1u)) ? cf.base[i] + delta : OOB;
+            ci_u += BKT;
+            if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
+        } else cg.offs(oa, a.g, k0, kend, tid);
+#pragma unroll
+        for (int i = 0; i < NB; ++i) ob[i] = (rb.off[i] != OOB && k0 + kcb[i] < kend) ? rb.off[i] + k0 * ESZ : OOB;
+        char* ad = As + buf * A_BUF + wbase;
+        char* bd = Bs + buf * B_BUF + wbase;
+#pragma unroll
+        for (int i = 0; i < NA; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * 4096), 16, oa[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(bd + i * 4096), 16, ob[i], 0, 0, 0);
+    };
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s) issue(kbeg + s * BKT, s);          // prologue: STAGES-1 tiles in flight
+
+    int cur = 0, nxt = STAGES - 1;
+    const int kl = lane >> 5, ml = lane & 31;
+    const int sw = G::swz(ml);                                     // sub-tile bases are multiples of 32: swz(row) == swz(ml)
+    for (int k0 = kbeg; k0 < kend; k0 += BKT) {
+        // tile k0 has landed for this wave (all but the newest STAGES-2 tiles are complete) ... and for every wave after the barrier,
+        // which also says that everybody is done reading the slot that is refilled next (it was read in the previous iteration)
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(k0 + (STAGES - 1) * BKT, nxt);
+        const char* arow = As + cur * A_BUF + (wm * (BM / 2) + ml) * RB;
+        const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * RB;
+#pragma unroll
+        for (int s = 0; s < G::CPR / 2; ++s) {                     // one 16-byte chunk per half-wave: 16 bf16 / 8 fp32 of k per step
+            const int co = ((2 * s + kl) ^ sw) * 16;
+            Frag av[TM], bv[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) av[i] = *reinterpret_cast<const Frag*>(arow + i * 32 * RB + co);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) bv[j] = *reinterpret_cast<const Frag*>(brow + j * 32 * RB + co);
+            if constexpr (ESZ == 2) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[i], bv[j], acc[i][j], 0, 0, 0);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[i][e], bv[j][e], acc[i][j], 0, 0, 0);
+            }
+        }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill tiles issued past the end of K
+    gemm_glds_epilogue<T, BM, BN>(p, acc, lds, m0, n0, wm, wn, lane, wave, split, z, zb, zh);
+}
+
+template <typename T, int BM, int BN, int AK, int RB, int STAGES>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const KArgs p) {
+    constexpr int RING = STAGES * (BM + BN) * RB, CTILE = BM * BN * 4;        // the epilogue parks the fp32 output tile in the ring
+    __shared__ __attribute__((aligned(16))) char lds[RING > CTILE ? RING : CTILE];
+    gemm_glds_body<T, BM, BN, AK, RB, STAGES>(p, lds);
+}
+
+// ---------------------------------------------------------------- host side
+// Variant selection (experiments): CB_BF16_GEMM = regs | 128x2 | 128x3 | 64x2 | 64x3  (row bytes x ring stages; default 128x2)
+struct GVariant { bool glds; int rb, stages; };
+static const GVariant& gvariant() {
+    static const GVariant v = [] {
+        GVariant g{true, 128, 2};
+        if (const char* e = getenv("CB_BF16_GEMM")) {
+            std::string s(e);
+            if (s == "regs") g = {false, 64, 2};
+            else { int rb = 0, st = 0; if (sscanf(e, "%dx%d", &rb, &st) == 2 && (rb == 64 || rb == 128) && st >= 2 && st <= 3) g = {true, rb, st}; }
+        }
+        return g;
+    }();
+    return v;
+}
+static int bf16_bk() { return gvariant().glds ? gvariant().rb / 2 : BKE; }
+template <typename T, int AK, int RB, int ST>
+static void launch_glds(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 128, AK, RB, ST>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 64, AK, RB, ST>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 64, 128, AK, RB, ST>), grid, dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL((gemm_glds_kernel<T, 64, 64, AK, RB, ST>), grid, dim3(256), 0, s, ka);
+}
+template <int AK>
+static void launch_tiles_bf16(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    const GVariant& v = gvariant();
+    if (v.glds) {
+        if (v.rb == 128 && v.stages == 2) launch_glds<bf16_t, AK, 128, 2>(pl, grid, s, ka);
+        else if (v.rb == 128 && v.stages == 3) launch_glds<bf16_t, AK, 128, 3>(pl, grid, s, ka);
+        else if (v.rb == 64 && v.stages == 3) launch_glds<bf16_t, AK, 64, 3>(pl, grid, s, ka);
+        else launch_glds<bf16_t, AK, 64, 2>(pl, grid, s, ka);
+        return;
+    }
+    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, AK>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, AK>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_bf16_kernel<64, 128, AK>), grid, dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, AK>), grid, dim3(256), 0, s, ka);
+}
+
+// ---------------------------------------------------------------- fp32 through the LDS-DMA kernel
+// Eligible: both operands k-contiguous (ROW / CONV x ROW: activations or conv gathers against [out][in] weights), every row a whole
+// number of 16-byte chunks (K, lda, ldb, conv C multiples of 4), operand slices below 2 GiB. Everything else — m-contiguous
+// operands (Linear input gradients, attention P.V), the 3-channel image conv, misaligned op-level pointers — stays on the
+// register-staged kernel of cb_gemm.hip. CB_F32_GLDS=0 switches it off (A/B measurements); CB_F32_GLDS=64x3 selects 64-byte rows.
+static int f32_glds_mode() {
+    static const int m = [] {
+        const char* e = getenv("CB_F32_GLDS");
+        if (!e) return 1;
+        if (!strcmp(e, "0")) return 0;
+        if (!strcmp(e, "64x3")) return 2;
+        return 1;
+    }();
+    return m;
+}
+static int f32_glds_bk() { return f32_glds_mode() == 2 ? 16 : 32; }
+bool gemm_f32_glds_shape_ok(const GemmArgs& a) {
+    if (!f32_glds_mode() || a.dt != DT_F32 || a.b_kind != LD_ROW) return false;
+    if (a.K % 4 || a.ldb % 4 || a.sBb % 4 || a.sBh % 4) return false;
+    const long lim = ((1L << 31) - 64) / 4;
+    if ((long)a.N * a.ldb >= lim) return false;
+    if (a.a_kind == LD_CONV) {
+        const ConvGeom& g = a.g;
+        if (g.C % 4 || (g.ks != 1 && g.ks != 3) || a.K != g.ks * g.ks * g.C) return false;
+        return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C < lim;
+    }
+    if (a.a_kind != LD_ROW || a.lda % 4 || a.sAb % 4 || a.sAh % 4) return false;
+    return (long)a.M * a.lda < lim;
+}
+static double f32_glds_speed() {
+    static const double s = [] { const char* e = getenv("CB_PLAN_F32G_SPEED"); return e && atof(e) > 0 ? atof(e) : 1.25; }();
+    return s;
+}
+size_t gemm_f32_glds_ws_bytes(const GemmArgs& a) {
+    Plan pl = make_plan(a, f32_glds_bk(), f32_glds_speed());
+    return pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+}
+template <int AK>
+static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if (f32_glds_mode() == 2) launch_glds<float, AK, 64, 3>(pl, grid, s, ka);
+    else launch_glds<float, AK, 128, 2>(pl, grid, s, ka);
+}
+// returns false (nothing launched, nothing counted) when the problem is not eligible
+bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
+    if (!gemm_f32_glds_shape_ok(a)) return false;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    if (!L.dry && !(aligned16(a.A) && aligned16(a.B))) return false;
+    if (a.a_kind == LD_CONV) {
+        CB_CHECK(a.M % (a.g.Ho * a.g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, a.g.Ho * a.g.Wo);
+        CB_CHECK(!(a.g.up && a.g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
+    }
+    const int bk = f32_glds_bk();
+    Plan pl = make_plan(a, bk, f32_glds_speed());
+    if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
+    L.count(pl.splitk > 1 ? 2 : 1);
+    if (pl.splitk > 1) {
+        size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+        CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
+    }
+    if (L.dry) return true;
+    KArgs ka;
+    ka.a = a;
+    ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
+    ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
+    ProfRec rec; bool prof = L.prof && L.prof->on;
+    if (prof) {
+        rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+        double ea_ = a.a_kind == LD_CONV ? (double)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (double)a.M * a.K * a.batch;
+        double eb_ = (double)a.N * a.K * (a.sBb || a.sBh ? a.batch : 1);
+        rec.bytes = 4.0 * (ea_ + eb_ + (double)a.M * a.N * a.batch);
+        CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
+        CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
+    if (a.a_kind == LD_ROW) launch_tiles_f32<AK_ROW>(pl, grid, L.stream, ka);
+    else if (convf) launch_tiles_f32<AK_CONVF>(pl, grid, L.stream, ka);
+    else launch_tiles_f32<AK_CONV>(pl, grid, L.stream, ka);
+    CB_HIP(hipGetLastError());
+    if (prof) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "gemm_glds_kernel<float,%d,%d,%s>", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        rec.variant = L.prof->id_of(nm);
+        CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
+    }
+    if (pl.splitk > 1) {
+        long total = (long)a.M * a.N * a.batch;
+        unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+        ProfRec r2;
+        if (prof) {
+            r2.variant = L.prof->id_of("splitk_reduce_kernel");
+            r2.flops = 0;
+            r2.bytes = 4.0 * total * (pl.splitk + 1 + (a.R ? 1 : 0) + (a.beta != 0.f ? 1 : 0));
+            CB_HIP(hipEventCreate(&r2.e0)); CB_HIP(hipEventCreate(&r2.e1));
+            CB_HIP(hipEventRecord(r2.e0, L.stream));
+        }
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3(nb), dim3(256), 0, L.stream, ka);
+        CB_HIP(hipGetLastError());
+        if (prof) { CB_HIP(hipEventRecord(r2.e1, L.stream)); L.prof->recs.push_back(r2); }
+    }
+    return true;
+}
+
+size_t gemm_bf16_ws_bytes(const GemmArgs& a) {
+    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed);
+    if (pl.splitk <= 1) return 0;
+    return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+}
+
+void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
+    CB_CHECK(a.dt == DT_BF16, CB_ERR_ARG, "gemm_bf16: the bf16 kernel was handed an fp32 problem");
+    CB_CHECK(a.M > 0 && a.N > 0 && a.K > 0, CB_ERR_SHAPE, "gemm: bad shape M=%d N=%d K=%d", a.M, a.N, a.K);
+    CB_CHECK(a.batch >= 1 && a.nh >= 1 && a.batch % a.nh == 0, CB_ERR_SHAPE, "gemm: bad batch %d/%d", a.batch, a.nh);
+    CB_CHECK(a.beta == 0.f || a.beta == 1.f, CB_ERR_ARG, "gemm: beta must be 0 or 1");
+    CB_CHECK(a.b_kind == LD_ROW && (a.a_kind == LD_ROW || a.a_kind == LD_CONV), CB_ERR_ARG,
+             "gemm_bf16: operands must be k-contiguous (ROW / CONV x ROW), got kinds %d/%d", a.a_kind, a.b_kind);
+    CB_CHECK(a.K % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: K=%d must be a multiple of 8 (16-byte chunks)", a.K);
+    if (a.a_kind == LD_CONV) {
+        const ConvGeom& g = a.g;
+        CB_CHECK(g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
+        CB_CHECK(a.K == g.ks * g.ks * g.C, CB_ERR_SHAPE, "conv: K=%d != %d*%d*%d", a.K, g.ks, g.ks, g.C);
+        CB_CHECK(g.C % 8 == 0, CB_ERR_SHAPE, "conv bf16: C=%d must be a multiple of 8 (pad the channel axis)", g.C);
+        CB_CHECK(a.M % (g.Ho * g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, g.Ho * g.Wo);
+        CB_CHECK(!(g.up && g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
+    } else {
+        CB_CHECK(a.lda % 8 == 0 && a.sAb % 8 == 0 && a.sAh % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: A strides must be multiples of 8 elements");
+    }
+    CB_CHECK(a.ldb % 8 == 0 && a.sBb % 8 == 0 && a.sBh % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: B strides must be multiples of 8 elements");
+    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed);
+    if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
+    L.count(pl.splitk > 1 ? 2 : 1);
+    if (pl.splitk > 1) {
+        size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+        CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
+    }
+    if (L.dry) return;
+    auto aligned16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    CB_CHECK(aligned16(a.A) && aligned16(a.B), CB_ERR_ARG, "gemm_bf16: operands must be 16-byte aligned");
+    {   // 32-bit byte offsets inside one operand slice (buffer loads)
+        const long lim = (1L << 31) - 64;
+        long ea = a.a_kind == LD_CONV ? (long)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (long)a.M * a.lda;
+        long eb = (long)a.N * a.ldb;
+        CB_CHECK(ea * 2 < lim && eb * 2 < lim, CB_ERR_SHAPE, "gemm_bf16: an operand slice exceeds 2 GiB");
+    }
+    KArgs ka;
+    ka.a = a;
+    ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
+    ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bf16_bk() == 0);
+    ProfRec rec; bool prof = L.prof && L.prof->on;
+    if (prof) {
+        rec.flops = 2.0 * a.M * a.N * (double)a.K * a.batch;
+        double ea_ = a.a_kind == LD_CONV ? (double)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (double)a.M * a.K * a.batch;
+        double eb_ = (double)a.N * a.K * (a.sBb || a.sBh ? a.batch : 1);
+        rec.bytes = 2.0 * (ea_ + eb_ + (double)a.M * a.N * a.batch);
+        CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1));
+        CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
+    if (a.a_kind == LD_ROW) launch_tiles_bf16<AK_ROW>(pl, grid, L.stream, ka);
+    else if (convf) launch_tiles_bf16<AK_CONVF>(pl, grid, L.stream, ka);
+    else launch_tiles_bf16<AK_CONV>(pl, grid, L.stream, ka);
+    CB_HIP(hipGetLastError());
+    if (prof) {
+        char nm[96];
+        snprintf(nm, sizeof nm, "gemm_%skernel<%s%d,%d,%s>", gvariant().glds ? "glds_" : "bf16_", gvariant().glds ? "bf16," : "", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        rec.variant = L.prof->id_of(nm);
+        CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
+    }
+    if (pl.splitk > 1) {
+        long total = (long)a.M * a.N * a.batch;
+        unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
+        ProfRec r2;
+        if (prof) {
+            r2.variant = L.prof->id_of("splitk_reduce_kernel<bf16>");
+            r2.flops = 0;
+            r2.bytes = 4.0 * total * pl.splitk + 2.0 * total * (1 + (a.R ? 1 : 0) + (a.beta != 0.f ? 1 : 0));
+            CB_HIP(hipEventCreate(&r2.e0)); CB_HIP(hipEventCreate(&r2.e1));
+            CB_HIP(hipEventRecord(r2.e0, L.stream));
+        }
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3(nb), dim3(256), 0, L.stream, ka);
+        CB_HIP(hipGetLastError());
+        if (prof) { CB_HIP(hipEventRecord(r2.e1, L.stream)); L.prof->recs.push_back(r2); }
+    }
+}
+
+}  // namespace cb

@@ -1,4 +1,4 @@
-// cb_gemm_tiles.h — pieces shared by the fp32 (cb_gemm.hip) and bf16 (cb_gemm_bf16.hip) MFMA GEMM / implicit-GEMM kernels:
+// cb_gemm_tiles.h — pieces shared by the fp32 (cb_gemm.hip) and bf16 (cb_gemm_glds.hip) MFMA GEMM / implicit-GEMM kernels:
 // kernel arguments, the branch-free 16-byte buffer loaders for k-contiguous operands, the swizzled LDS store, the XCD-aware
 // block -> tile remap, the split-K reduce and the tile / split planner. Everything is templated on the element size ESZ
 // (bytes): a 16-byte chunk holds EPC = 16 / ESZ elements of k and a k-tile is 4 chunks per row (64 bytes), so the thread ->
@@ -213,6 +213,9 @@ inline const PlanKnobs& plan_knobs() {
     }();
     return k;
 }
+// diagnostics (tools/tune_gemm.py): restrict the planner to one tile shape / split count; 0 = free. Not thread safe, not for production.
+struct PlanForce { int BM = 0, BN = 0, split = 0; };
+inline PlanForce& plan_force() { static PlanForce f; return f; }
 // bke = elements of k per tile (16 for fp32, 32 for bf16); speed = MFMA rate relative to the fp32 kernel
 inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
@@ -227,11 +230,14 @@ inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
     Plan pl{128, 128, 1, 1, 1, ksteps * bke};
     for (int t = 0; t < 4; ++t) {
         const int BM = tiles[t][0], BN = tiles[t][1];
-        if (BM == 128 && a.M <= 64) continue;
-        if (BN == 128 && a.N <= 64) continue;
+        const PlanForce& pf = plan_force();
+        if (pf.BM && (pf.BM != BM || pf.BN != BN)) continue;
+        if (!pf.BM && BM == 128 && a.M <= 64) continue;
+        if (!pf.BM && BN == 128 && a.N <= 64) continue;
         const long tm = cdiv(a.M, BM), tn = cdiv(a.N, BN);
         for (int sp : splits) {
-            if (sp > 1 && ksteps / sp < kn.mink) break;      // keep >= mink k-tiles per split
+            if (pf.split && sp != pf.split) continue;
+            if (!pf.split && sp > 1 && ksteps / sp < kn.mink) break;      // keep >= mink k-tiles per split
             int kps = cdiv(ksteps, sp) * bke;
             int split = cdiv(a.K, kps);
             double blocks = (double)tm * tn * a.batch * split;

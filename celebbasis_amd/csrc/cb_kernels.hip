@@ -1384,6 +1384,41 @@ void k_ema_update(const Launch& L, float* id_emb, float* id_coef, const float* z
            m);
 }
 
+// use_rm_mlp (meta_net.py:173-175, 272-273): x = self.coef[id_idx] with id_idx = torch.flatten(id_multi) (meta_net.py:338-340), i.e.
+// row r of the face-chunk-major batch (r = f*B + b) takes the r-th entry of the ROW-MAJOR [B][nface] id table, ids[r / nface][r % nface]
+// — the reference's own pairing (it equals ids[b][f] for B == 1 and whenever all rows carry one identity).
+__global__ void coef_gather_kernel(float* __restrict__ out, const float* __restrict__ coef, const int64_t* __restrict__ ids,
+                                   int ids_stride, int B, int nface, int D, int max_ids) {
+    long total = (long)nface * B * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % D);
+        int r = (int)(i / D);
+        int64_t id = ids[(long)(r / nface) * ids_stride + (r % nface)];
+        out[i] = (id >= 0 && id < max_ids) ? coef[id * D + c] : 0.f;
+    }
+}
+void k_coef_gather(const Launch& L, float* out, const float* coef, const int64_t* ids, int ids_stride, int B, int nface, int D, int max_ids) {
+    LAUNCH(coef_gather_kernel, grid1d((long)nface * B * D), dim3(256), L, out, coef, ids, ids_stride, B, nface, D, max_ids);
+}
+// dense gradient of the gather (what autograd's index backward produces): one thread per (identity, column) sums its rows in a
+// fixed order — deterministic, identities absent from the batch get an explicit zero
+__global__ void coef_scatter_grad_kernel(float* __restrict__ g, const float* __restrict__ dout, const int64_t* __restrict__ ids,
+                                         int ids_stride, int B, int nface, int D, int max_ids) {
+    long total = (long)max_ids * D;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int c = (int)(i % D);
+        int64_t id = i / D;
+        float acc = 0.f;
+        for (int r = 0; r < nface * B; ++r)
+            if (ids[(long)(r / nface) * ids_stride + (r % nface)] == id) acc += dout[(long)r * D + c];
+        g[i] = acc;
+    }
+}
+void k_coef_scatter_grad(const Launch& L, float* gcoef, const float* dout, const int64_t* ids, int ids_stride, int B, int nface, int D,
+                         int max_ids) {
+    LAUNCH(coef_scatter_grad_kernel, grid1d((long)max_ids * D), dim3(256), L, gcoef, dout, ids, ids_stride, B, nface, D, max_ids);
+}
+
 // dW[o][i] = sum_r dpre[r][o] * v[r][i] ; db[o] = sum_r dpre[r][o]   (EqualLinear wgrad, meta_net.py:41-48)
 __global__ void outer_grad_kernel(float* __restrict__ dW, float* __restrict__ db, const float* __restrict__ dpre,
                                   const float* __restrict__ v, int R, int O, int I) {

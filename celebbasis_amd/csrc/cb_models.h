@@ -106,6 +106,9 @@ struct TrainerCfg {
     float linear_start = 0.00085f, linear_end = 0.012f; int timesteps = 1000;
     int64_t placeholder_token = 48136;   // 'sks' (modules.py:198-262)
     float adam_b1 = 0.9f, adam_b2 = 0.999f, adam_eps = 1e-8f, weight_decay = 1e-2f;
+    // meta_net.py:173-175, 272-273 (ablation switch `use_rm_mlp`): the (max_ids, es, 1, inner) coefficients are the trainable
+    // parameter themselves — x = coef[id_idx], no FR-net / MLP / L2-norm — "optimise the 1024 coefficients directly"
+    int use_rm_mlp = 0;
 };
 struct Trainer {
     Ctx* ctx = nullptr;
@@ -115,6 +118,7 @@ struct Trainer {
     float* W = nullptr; float* b = nullptr;       // EqualLinear(512 -> es*inner) — the only trainable tensors
     float* mW = nullptr; float* vW = nullptr; float* mb = nullptr; float* vb = nullptr;
     float* gW = nullptr; float* gb = nullptr;
+    float* coef = nullptr; float* mC = nullptr; float* vC = nullptr; float* gC = nullptr;   // use_rm_mlp: [max_ids][es*inner]
     int* step = nullptr;
     float* id_emb = nullptr; float* id_coef = nullptr;   // [max_ids][es*width], [max_ids][es*inner]
     float* sqrt_ac = nullptr; float* sqrt_1mac = nullptr;
@@ -123,14 +127,14 @@ struct Trainer {
     // ---- optional first-stage prefetch (trainer_prefetch): the frozen, gradient-free stages of the NEXT batch (VAE encode ->
     // z0, FR backbone -> features) run on their own stream and arena while the current step's UNet is in flight
     struct Prefetch {
-        hipStream_t stream = nullptr; hipEvent_t ready = nullptr;
+        hipStream_t stream = nullptr; bool own_stream = false; hipEvent_t ready = nullptr;
         Arena arena; size_t need = 0; int planned_B = 0;
         // two result slots: prefetch(n+1) is enqueued before step(n) consumes slot n
         struct Slot { void* z0 = nullptr; float* feat = nullptr; hipEvent_t done = nullptr;
                       const void *image = nullptr, *faces = nullptr, *post_noise = nullptr; int B = 0; bool valid = false; } slot[2];
         int next = 0;
         ~Prefetch() {
-            if (stream) { (void)hipStreamSynchronize(stream); (void)hipStreamDestroy(stream); }
+            if (stream) { (void)hipStreamSynchronize(stream); if (own_stream) (void)hipStreamDestroy(stream); }
             if (ready) (void)hipEventDestroy(ready);
             for (auto& sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
             if (arena.base) (void)hipFree(arena.base);
@@ -152,5 +156,7 @@ void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only);
 // Enqueue the first stage of `next` (image -> z0, faces -> FR features) on the prefetch stream. A following trainer_step on the
 // same buffers consumes the results instead of recomputing them; any other batch recomputes inline. Results are identical.
 void trainer_prefetch(Trainer* T, const Batch& next);
+hipStream_t trainer_prefetch_stream(Trainer* T);      // created on first use; nullptr on a dry context
+void trainer_set_prefetch_stream(Trainer* T, hipStream_t s);   // caller-owned stream instead (before the first prefetch)
 
 }  // namespace cb

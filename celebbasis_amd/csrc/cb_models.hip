@@ -453,6 +453,11 @@ void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     auto zeros = [&](size_t n) { float* p = ctx->pool.allocf(n); k_fill(L, p, (long)n, 0.f); return p; };
     T->mW = zeros((size_t)O * I); T->vW = zeros((size_t)O * I); T->gW = zeros((size_t)O * I);
     T->mb = zeros(O); T->vb = zeros(O); T->gb = zeros(O);
+    if (cfg.use_rm_mlp) {
+        const size_t n = (size_t)cfg.max_ids * O;
+        T->coef = ctx->upload(wt, "embedding_manager.meta_id_net.coef", {cfg.max_ids, cfg.es, 1, cfg.inner_dim});
+        T->mC = zeros(n); T->vC = zeros(n); T->gC = zeros(n);
+    }
     T->step = reinterpret_cast<int*>(zeros(64));
     T->id_emb = wt.has("id_embeddings") ? ctx->upload(wt, "id_embeddings", {cfg.max_ids, cfg.es * w}) : zeros((size_t)cfg.max_ids * cfg.es * w);
     T->id_coef = wt.has("id_coefficients") ? ctx->upload(wt, "id_coefficients", {cfg.max_ids, cfg.es * cfg.inner_dim})
@@ -510,19 +515,20 @@ static void prefetch_impl(Trainer* T, const Batch& bt, Trainer::Prefetch::Slot& 
     Ctx* ctx = T->ctx;
     Graph G(ctx);
     G.L.stream = T->pf.stream;
-    Ten* feat = first_stage_faces(G, T, bt);
+    if (!T->cfg.use_rm_mlp) {
+        Ten* feat = first_stage_faces(G, T, bt);
+        k_axpby(G.L, sl.feat, feat->pf(), feat->numel(), 1.f, 0.f);
+    }
     Ten* z0 = first_stage_latent(G, T, bt);
-    k_axpby(G.L, sl.feat, feat->pf(), feat->numel(), 1.f, 0.f);
     k_axpby(G.L, z0->dt, sl.z0, z0->p, z0->numel(), 1.f, 0.f);
 }
-void trainer_prefetch(Trainer* T, const Batch& bt) {
+hipStream_t trainer_prefetch_stream(Trainer* T) {
     Ctx* ctx = T->ctx;
-    CB_CHECK(bt.B >= 1 && bt.B <= kMaxBatch, CB_ERR_ARG, "trainer: batch %d unsupported (1..%d)", bt.B, kMaxBatch);
     Trainer::Prefetch& pf = T->pf;
     const TrainerCfg& c = T->cfg;
-    if (ctx->dry) return;
-    if (!pf.stream) {
-        CB_HIP(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking));
+    if (ctx->dry) return nullptr;
+    if (!pf.ready) {
+        if (!pf.stream) { CB_HIP(hipStreamCreateWithFlags(&pf.stream, hipStreamNonBlocking)); pf.own_stream = true; }
         CB_HIP(hipEventCreateWithFlags(&pf.ready, hipEventDisableTiming));
         const int lat = c.image_size / (1 << (c.vae.n_mult - 1));
         for (auto& sl : pf.slot) {
@@ -531,6 +537,23 @@ void trainer_prefetch(Trainer* T, const Batch& bt) {
             sl.feat = ctx->pool.allocf((size_t)2 * kMaxBatch * T->fr.feat);
         }
     }
+    return pf.stream;
+}
+
+void trainer_set_prefetch_stream(Trainer* T, hipStream_t s) {
+    Trainer::Prefetch& pf = T->pf;
+    CB_CHECK(s != nullptr, CB_ERR_ARG, "prefetch stream: null");
+    CB_CHECK(!pf.ready, CB_ERR_STATE, "prefetch stream: must be set before the first cb_trainer_prefetch");
+    pf.stream = s; pf.own_stream = false;
+}
+
+void trainer_prefetch(Trainer* T, const Batch& bt) {
+    Ctx* ctx = T->ctx;
+    CB_CHECK(bt.B >= 1 && bt.B <= kMaxBatch, CB_ERR_ARG, "trainer: batch %d unsupported (1..%d)", bt.B, kMaxBatch);
+    Trainer::Prefetch& pf = T->pf;
+    const TrainerCfg& c = T->cfg;
+    if (ctx->dry) return;
+    trainer_prefetch_stream(T);
     Trainer::Prefetch::Slot& sl = pf.slot[pf.next];
     pf.next ^= 1;
     sl.valid = false;
@@ -589,17 +612,24 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         ps->valid = false;                              // consumed; the slot is rewritten no earlier than the prefetch after next
     }
     std::unique_ptr<Phase> ph_id(new Phase(L, "phase:frnet_head"));
-    Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat, false, DT_F32) : first_stage_faces(G, T, bt);
+    const bool rm = c.use_rm_mlp != 0;
     const int I = T->fr.feat, O = es * K;
-    Ten* v = G.make(NF, 1, 1, I, false, DT_F32);
-    k_l2norm_fwd(L, v->pf(), nullptr, feat->pf(), NF, I);
-    Lin head; head.w = T->W; head.b = T->b; head.in = I; head.out = O;
-    Ten* pre = G.linear(v, head);                         // EqualLinear with lr_mul = 1 (meta_net.py:41-48)
-    Ten* act = G.make(NF, 1, 1, O, false, DT_F32);
-    k_leakyrelu_fwd(L, act->pf(), pre->pf(), act->numel(), 0.2f);
+    Ten *v = nullptr, *pre = nullptr;
     Ten* xn = G.make(NF * es, 1, 1, K, false, DT_F32);    // 'b (e h d) -> b e h d', h = 1
     float* cn = ctx->arena.allocf((size_t)NF * es);
-    k_l2norm_fwd(L, xn->pf(), cn, act->pf(), (long)NF * es, K);
+    if (rm) {
+        // meta_net.py:272-273 x = self.coef[id_idx], id_idx = flatten(ids) over the chunk-major rows (forward_multi_faces :338-340)
+        k_coef_gather(L, xn->pf(), T->coef, bt.ids, 2, B, 2, O, c.max_ids);
+    } else {
+        Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat, false, DT_F32) : first_stage_faces(G, T, bt);
+        v = G.make(NF, 1, 1, I, false, DT_F32);
+        k_l2norm_fwd(L, v->pf(), nullptr, feat->pf(), NF, I);
+        Lin head; head.w = T->W; head.b = T->b; head.in = I; head.out = O;
+        pre = G.linear(v, head);                              // EqualLinear with lr_mul = 1 (meta_net.py:41-48)
+        Ten* act = G.make(NF, 1, 1, O, false, DT_F32);
+        k_leakyrelu_fwd(L, act->pf(), pre->pf(), act->numel(), 0.2f);
+        k_l2norm_fwd(L, xn->pf(), cn, act->pf(), (long)NF * es, K);
+    }
     Ten* zz = G.make(NF, es, 1, w, false, DT_F32);
     k_basis_fwd(L, zz->pf(), xn->pf(), T->basis, NF, es, K, w);
     G.tap("coef", xn); G.tap("zz", zz);
@@ -653,6 +683,14 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     k_row_surgery_bwd(L, dzz, static_cast<float*>(emb1->g), map, B, T77, w, es);          // fills the first B samples
     float* dxn = ctx->arena.allocf((size_t)NF * es * K);
     k_basis_bwd(L, dxn, dzz, T->basis, NF, es, K, w);
+    k_step_inc(L, T->step);
+    if (rm) {
+        // d coef[id] = sum of dxn over the rows that gathered it (dense gradient: absent identities get zero, like autograd's
+        // index backward; torch's AdamW then still applies weight decay to those rows)
+        k_coef_scatter_grad(L, T->gC, dxn, bt.ids, 2, B, 2, O, c.max_ids);
+        k_adamw(L, T->coef, T->mC, T->vC, T->gC, (long)c.max_ids * O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
+        return;
+    }
     float* dact = ctx->arena.allocf((size_t)NF * O);
     k_l2norm_bwd(L, dact, xn->pf(), cn, dxn, (long)NF * es, K);
     float* dpre = ctx->arena.allocf((size_t)NF * O);
@@ -660,7 +698,6 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     k_outer_grad(L, T->gW, T->gb, dpre, v->pf(), NF, O, I);
 
     // (8) AdamW on the 525 312 trainable floats (ddpm.py:1442-1454)
-    k_step_inc(L, T->step);
     k_adamw(L, T->W, T->mW, T->vW, T->gW, (long)O * I, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
     k_adamw(L, T->b, T->mb, T->vb, T->gb, (long)O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
 }

@@ -131,7 +131,6 @@ class DDIMSampler(object):
             c_ = self._crossattn(cond).float().contiguous()
             x, pred = unet.ddim_sample(x, c_, uc, seq, a, a_prev, sigma, s1m,
                                        scale=float(unconditional_guidance_scale), noise=noise, want_pred_x0=True)
-            _lib.keep_alive(noise, uc, c_)
             log["x_inter"].append(x); log["pred_x0"].append(pred)
             return x, log
         for i in range(S):

@@ -68,6 +68,9 @@ class LatentDiffusion:
             missing += m4
             if "celeb_embeddings" in sd:
                 self.cond_stage_model.load_celeb_basis(sd["celeb_embeddings"])
+            tk = "cond_stage_model." + self.cond_stage_model.PREFIX + "embeddings.token_embedding.weight"
+            if tk in sd:       # embedding_manager.py:239-253: id_embeddings start at the initializer word's embedding
+                self.embedding_manager.init_id_embeddings(sd[tk])
         if strict and missing:
             raise RuntimeError(f"missing keys: {missing[:5]}…")
         self._trainer = None
@@ -101,9 +104,24 @@ class LatentDiffusion:
         return self.first_stage_model.decode(z, scale_factor=self.scale_factor)
 
     def q_sample(self, x_start, t, noise=None):
-        """ddpm.py:289-292. Inside training_step the forward diffusion runs natively (cb_q_sample, fused into cb_trainer_step); a
-        stand-alone call is only made by DDIMSampler's inpainting-mask blending, which is not part of the CelebBasis flow."""
-        raise NotImplementedError("stand-alone q_sample (inpainting masks) is outside the CelebBasis path")
+        """ddpm.py:289-292: sqrt(ac_t) * x_start + sqrt(1 - ac_t) * noise on NCHW latents, natively (cb_q_sample between two layout
+        changes). Inside training_step the same kernel runs fused in cb_trainer_step; this entry serves stand-alone callers."""
+        dev = x_start.device
+        ctx = context_for(dev)
+        if ctx.dtype != _lib.DTYPE_F32:
+            raise NotImplementedError("stand-alone q_sample runs on an fp32 context (public latents are fp32)")
+        L = _lib.load()
+        B, Cc, H, W = x_start.shape
+        x = x_start.float().contiguous()
+        nz = (torch.randn_like(x) if noise is None else noise.to(dev).float()).contiguous()
+        tt = t.to(dev).to(torch.int64).contiguous()
+        sa, sb = self.sqrt_alphas_cumprod.to(dev).contiguous(), self.sqrt_one_minus_alphas_cumprod.to(dev).contiguous()
+        x_nhwc, xt_nhwc, out = torch.empty(B, H, W, Cc, device=dev), torch.empty(B, H, W, Cc, device=dev), torch.empty_like(x)
+        _lib.check(L.cb_nchw_to_nhwc(ctx.h, _lib.ptr(x), _lib.ptr(x_nhwc), B, Cc, H, W))
+        _lib.check(L.cb_q_sample(ctx.h, _lib.ptr(x_nhwc), _lib.ptr(nz), _lib.ptr(tt, torch.int64), _lib.ptr(sa), _lib.ptr(sb),
+                                 _lib.ptr(xt_nhwc), B, Cc, H * W))
+        _lib.check(L.cb_nhwc_to_nchw(ctx.h, _lib.ptr(xt_nhwc), _lib.ptr(out), B, Cc, H, W))
+        return out
 
     def train(self, mode=True):
         self.training = mode
@@ -122,8 +140,10 @@ class LatentDiffusion:
         sd.update(self.first_stage_model.state_dict("first_stage_model.", only=self.first_stage_model.ENC_KEYS))   # the step never decodes
         sd.update(self.cond_stage_model.state_dict("cond_stage_model."))
         sd.update(em.meta_id_net.id_model.state_dict("embedding_manager.meta_id_net.id_model."))
-        sd["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"] = em.meta_id_net.weight
-        sd["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"] = em.meta_id_net.bias
+        sd["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"] = em.meta_id_net.weight.data
+        sd["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"] = em.meta_id_net.bias.data
+        if em.use_rm_mlp:
+            sd["embedding_manager.meta_id_net.coef"] = em.meta_id_net.coef.data
         if self.cond_stage_model.celeb_embeddings is None:
             raise RuntimeError("the celeb basis is not loaded: cond_stage_model.load_celeb_basis(tensor (es,1+K,768))")
         sd["celeb_embeddings"] = self.cond_stage_model.celeb_embeddings
@@ -146,6 +166,7 @@ class LatentDiffusion:
             cfg.es, cfg.inner_dim, cfg.max_ids, cfg.momentum = em.num_es, em.inner_dim, em.max_ids, em.momentum
             cfg.scale_factor, cfg.linear_start, cfg.linear_end, cfg.timesteps = self.scale_factor, self.linear_start, self.linear_end, self.num_timesteps
             cfg.placeholder_token = em.string_to_token_dict[em.placeholder_strings[0]]
+            cfg.use_rm_mlp = 1 if em.use_rm_mlp else 0
             self._trainer = _lib.Trainer(context_for(device), _lib.WeightTable(self._state_for_trainer()), cfg)
         return self._trainer
 
@@ -187,18 +208,21 @@ class LatentDiffusion:
         assert int(ori["num_ids"].max()) == 1, "training prompts carry one identity (dual_img is never set, face_id.py:612)"
         ids_c, t_c, noise_c = ori["ids"].to(dev).to(torch.int64).contiguous(), t.to(torch.int64).contiguous(), noise.float().contiguous()
         tr.step(image_c, faces_c, ids_c, tokens, t_c, noise_c, post, float(self.learning_rate))
-        # the step is only ENQUEUED here: its input buffers must outlive this call (a freed block can be refilled by the next
-        # host-to-device copy before the queued kernels have read it), so the last few steps' tensors stay referenced
-        self._inflight = (getattr(self, "_inflight", []) + [(image_c, faces_c, ids_c, tokens, t_c, noise_c, post)])[-4:]
+        # the step is only ENQUEUED here; its reads are ordered on this context's stream (the side stream is joined inside the
+        # call), so the temporaries above can be dropped: the caching allocator recycles them in stream order
         self.global_step += 1
-        return tr
+        return tr.loss_tensor(dev)          # ddpm.py:357-370 returns `loss`: a 0-dim device tensor, copied in stream order (no sync)
 
     def last_loss(self):
         return float(self._trainer.get_state("loss")[0])
 
     def configure_optimizers(self):
-        """ddpm.py:1442-1454: AdamW over embedding_manager.trainable_parameters(); here the optimiser is fused in the native step."""
-        return dict(optimizer="AdamW(fused in cb_trainer_step)", lr=self.learning_rate, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+        """ddpm.py:1442-1454: `torch.optim.AdamW(embedding_params, lr=lr)` over embedding_parameters() + trainable_parameters().
+        The object is returned for callers that inspect it (param groups, lr); the update itself is fused into the native step
+        (cb_trainer_step applies the same single-tensor AdamW with torch's defaults), so its .step() has nothing to do — the
+        Parameters carry no .grad, exactly like the frozen FR-net's in the reference."""
+        params = list(self.embedding_manager.embedding_parameters()) + list(self.embedding_manager.trainable_parameters())
+        return torch.optim.AdamW(params, lr=self.learning_rate)
 
     def sync_manager_from_trainer(self):
         em, tr = self.embedding_manager, self._trainer
@@ -209,8 +233,10 @@ class LatentDiffusion:
         emb = tr.get_state("id_embeddings").reshape(em.max_ids, es * em.meta_heads, W)
         em.id_coefficients = [coef[i].clone() for i in range(em.max_ids)]
         em.id_embeddings = [emb[i].clone() for i in range(em.max_ids)]
-        em.meta_id_net.weight = tr.get_state("mlp.weight").reshape(es * K, -1)
-        em.meta_id_net.bias = tr.get_state("mlp.bias")
+        em.meta_id_net.weight.data = tr.get_state("mlp.weight").reshape(es * K, -1)       # same Parameter objects, refreshed
+        em.meta_id_net.bias.data = tr.get_state("mlp.bias")
+        if em.use_rm_mlp:
+            em.meta_id_net.coef.data = tr.get_state("rm.coef").reshape(em.max_ids, es, em.meta_heads, K)
 
     def on_save_checkpoint(self, checkpoint, ckptdir="."):
         """ddpm.py:1519-1528: clear the (frozen) model checkpoint, write embeddings.pt + embeddings_gs-{step}.pt"""

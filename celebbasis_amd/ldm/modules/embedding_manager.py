@@ -15,29 +15,43 @@ KNOWN_TOKENS = {"sks": 48136, "ks": 662, "ata": 4236, "tre": 6033, "face": 1710,
 
 
 class MetaIdNet:
-    """state holder for meta_net.py:103-377: frozen id_model + the trainable EqualLinear (`stylegan_mlp.net.0`)"""
+    """state holder for meta_net.py:103-377: frozen id_model + the trainable EqualLinear (`stylegan_mlp.net.0`), and with
+    `use_rm_mlp` (:173-175) the directly optimised coefficients `coef` (num_ids, es, heads, inner). The trainable tensors are
+    torch.nn.Parameter objects (what `trainable_parameters()` hands to the caller's optimiser in the reference); the fused native
+    step owns the working copies and `LatentDiffusion.sync_manager_from_trainer` refreshes these."""
 
-    def __init__(self, inner_dim=512, num_embeds_per_token=2, heads=1, fr_dim=512, mlp_depth=1, generator=None):
+    def __init__(self, inner_dim=512, num_embeds_per_token=2, heads=1, fr_dim=512, mlp_depth=1, generator=None, use_rm_mlp=False,
+                 num_ids=10):
         assert heads == 1 and mlp_depth == 1, "the shipped configuration (meta_heads 1, meta_mlp_depth 1) is the hot path"
         self.id_model = IResNet((3, 13, 30, 3))
         out = inner_dim * num_embeds_per_token * heads
-        self.weight = torch.randn(out, fr_dim, generator=generator)      # EqualLinear init (meta_net.py:30-32)
-        self.bias = torch.zeros(out)
+        P = torch.nn.Parameter
+        self.weight = P(torch.randn(out, fr_dim, generator=generator))      # EqualLinear init (meta_net.py:30-32)
+        self.bias = P(torch.zeros(out))
+        self.use_rm_mlp = bool(use_rm_mlp)
+        self.coef = P(torch.randn(num_ids, num_embeds_per_token, heads, inner_dim, generator=generator)) if use_rm_mlp else None
+
+    def parameters(self):
+        """the tensors that receive gradients (the frozen id_model's stay None in the reference: meta_net.py:253-264)"""
+        return [self.weight, self.bias] + ([self.coef] if self.coef is not None else [])
 
     def trainable_state_dict(self):
-        return {"stylegan_mlp.net.0.weight": self.weight, "stylegan_mlp.net.0.bias": self.bias}
+        d = {"stylegan_mlp.net.0.weight": self.weight.data, "stylegan_mlp.net.0.bias": self.bias.data}
+        if self.coef is not None:
+            d["coef"] = self.coef.data
+        return d
 
     def load_trainable_state_dict(self, sd):
-        self.weight = sd["stylegan_mlp.net.0.weight"].float().clone()
-        self.bias = sd["stylegan_mlp.net.0.bias"].float().clone()
+        self.weight.data = sd["stylegan_mlp.net.0.weight"].float().clone()
+        self.bias.data = sd["stylegan_mlp.net.0.bias"].float().clone()
+        if self.coef is not None and "coef" in sd:
+            self.coef.data = sd["coef"].float().clone()
 
 
 class EmbeddingManagerId:
     def __init__(self, embedder, placeholder_strings=None, initializer_words=None, max_ids=10, num_embeds_per_token=1,
                  momentum=0.9, meta_mlp_depth=2, loss_type=None, meta_inner_dim=512, meta_heads=1, use_rm_mlp=False,
                  test_mode="coefficient", save_fp16=True, **kwargs):
-        if use_rm_mlp:
-            raise NotImplementedError("use_rm_mlp (ablation switch, meta_net.py:173-175) is not on the default hot path")
         if loss_type not in (None, "none"):
             raise NotImplementedError("only loss_type 'none' (aigc_id.yaml:31) is on the hot path")
         assert test_mode in ("coefficient", "embedding", "image")
@@ -45,6 +59,7 @@ class EmbeddingManagerId:
         self.placeholder_strings = list(placeholder_strings or ["sks"])
         self.max_ids, self.num_es, self.meta_heads = max_ids, num_embeds_per_token, meta_heads
         self.momentum, self.test_mode, self.save_fp16, self.loss_type = momentum, test_mode, save_fp16, loss_type
+        self.use_rm_mlp = bool(use_rm_mlp)
         self.token_dim = embedder.cfg["width"] if hasattr(embedder, "cfg") else 768
         self.inner_dim = meta_inner_dim
         self.training = True
@@ -52,10 +67,21 @@ class EmbeddingManagerId:
         for s in self.placeholder_strings:
             self.string_to_token_dict[s] = self._token_for(s)
         g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
-        self.meta_id_net = MetaIdNet(meta_inner_dim, num_embeds_per_token, meta_heads, mlp_depth=meta_mlp_depth, generator=g)
-        # dictionaries (embedding_manager.py:229-231, 239-253); embeddings start at the initializer word when available
+        self.meta_id_net = MetaIdNet(meta_inner_dim, num_embeds_per_token, meta_heads, mlp_depth=meta_mlp_depth, generator=g,
+                                     use_rm_mlp=use_rm_mlp)
+        # dictionaries (embedding_manager.py:225-253): coefficients start as ONE randn block shared by all slots; embeddings start
+        # at the initializer word's token embedding (repeated es*h times) or at torch.rand when no initializer word is given
         self.id_coefficients = [torch.randn(num_embeds_per_token, meta_heads, meta_inner_dim, generator=g)] * max_ids
-        self.id_embeddings = [torch.zeros(num_embeds_per_token * meta_heads, self.token_dim) for _ in range(max_ids)]
+        self.initializer_words = list(initializer_words or [])
+        rows = num_embeds_per_token * meta_heads
+        if self.initializer_words:
+            # the token table arrives with the checkpoint (the reference's CLIP is pretrained at construction): filled by
+            # init_id_embeddings() as soon as the embedder's weights are loaded; zeros only until then
+            self.id_embeddings = [torch.zeros(rows, self.token_dim) for _ in range(max_ids)]
+            self._id_emb_pending = True
+        else:
+            self.id_embeddings = [torch.rand(rows, self.token_dim, generator=g) for _ in range(max_ids)]
+            self._id_emb_pending = False
         self.celeb_embeddings = None
 
     def _token_for(self, s):
@@ -71,7 +97,21 @@ class EmbeddingManagerId:
         return []
 
     def trainable_parameters(self):
-        return [self.meta_id_net.weight, self.meta_id_net.bias]
+        """embedding_manager.py:432-437: list(self.meta_id_net.parameters()) — torch.nn.Parameter objects"""
+        return list(self.meta_id_net.parameters())
+
+    def init_id_embeddings(self, token_table):
+        """embedding_manager.py:239-253: every id_embeddings[idx] = embedding(initializer_words[0]) repeated (es*h) times.
+        `token_table`: the embedder's token_embedding.weight (vocab, width). No-op once done or after a checkpoint load."""
+        if not self._id_emb_pending:
+            return
+        tok = self._token_for(self.initializer_words[0])
+        if tok is None:
+            raise RuntimeError(f"the BPE id of initializer word '{self.initializer_words[0]}' is unknown offline")
+        row = token_table[tok].detach().float().cpu()
+        rows = self.num_es * self.meta_heads
+        self.id_embeddings = [row.unsqueeze(0).repeat(rows, 1).clone() for _ in range(self.max_ids)]
+        self._id_emb_pending = False
 
     def embedding_neg_loss(self):
         return 0.0
@@ -102,6 +142,7 @@ class EmbeddingManagerId:
             self.id_coefficients = [x.float() for x in ckpt["id_coefficients"]]
         if ckpt.get("id_embeddings") is not None:
             self.id_embeddings = [x.float() for x in ckpt["id_embeddings"]]
+            self._id_emb_pending = False
         if ckpt.get("meta_id_net") is not None:
             self.meta_id_net.load_trainable_state_dict(ckpt["meta_id_net"])
 
@@ -122,7 +163,6 @@ class EmbeddingManagerId:
             d.a_layout, d.b_layout, d.batch = 0, 1, 1
             d.bias = basis[e, 0].data_ptr(); d.alpha, d.beta = 1.0, 0.0
             _lib.check(L.cb_gemm(ctx.h, C.byref(d)))
-        _lib.keep_alive(coef, z, basis)
         return z
 
     def _embedding_from_faces(self, faces, basis, dev):
@@ -137,11 +177,10 @@ class EmbeddingManagerId:
         warped = torch.empty(k * B, S, S, 3, device=dev); small = torch.empty(k * B, fr.in_size, fr.in_size, 3, device=dev)
         _lib.check(L.cb_face_warp_resize(ctx.h, _lib.ptr(f), _lib.ptr(warped), _lib.ptr(small), B, S, k, fr.in_size))
         feat = fr.forward(small)
-        Wm, bm = self.meta_id_net.weight.to(dev).float().contiguous(), self.meta_id_net.bias.to(dev).float().contiguous()
+        Wm, bm = self.meta_id_net.weight.data.to(dev).float().contiguous(), self.meta_id_net.bias.data.to(dev).float().contiguous()
         coef = torch.empty(k * B, es * K, device=dev); z = torch.empty(k * B, es * W, device=dev)
         _lib.check(L.cb_celeb_head_forward(ctx.h, _lib.ptr(feat), _lib.ptr(Wm), _lib.ptr(bm), _lib.ptr(basis), k * B, feat.shape[1], es, K, W,
                                            _lib.ptr(coef), _lib.ptr(z)))
-        _lib.keep_alive(f, warped, small, feat, Wm, bm, coef, z)
         return z.reshape(k, B, es * self.meta_heads, W)
 
     def forward(self, tokenized_text, embedded_text, face_image=None, img_ori=None, celeb_embeddings=None):
@@ -177,11 +216,15 @@ class EmbeddingManagerId:
                 ph[b, k] = tok
                 z[b, k * reps:(k + 1) * reps] = from_faces[k, b] if from_faces is not None else self._predicted_embedding(int(ids[b][k]), basis, dev)
         ph = ph.to(dev)
-        out = torch.empty_like(embedded_text)
+        src = embedded_text.contiguous()
+        out = torch.empty_like(src)
         mp = torch.empty(B * T, dtype=torch.int32, device=dev)
-        _lib.check(L.cb_row_surgery_multi(ctx.h, _lib.ptr(embedded_text.contiguous()), _lib.ptr(z), _lib.ptr(tokenized_text.contiguous(), torch.int64),
+        toks = tokenized_text.contiguous()
+        _lib.check(L.cb_row_surgery_multi(ctx.h, _lib.ptr(src), _lib.ptr(z), _lib.ptr(toks, torch.int64),
                                           _lib.ptr(out), C.c_void_p(mp.data_ptr()), B, T, W, reps, _lib.ptr(ph, torch.int64), nph))
-        _lib.keep_alive(z, ph, mp, basis, embedded_text, tokenized_text)
-        return out
+        # the reference MUTATES embedded_text in place and returns it (embedding_manager.py:347-394); rows shift, so the surgery
+        # itself cannot run in place
+        embedded_text.copy_(out)
+        return embedded_text
 
     __call__ = forward

@@ -133,7 +133,6 @@ class FrozenCLIPEmbedder(FrozenModule):
         if embedding_manager is not None:
             embedded = embedding_manager(tokens, embedded, face_img, image_ori, self.celeb_embeddings)
         embedded = embedded.contiguous()
-        _lib.keep_alive(tokens, embedded)
         return h.forward(embedded, need_grad=bool(kwargs.get("need_grad", False)))
 
     def encode(self, text, **kwargs):

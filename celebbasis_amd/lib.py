@@ -85,7 +85,7 @@ class TrainerCfg(C.Structure):
                 ("momentum", C.c_float), ("scale_factor", C.c_float), ("linear_start", C.c_float), ("linear_end", C.c_float),
                 ("timesteps", C.c_int), ("placeholder_token", C.c_int64),
                 ("adam_b1", C.c_float), ("adam_b2", C.c_float), ("adam_eps", C.c_float), ("weight_decay", C.c_float),
-                ("dtype", C.c_int)]
+                ("dtype", C.c_int), ("use_rm_mlp", C.c_int)]
 
 
 class Batch(C.Structure):
@@ -95,7 +95,7 @@ class Batch(C.Structure):
 
 # every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
-    "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_create_dtype", "cb_ctx_dtype", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
+    "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_create_dtype", "cb_ctx_dtype", "cb_ctx_aux_stream", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
     "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
@@ -104,14 +104,14 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
-    "cb_trainer_prefetch", "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
+    "cb_debug_force_plan", "cb_trainer_prefetch", "cb_trainer_prefetch_stream", "cb_trainer_set_prefetch_stream", "cb_trainer_loss_to", "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
 _P, _I, _L, _F = C.c_void_p, C.c_int, C.c_int64, C.c_float
 _ARGTYPES = {
     "cb_last_error": [], "cb_version": [],
-    "cb_ctx_create": [_I, _P, _P], "cb_ctx_create_dtype": [_I, _P, _I, _P], "cb_ctx_dtype": [_P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
+    "cb_ctx_create": [_I, _P, _P], "cb_ctx_create_dtype": [_I, _P, _I, _P], "cb_ctx_dtype": [_P, _P], "cb_ctx_aux_stream": [_P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
     "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
     "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
     "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
@@ -140,8 +140,8 @@ _ARGTYPES = {
     "cb_clip_backward_embeds": [_P, _P, _P],
     "cb_frnet_create": [_P, _P, C.c_char_p, _P, _I, _I, _P], "cb_frnet_destroy": [_P], "cb_frnet_forward": [_P, _P, _I, _P],
     "cb_trainer_cfg_default": [_P], "cb_trainer_create": [_P, _P, _P, _P], "cb_trainer_destroy": [_P],
-    "cb_trainer_step": [_P, _P, _F], "cb_trainer_prefetch": [_P, _P], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
-    "cb_trainer_set_state": [_P, C.c_char_p, _P, _L],
+    "cb_trainer_step": [_P, _P, _F], "cb_trainer_prefetch": [_P, _P], "cb_trainer_prefetch_stream": [_P, _P], "cb_debug_force_plan": [_I, _I, _I], "cb_trainer_set_prefetch_stream": [_P, _P], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
+    "cb_trainer_set_state": [_P, C.c_char_p, _P, _L], "cb_trainer_loss_to": [_P, _P],
     "cb_row_surgery_multi": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I],
     "cb_celeb_head_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
     "cb_face_augment": [_P, _P, _P, _P, _I, _I], "cb_paste_on_canvas": [_P, _P, _P, _P, _I, _I, _I],
@@ -176,18 +176,6 @@ def load():
 def check(code):
     if code != 0:
         raise CBError(code, load().cb_last_error().decode("utf-8", "replace"))
-
-
-import collections as _collections
-
-_INFLIGHT = _collections.deque(maxlen=512)
-
-
-def keep_alive(*tensors):
-    """Native calls only ENQUEUE work. A temporary that is freed right after the call returns goes back to torch's caching
-    allocator, and a later pageable host-to-device copy may refill that block outside stream order, before the queued kernels
-    have read it. Callers that build temporaries park them here (a bounded ring) instead of synchronising."""
-    _INFLIGHT.append(tensors)
 
 
 def ptr(t, dtype=torch.float32):
@@ -227,6 +215,14 @@ class Context:
 
     def sync(self):
         check(load().cb_ctx_sync(self.h))
+
+    def aux_stream(self):
+        """the library's side stream as a torch stream (for Tensor.record_stream); None on a dry context"""
+        if self.dry:
+            return None
+        p = C.c_void_p()
+        check(load().cb_ctx_aux_stream(self.h, C.byref(p)))
+        return torch.cuda.ExternalStream(p.value, device=torch.device("cuda", self.device)) if p.value else None
 
     def stats(self):
         f = C.c_double(); l = C.c_int64(); a = C.c_int64(); p = C.c_int64()
@@ -446,7 +442,6 @@ class VAEDecoder(_Handle):
         for s0 in range(0, B, per):
             n = min(per, B - s0)
             zc = z[s0:s0 + n].contiguous()
-            keep_alive(zc)
             check(load().cb_vae_decode(self.h, None if dry else ptr(zc), n, h, w, C.c_float(scale_factor),
                                        C.c_int(1 if to01 else 0), None if dry else C.c_void_p(out[s0:s0 + n].data_ptr())))
         return out
@@ -545,6 +540,12 @@ class Trainer(_Handle):
             b.noise, b.post_noise = ptr(noise), ptr(post_noise)
         check(load().cb_trainer_step(self.h, C.byref(b), C.c_float(lr)))
 
+    def loss_tensor(self, device):
+        """the last step's loss as a 0-dim DEVICE tensor, copied in stream order (no host sync)"""
+        out = torch.empty((), dtype=torch.float32, device=device)
+        check(load().cb_trainer_loss_to(self.h, None if self.ctx.dry else ptr(out)))
+        return out
+
     def prefetch(self, image, faces, post_noise):
         """enqueue the first stage (VAE encode, FR backbone) of the NEXT batch so that it overlaps the step enqueued after this
         call; `step` on the same tensors then consumes it (identical results). Order: prefetch(batch[i+1]); step(batch[i])."""
@@ -552,7 +553,15 @@ class Trainer(_Handle):
         b.B = int(image.shape[0])
         if not self.ctx.dry:
             b.image, b.faces, b.post_noise = ptr(image), ptr(faces), ptr(post_noise)
+            if getattr(self, "_pf_stream", None) is None:
+                # the prefetch stream is TORCH's (never destroyed): the one call whose reads of caller memory are not ordered on
+                # the context stream when it returns (celebbasis_hip.h), so the caching allocator is told about the second reader
+                self._pf_stream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device))
+                check(load().cb_trainer_set_prefetch_stream(self.h, C.c_void_p(self._pf_stream.cuda_stream)))
         check(load().cb_trainer_prefetch(self.h, C.byref(b)))
+        if not self.ctx.dry:
+            for t_ in (image, faces, post_noise):
+                t_.record_stream(self._pf_stream)
 
     def unet(self):
         """UNet view sharing the trainer's device weights (sampling after personalisation without a second copy)"""

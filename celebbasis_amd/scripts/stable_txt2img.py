@@ -6,7 +6,8 @@
         --embedding_path logs/<run>/checkpoints/embeddings_gs-800.pt --celeb_basis weights/celeb_basis.pt \\
         --from-file infer_images/example_prompt.txt --eval_id1 0 --ddim_steps 50 --n_samples 8 --scale 10 --outdir outputs/
 
-Flags keep the reference's names and defaults (stable_txt2img.py:60-230); PLMS, the face-image test mode and the evaluation
+Flags keep the reference's names and defaults (stable_txt2img.py:60-230). `test_mode: image` takes the identities from face
+images (--face_img1 / --face_img2: the reference hard-codes its evaluation-dataset paths, :272-299). PLMS and the evaluation
 datasets are outside the CelebBasis hot path. The arithmetic all runs in libcelebbasis_hip.so; this file is orchestration.
 """
 import argparse
@@ -44,6 +45,11 @@ def get_parser():
     p.add_argument("--eval_id1", type=int, default=0)
     p.add_argument("--eval_id2", type=int, default=-1)
     p.add_argument("--img_suffix", type=str, default="")
+    p.add_argument("--face_img1", type=str, default=None, help="`test_mode: image`: face image of the first person (stable_txt2img.py:290-308)")
+    p.add_argument("--face_img2", type=str, default=None, help="face image of the second person (defaults to --face_img1)")
+    p.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                   help="UNet / VAE element type (the reference samples under fp16 autocast, stable_txt2img.py:320-322; bf16 is the MI355X counterpart)")
+    p.add_argument("--allow_offline_tokens", action="store_true", help="hashed stand-in token ids when the CLIP BPE vocabulary is not on disk (synthetic runs only)")
     return p
 
 
@@ -67,12 +73,15 @@ def main(argv=None):
     opt = get_parser().parse_args(argv)
     torch.manual_seed(opt.seed); np.random.seed(opt.seed)
     celebbasis_amd.install_ldm_alias()
+    from celebbasis_amd.ldm.modules import frozen
+    frozen.set_precision(opt.precision)
     cfg = load_config([opt.config])
     model = instantiate_from_config(cfg["model"])
     model.load_state_dict(load_sd_checkpoint(opt.ckpt), strict=False)
     if opt.celeb_basis:
         model.cond_stage_model.load_celeb_basis(torch.load(opt.celeb_basis, map_location="cpu", weights_only=False))
     model.embedding_manager.load(opt.embedding_path)
+    model.cond_stage_model.allow_offline_tokens = bool(opt.allow_offline_tokens)
     model.eval()
     device = model.device
     sampler = DDIMSampler(model)
@@ -83,8 +92,19 @@ def main(argv=None):
     n_rows = opt.n_rows if opt.n_rows > 0 else bs
     prompts_all = [opt.prompt] if not opt.from_file else [l for l in open(opt.from_file).read().splitlines() if l.strip()]
     id2 = opt.eval_id2 if opt.eval_id2 >= 0 else opt.eval_id1
-    image_ori = {"faces": None, "ids": torch.tensor([opt.eval_id1, id2], device=device).unsqueeze(0).repeat(bs, 1),
-                 "num_ids": torch.ones(bs, dtype=torch.long, device=device)}
+    faces = None
+    if model.embedding_manager.test_mode == "image":        # stable_txt2img.py:290-308: the identities come from face images
+        if not opt.face_img1:
+            raise SystemExit("test_mode 'image' needs --face_img1 (and optionally --face_img2)")
+
+        def pil_to_4d(path):                                  # transforms.Resize((512,512)) + ToTensor + Normalize(0.5, 0.5)
+            img = Image.open(path).convert("RGB").resize((opt.W, opt.H), Image.BILINEAR)
+            t = torch.from_numpy(np.asarray(img).copy()).float() / 127.5 - 1.0
+            return t.unsqueeze(0).repeat(bs, 1, 1, 1).to(device)
+        faces = torch.cat([pil_to_4d(opt.face_img1), pil_to_4d(opt.face_img2 or opt.face_img1)], dim=-1)
+    # stable_txt2img.py:310-318: ALWAYS two identities — 'sks' takes ids[:, 0], 'ks' takes ids[:, 1] (= eval_id1 unless --eval_id2)
+    image_ori = {"faces": faces, "ids": torch.tensor([opt.eval_id1, id2], device=device).unsqueeze(0).repeat(bs, 1),
+                 "num_ids": torch.ones(bs, dtype=torch.long, device=device) * 2}
     shape = [opt.C, opt.H // opt.f, opt.W // opt.f]
     start_code = torch.randn([bs] + shape, device=device) if opt.fixed_code else None
     tic = time.time()

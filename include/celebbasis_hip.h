@@ -59,6 +59,10 @@ int cb_version(void);
 int cb_ctx_create(int device, void* hip_stream, cb_ctx** out);                           /* activation dtype f32 */
 int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out);         /* dtype: cb_dtype */
 int cb_ctx_dtype(cb_ctx* ctx, int* dtype);
+/* The library-owned side stream (hipStream_t) on which cb_trainer_step runs the identity branch — it reads the caller's `faces`,
+ * `ids` and `tokens` buffers there, forked from AND JOINED BACK INTO the context stream with events inside the call: when the call
+ * returns every read is ordered before later context-stream work, so no record_stream is needed for it (exposed for profilers). */
+int cb_ctx_aux_stream(cb_ctx* ctx, void** hip_stream);
 int cb_ctx_destroy(cb_ctx* ctx);
 int cb_ctx_sync(cb_ctx* ctx);
 /* accounting since the last reset: sum of 2*M*N*K over GEMM-class launches, kernel launches,
@@ -98,6 +102,9 @@ typedef struct {
     int dtype;                                   /* cb_dtype of A, B, C, R (descriptor-level: independent of the context's) */
 } cb_gemm_desc;
 int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
+/* diagnostics (tools/tune_gemm.py): pin the GEMM planner to one tile shape (64/128 x 64/128) and split-K count for every later
+ * launch of this process; (0, 0, 0) releases it. Process-global, not thread safe — never call it in production code. */
+int cb_debug_force_plan(int BM, int BN, int split);
 
 /* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped. */
 /* the source is the float32 state-dict tensor; the pack is in the context's dtype. bf16 packs pad the contiguous channel axis to a
@@ -239,7 +246,9 @@ typedef struct {
     float momentum, scale_factor, linear_start, linear_end; int timesteps;
     int64_t placeholder_token;
     float adam_b1, adam_b2, adam_eps, weight_decay;
-    int dtype;            /* cb_dtype of the frozen UNet / VAE / CLIP (must equal the context's); head + AdamW are always f32 */
+    int dtype;            /* cb_dtype of the frozen UNet / VAE (must equal the context's); CLIP, head + AdamW are always f32 */
+    int use_rm_mlp;       /* meta_net.py:173-175, 272-273: the (max_ids, es, 1, inner) coefficients are the trainable parameter
+                             (`embedding_manager.meta_id_net.coef` in the weight table); no FR-net / MLP / L2-norm in the step */
 } cb_trainer_cfg;
 int cb_trainer_cfg_default(cb_trainer_cfg* cfg);   /* SD v1-4 + aigc_id.yaml values */
 /* wt must hold: model.diffusion_model.*, first_stage_model.*, cond_stage_model.transformer.text_model.*,
@@ -267,11 +276,26 @@ int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
  * FR backbone -> face features; only image / faces / post_noise / B of `next` are read) on a library-owned stream so that it
  * overlaps the UNet of the step that is enqueued afterwards. A later cb_trainer_step on the same buffers consumes the result
  * (bitwise identical to computing it in the step); any other batch is computed inline as usual. Call order per iteration:
- * cb_trainer_prefetch(batch[i+1]); cb_trainer_step(batch[i]). */
+ * cb_trainer_prefetch(batch[i+1]); cb_trainer_step(batch[i]).
+ * BUFFER LIFETIME: this is the one entry point whose reads of caller memory are NOT ordered on the context stream when it returns —
+ * image / faces / post_noise are read on the prefetch stream until the cb_trainer_step that consumes them has been enqueued (that
+ * step makes the context stream wait for the prefetch). Keep the three buffers alive until then, or tell a stream-ordered
+ * allocator about the second reader (PyTorch: hand the library a torch-owned stream with cb_trainer_set_prefetch_stream before
+ * the first prefetch and tensor.record_stream() the three tensors on it — what celebbasis_amd.lib.Trainer.prefetch does; a
+ * library-owned stream would be destroyed with the trainer while the allocator still holds events on it). Every other entry point
+ * joins its internal side stream into the context stream before it returns, so freeing a buffer in context-stream order after the
+ * call is safe (tools/probes/probe_temporaries.py). */
 int cb_trainer_prefetch(cb_trainer* t, const cb_batch* next);
+int cb_trainer_set_prefetch_stream(cb_trainer* t, void* hip_stream); /* caller-owned hipStream_t; before the first prefetch */
+int cb_trainer_prefetch_stream(cb_trainer* t, void** hip_stream);   /* the stream in use (created on first use); NULL on a dry context */
+
+/* enqueue a copy of the last step's loss (device scalar) into caller-owned DEVICE memory: `training_step` can return the loss as a
+ * 0-dim device tensor without a host synchronisation (ddpm.py:357-370 returns `loss`) */
+int cb_trainer_loss_to(cb_trainer* t, float* loss_dev);
 
 /* state names: "loss"(1) "mlp.weight" "mlp.bias" "mlp.grad_weight" "mlp.grad_bias" "adam.m_weight" "adam.v_weight"
- * "adam.m_bias" "adam.v_bias" "id_embeddings" "id_coefficients" "step"(1, as float) */
+ * "adam.m_bias" "adam.v_bias" "id_embeddings" "id_coefficients" "step"(1, as float);
+ * with use_rm_mlp additionally "rm.coef" "rm.grad_coef" "adam.m_coef" "adam.v_coef" ([max_ids, es*inner]) */
 int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);
 int cb_trainer_set_state(cb_trainer* t, const char* name, const float* host_src, int64_t numel);
 

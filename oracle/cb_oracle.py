@@ -687,14 +687,20 @@ class TrainState:
         self.step = 0
         self.id_emb = W["id_embeddings"].clone() if "id_embeddings" in W else None
         self.id_coef = W["id_coefficients"].clone() if "id_coefficients" in W else None
+        # use_rm_mlp ablation (meta_net.py:173-175): the coefficients themselves are the parameter, (max_ids, es, h=1, inner)
+        self.coef = W["embedding_manager.meta_id_net.coef"].clone() if "embedding_manager.meta_id_net.coef" in W else None
+        if self.coef is not None:
+            self.mc = torch.zeros_like(self.coef); self.vc = torch.zeros_like(self.coef)
 
 
 def train_step(W, st, batch, lr, unet=UNET_SD14, vae=VAE_SD14, clip=CLIP_L14, fr=FR_R100, es=2, inner=512, momentum=0.99,
-               scale=0.18215, placeholder=PLACEHOLDER_SKS, sched=None, return_aux=False):
+               scale=0.18215, placeholder=PLACEHOLDER_SKS, sched=None, return_aux=False, use_rm_mlp=False):
     """One LatentDiffusion.training_step + backward + AdamW.step (SURVEY.md §3.1 hot loop):
     ddpm.py:357-370 -> 921-936 -> 702-759 (VAE encode) -> 599-611 (conditioning with the manager hook,
     embedding_manager.py:279-394) -> 1069-1116 (q_sample, UNet, l2 loss) -> autograd -> AdamW (1442-1454).
-    batch: image [B,S,S,3], faces [B,S,S,6], ids [B,2], tokens [B,77], t [B], noise [B,4,h,w], post_noise [B,4,h,w]."""
+    batch: image [B,S,S,3], faces [B,S,S,6], ids [B,2], tokens [B,77], t [B], noise [B,4,h,w], post_noise [B,4,h,w].
+    use_rm_mlp (meta_net.py:173-175, 272-273): x = coef[id_idx] replaces FR-net + MLP + L2-norm; AdamW runs on the whole
+    (max_ids, es, 1, inner) parameter (rows of identities absent from the batch get a zero gradient, i.e. only weight decay)."""
     sched = sched or make_schedule()
     B = batch["tokens"].shape[0]
     W = dict(W)
@@ -706,10 +712,20 @@ def train_step(W, st, batch, lr, unet=UNET_SD14, vae=VAE_SD14, clip=CLIP_L14, fr
         mom = vae_encode_moments(W, vae, x, "first_stage_model.")
         z0 = vae_sample(mom, batch["post_noise"], scale)
         faces = torch.cat(batch["faces"].chunk(2, -1), 0)                                      # meta_net.py:336-337
-        _, small = face_warp_resize(faces, fr["in_size"])
-        feat = frnet_forward(W, fr, small, "embedding_manager.meta_id_net.id_model.")
-        v = F.normalize(feat, dim=-1, p=2)
-    coef, z = celeb_head(W, v, es, inner)
+        feat = small = None
+        if not use_rm_mlp:
+            _, small = face_warp_resize(faces, fr["in_size"])
+            feat = frnet_forward(W, fr, small, "embedding_manager.meta_id_net.id_model.")
+            v = F.normalize(feat, dim=-1, p=2)
+    if use_rm_mlp:
+        cp = st.coef.clone().requires_grad_(True)
+        idx = torch.flatten(batch["ids"])                                                       # meta_net.py:338-340: flatten(id_multi), row-major
+        x = cp[idx]                                                                             # (2B, es, 1, inner), NOT normalised
+        c_all = W["celeb_embeddings"]
+        z = (torch.einsum("behk,ekc->behc", x, c_all[:, 1:]) + c_all[:, 0][None, :, None, :]).reshape(2 * B, es, -1)
+        coef = x.reshape(2 * B, es, inner)
+    else:
+        coef, z = celeb_head(W, v, es, inner)
     with torch.no_grad():                                                                       # embedding_manager.py:484-489
         for b in range(B):
             i = int(batch["ids"][b, 0])
@@ -724,10 +740,15 @@ def train_step(W, st, batch, lr, unet=UNET_SD14, vae=VAE_SD14, clip=CLIP_L14, fr
     xt = sa * z0 + sb * batch["noise"]                                                          # ddpm.py:289-292
     eps_hat = unet_forward(W, unet, xt, t, cond, "model.diffusion_model.")
     loss = F.mse_loss(batch["noise"], eps_hat, reduction="none").mean([1, 2, 3]).mean()         # ddpm.py:1081-1093 (logvar == 0)
-    gW, gb = torch.autograd.grad(loss, [Wm, bm])
     st.step += 1
-    st.Wm, st.mW, st.vW = adamw_step(st.Wm, gW, st.mW, st.vW, st.step, lr)
-    st.bm, st.mb, st.vb = adamw_step(st.bm, gb, st.mb, st.vb, st.step, lr)
+    if use_rm_mlp:
+        (gc,) = torch.autograd.grad(loss, [cp])
+        st.coef, st.mc, st.vc = adamw_step(st.coef, gc, st.mc, st.vc, st.step, lr)
+        gW, gb = gc, None
+    else:
+        gW, gb = torch.autograd.grad(loss, [Wm, bm])
+        st.Wm, st.mW, st.vW = adamw_step(st.Wm, gW, st.mW, st.vW, st.step, lr)
+        st.bm, st.mb, st.vb = adamw_step(st.bm, gb, st.mb, st.vb, st.step, lr)
     if return_aux:
         return loss.detach(), dict(gW=gW, gb=gb, z0=z0, coef=coef.detach(), z=z.detach(), cond=cond.detach(),
                                    eps_hat=eps_hat.detach(), moments=mom, feat=feat, small=small)

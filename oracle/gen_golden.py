@@ -497,6 +497,171 @@ def gen_clip(manifest):
     return keys_digest(fs)
 
 
+
+STEP_UNET = dict(in_channels=4, out_channels=4, model_channels=32, num_res_blocks=1, channel_mult=(1, 2, 2),
+                 attention_resolutions=(1, 2), num_heads=2, context_dim=768)
+STEP_CLIP = dict(vocab=50000, width=768, layers=1, heads=12, ctx_len=77, mlp=128)
+
+
+def gen_step(manifest):
+    """SURVEY C-8 item 6: K optimiser steps of the COMPOSED training step, run by the reference's own code —
+    LatentDiffusion.forward / get_learned_conditioning / p_losses / apply_model (ddpm.py:926-936, 599-611, 1069-1116, 948-1049),
+    DDPM.register_schedule / q_sample / get_loss (:126-178, 289-307), DiffusionWrapper.forward (:1537-1556) unbound on a stand-in
+    `self`, over the reference UNetModel, Encoder + DiagonalGaussianDistribution (encode_first_stage + get_first_stage_encoding),
+    EmbeddingManagerId + MetaIdNet (training mode) and torch.optim.AdamW exactly as configure_optimizers builds it (:1442-1454).
+    The one piece that is NOT reference code is the CLIP layer stack (the reference wrapper cannot be imported offline, SURVEY
+    C-5): the oracle's restatement, wired at the reference's hook point (token embedding -> manager -> + positions, layers).
+    Two runs: the default MLP path (3 steps) and `use_rm_mlp` (2 steps, incl. the reference's flatten(ids) pairing)."""
+    import ldm.modules.id_embedding.meta_net as meta_net
+    from ldm.modules.id_embedding.iresnet import IResNet, IBasicBlock
+    from ldm.models.diffusion.ddpm import LatentDiffusion, DDPM, DiffusionWrapper
+    from ldm.modules.diffusionmodules.openaimodel import UNetModel
+    from ldm.modules.diffusionmodules.model import Encoder
+    from ldm.modules.distributions.distributions import DiagonalGaussianDistribution
+
+    def load_fr_net(self):
+        self.id_model = IResNet(IBasicBlock, [1, 1, 1, 1]).eval()
+        for p in self.id_model.parameters():
+            p.requires_grad = False
+    meta_net.MetaIdNet.load_fr_net = load_fr_net
+    from ldm.modules.embedding_manager import EmbeddingManagerId
+
+    ucfg, vcfg, ccfg, frcfg = STEP_UNET, MINI_VAE, STEP_CLIP, MINI_FR
+    es, inner, width, scale = 2, 16, 768, 0.18215
+    table = O.formula_table(ccfg["vocab"], width)
+    tok_of = {"sks": 48136, "ks": 662, "face": 1710}
+    lr = 2 * 5e-3                                              # bs * base_lr (main_id_embed.py:778-782)
+    out = dict(unet=ucfg, vae=vcfg, clip=ccfg, fr=frcfg, es=es, inner=inner, lr=lr, scale=scale,
+               seeds=dict(unet=71, vae=72, clip=73, fr=74, basis=75))
+    Wu = O.init_weights(O.unet_param_shapes(ucfg, "model.diffusion_model."), seed=71)
+    Wv = O.init_weights(O.vae_encoder_param_shapes(vcfg, "first_stage_model."), seed=72)
+    Wc = O.init_weights(O.clip_param_shapes(ccfg, "cond_stage_model.transformer.text_model."), seed=73)
+    Wc["cond_stage_model.transformer.text_model.embeddings.token_embedding.weight"] = table
+    Wf = O.init_weights(O.frnet_param_shapes(frcfg, "embedding_manager.meta_id_net.id_model."), seed=74)
+    basis = O.init_weights({"celeb_embeddings": (es, 1 + inner, width)}, seed=75)["celeb_embeddings"]
+
+    unet = UNetModel(image_size=16, in_channels=4, model_channels=ucfg["model_channels"], out_channels=4, num_res_blocks=ucfg["num_res_blocks"],
+                     attention_resolutions=list(ucfg["attention_resolutions"]), channel_mult=list(ucfg["channel_mult"]),
+                     num_heads=ucfg["num_heads"], use_spatial_transformer=True, transformer_depth=1, context_dim=width,
+                     use_checkpoint=True, legacy=False)
+    load_into(unet, Wu, "model.diffusion_model.")
+    enc = Encoder(ch=vcfg["ch"], out_ch=3, ch_mult=vcfg["ch_mult"], num_res_blocks=vcfg["num_res_blocks"], attn_resolutions=[], dropout=0.0,
+                  in_channels=3, resolution=64, z_channels=vcfg["z_channels"], double_z=True).eval()
+    quant = nn.Conv2d(2 * vcfg["z_channels"], 2 * vcfg["z_channels"], 1)
+    load_into(enc, Wv, "first_stage_model.encoder."); load_into(quant, Wv, "first_stage_model.quant_conv.")
+    for m_ in (unet, enc, quant):
+        for p_ in m_.parameters():
+            p_.requires_grad = False                            # ddpm.py:491-500: everything pretrained is frozen
+
+    class Tok:
+        def __call__(self, s, **kw):
+            ids = torch.full((1, 77), 49407, dtype=torch.long); ids[0, 0] = 49406; ids[0, 1] = tok_of[s]
+            return {"input_ids": ids}
+
+    class Emb(nn.Module):
+        def forward(self, ids, **kw):
+            return table[ids]
+
+    def make_manager(use_rm_mlp, max_ids):
+        embedder = types.SimpleNamespace(tokenizer=Tok(), transformer=types.SimpleNamespace(text_model=types.SimpleNamespace(embeddings=Emb())))
+        torch.manual_seed(5)
+        mgr = EmbeddingManagerId(embedder, placeholder_strings=["sks", "ks"], initializer_words=["face", "face"], max_ids=max_ids,
+                                 num_embeds_per_token=es, meta_mlp_depth=1, loss_type="none", meta_inner_dim=inner, meta_heads=1,
+                                 use_rm_mlp=use_rm_mlp, test_mode="coefficient", momentum=0.99, save_fp16=False)
+        load_into(mgr.meta_id_net.id_model, Wf, "embedding_manager.meta_id_net.id_model.")
+        return mgr
+
+    class CondStage:                                             # FrozenCLIPEmbedder.encode with the reference's hook order (modules.py:176-298)
+        def __init__(self):
+            self.celeb_embeddings = basis
+
+        def encode(self, tokens, embedding_manager=None, face_img=None, image_ori=None):
+            embedded = table[tokens].clone()
+            embedded = embedding_manager(tokens, embedded, face_img, image_ori, self.celeb_embeddings)
+            return O.clip_encode(Wc, ccfg, embedded, "cond_stage_model.transformer.text_model.")
+
+    class Stub(nn.Module):                                       # the attributes LatentDiffusion's methods read
+        @property
+        def device(self):
+            return torch.device("cpu")
+
+    def run(use_rm_mlp, K, max_ids, ids_of, tag):
+        mgr = make_manager(use_rm_mlp, max_ids)
+        g = torch.Generator().manual_seed(81 + int(use_rm_mlp))
+        Wm = torch.randn(es * inner, 512, generator=g); bm = 0.1 * torch.randn(es * inner, generator=g)
+        with torch.no_grad():
+            mgr.meta_id_net.stylegan_mlp.net[0].weight.copy_(Wm); mgr.meta_id_net.stylegan_mlp.net[0].bias.copy_(bm)
+        id_coef0 = torch.randn(max_ids, es, 1, inner, generator=g); id_emb0 = torch.randn(max_ids, es, width, generator=g)
+        mgr.id_coefficients = [id_coef0[i].clone() for i in range(max_ids)]
+        mgr.id_embeddings = [id_emb0[i].clone() for i in range(max_ids)]
+        coef0 = None
+        if use_rm_mlp:
+            coef0 = torch.randn(tuple(mgr.meta_id_net.coef.shape), generator=g)
+            with torch.no_grad():
+                mgr.meta_id_net.coef.copy_(coef0)
+        me = Stub()
+        me.parameterization, me.v_posterior, me.loss_type, me.learn_logvar = "eps", 0.0, "l2", False
+        DDPM.register_schedule(me, beta_schedule="linear", timesteps=1000, linear_start=0.00085, linear_end=0.012)
+        me.logvar = torch.full((1000,), 0.0)                    # ddpm.py:110-113 logvar_init = 0
+        me.l_simple_weight, me.original_elbo_weight, me.embedding_reg_weight = 1.0, 0.0, 0.0
+        me.shorten_cond_schedule, me.cond_stage_trainable, me.cond_stage_forward = False, True, None
+        dw = DiffusionWrapper.__new__(DiffusionWrapper); nn.Module.__init__(dw)
+        dw.diffusion_model, dw.conditioning_key = unet, "crossattn"
+        me.model, me.embedding_manager, me.cond_stage_model = dw, mgr, CondStage()
+        for name in ("q_sample", "get_loss"):
+            setattr(me, name, types.MethodType(getattr(DDPM, name), me))
+        for name in ("forward", "p_losses", "apply_model", "get_learned_conditioning"):
+            setattr(me, name, types.MethodType(getattr(LatentDiffusion, name), me))
+        me.train(); mgr.train()
+        # ddpm.py:504-507 flips every returned parameter to requires_grad=True; the frozen FR-net still gets no gradient (no_grad forward)
+        params = mgr.embedding_parameters() + mgr.trainable_parameters()
+        for p_ in params:
+            p_.requires_grad = True
+        opt = torch.optim.AdamW(params, lr=lr)                  # ddpm.py:1454
+        B, S = 2, 64
+        rec = dict(Wm=Wm, bm=bm, id_coef0=id_coef0.reshape(max_ids, -1), id_emb0=id_emb0.reshape(max_ids, -1), coef0=coef0, steps=[])
+        for s_ in range(K):
+            gi = torch.Generator().manual_seed(2000 + 10 * int(use_rm_mlp) + s_)        # images are re-drawn from this seed by the tests
+            image = torch.rand(B, S, S, 3, generator=gi) * 2 - 1; faces = torch.rand(B, S, S, 6, generator=gi) * 2 - 1
+            ids = ids_of(s_)
+            tokens = torch.full((B, 77), 49407, dtype=torch.long); tokens[:, 0] = 49406
+            tokens[0, 1:9] = torch.tensor([320, 1125, 539, 320, 1710, 539, 48136, 2533]); tokens[1, 1:5] = torch.tensor([1125, 48136, 1125, 320])
+            with torch.no_grad():                               # get_input: encode_first_stage + get_first_stage_encoding (ddpm.py:702-759, 590-597)
+                post = DiagonalGaussianDistribution(quant(enc(image.permute(0, 3, 1, 2))))
+                torch.manual_seed(900 + s_)
+                x = scale * post.sample()
+                torch.manual_seed(900 + s_)
+                post_noise = torch.randn(post.mean.shape)
+            torch.manual_seed(1000 + s_)                        # LatentDiffusion.forward draws t, p_losses draws the noise
+            loss, loss_dict = me(x, tokens, face_img=None, image_ori={"faces": faces, "ids": ids, "num_ids": torch.tensor([1, 1])})
+            torch.manual_seed(1000 + s_)
+            t = torch.randint(0, 1000, (B,)).long(); noise = torch.randn_like(x)
+            opt.zero_grad()
+            loss.backward()
+            gmain = (mgr.meta_id_net.coef.grad if use_rm_mlp else mgr.meta_id_net.stylegan_mlp.net[0].weight.grad).detach().clone()
+            assert all(p_.grad is None for p_ in mgr.meta_id_net.id_model.parameters())       # SURVEY §0: FR-net never updated
+            opt.step()
+            mgr.id_coefficients = [c.detach() for c in mgr.id_coefficients]                 # cut the EMA's autograd chain (values unchanged)
+            mgr.id_embeddings = [e.detach() for e in mgr.id_embeddings]
+            rec["steps"].append(dict(image_seed=2000 + 10 * int(use_rm_mlp) + s_, ids=ids, tokens=tokens, t=t, noise=noise, post_noise=post_noise,
+                                     loss=loss.detach().clone(), z0=x, grad=gmain if s_ == 0 else None,
+                                     loss_simple=loss_dict["train/loss_simple"].detach().clone()))
+        rec["W_final"] = mgr.meta_id_net.stylegan_mlp.net[0].weight.detach().clone()
+        rec["b_final"] = mgr.meta_id_net.stylegan_mlp.net[0].bias.detach().clone()
+        rec["coef_final"] = mgr.meta_id_net.coef.detach().clone() if use_rm_mlp else None
+        rec["id_coef_final"] = torch.stack([c.reshape(-1) for c in mgr.id_coefficients])
+        rec["id_emb_final"] = torch.stack([e.reshape(-1) for e in mgr.id_embeddings])
+        out[tag] = rec
+
+    run(False, 3, 3, lambda s_: torch.tensor([[1, 1], [2, 2]]), "mlp")
+    run(True, 2, 10, lambda s_: torch.tensor([[1, 1], [2, 2]]) if s_ == 0 else torch.tensor([[4, 4], [4, 4]]), "rm_mlp")
+    torch.save(out, os.path.join(OUT, "step_mini.pt"))
+    manifest["step_mini.pt"] = ("ldm/models/diffusion/ddpm.py LatentDiffusion.forward:926-936, get_learned_conditioning:599-611, p_losses:1069-1116, "
+                                "apply_model:948-1049, DDPM.register_schedule:126-178, q_sample:289-292, get_loss:294-307, DiffusionWrapper.forward:"
+                                "1537-1556, torch.optim.AdamW as configure_optimizers:1442-1454 — over the reference UNetModel, Encoder, "
+                                "DiagonalGaussianDistribution, EmbeddingManagerId / MetaIdNet (default and use_rm_mlp); CLIP layers = oracle restatement")
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     import transformers  # noqa: F401  (resolve its optional-dependency probes before the torchvision stub exists)
@@ -534,6 +699,8 @@ def main():
         gen_manager(manifest)
     if want("clip"):
         digests["clip_l14_text"] = gen_clip(manifest)
+    if want("step"):
+        gen_step(manifest)
     with open(os.path.join(OUT, "state_dict_digests.json"), "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
     manifest["state_dict_digests.json"] = "sha256 over sorted 'key:shape' lines of the reference modules' float state_dict at SD v1-4 sizes"

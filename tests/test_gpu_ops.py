@@ -39,18 +39,26 @@ def close(name, got, ref, tol):
     assert err <= tol * scale, f"{name}: max abs err {err:.3e} vs ref max {scale:.3e} (rel {err / scale:.3e} > {tol})"
 
 
-_KEEP = []
-
-
 def dv(t):
-    """move to the device and KEEP a reference until the module ends: a temporary passed as a raw pointer would be freed
-    (and its block reused by the caching allocator) before the asynchronous kernel reads it"""
-    t = t.contiguous().to(_dev())
-    _KEEP.append(t)
-    if len(_KEEP) > 64:
-        torch.cuda.synchronize()
-        del _KEEP[:32]
-    return t
+    """device copy on the context's stream. Temporaries may be dropped right after a native call: every entry point orders its
+    reads on the context stream (cb_trainer_prefetch is the exception, handled by record_stream in lib.Trainer.prefetch)"""
+    return t.contiguous().to(_dev())
+
+
+class _Hold(list):
+    """device temporaries whose raw pointer goes straight into a native call: `lib.ptr(dv(x))` alone would drop the tensor before
+    the call is even made (a Python lifetime, not a stream-order question). Cleared by the `cb` fixture's sync at module end."""
+
+    def __call__(self, t, dtype=torch.float32):
+        from celebbasis_amd import lib
+        t = dv(t)
+        self.append(t)
+        if len(self) > 64:
+            del self[:32]
+        return lib.ptr(t, dtype)
+
+
+HOLD = _Hold()
 
 
 def rnd(*shape, seed=0, scale=1.0):
@@ -169,7 +177,7 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
         dx0 = rnd(N, H, W, Cin, seed=7)
         for beta in (0.0, 1.0):
             dx = dx0.clone().to(_dev())
-            lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(dv(nhwc(dy))), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
+            lib.check(L.cb_conv2d_dgrad(ctx.h, HOLD(nhwc(dy)), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
             ctx.sync()
             close(tag + f".dgrad(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
 
@@ -250,6 +258,9 @@ def torch_attention(q, k, v, heads, scale, causal):
     (2, 77, 77, 768, 12, 1, 1),      # CLIP causal
     (1, 300, 300, 512, 1, 0, 1),     # VAE AttnBlock: one head, d=512
     (1, 64, 77, 1280, 8, 0, 0),      # d=160
+    (1, 1024, 1024, 640, 8, 0, 1),   # 32x32 self-attention d=80: key-split forward / dQ (4 ranges) + query-split dK/dV
+    (1, 256, 256, 1280, 8, 0, 1),    # 16x16 self-attention d=160 (32-key tiles): key-split
+    (1, 320, 600, 320, 8, 0, 0),     # key-split with a ragged last range (600 keys = 192 + 192 + 192 + 24), d=40
 ])
 def test_attention(cb, B, Nq, Nk, Cc, heads, causal, fused):
     lib, ctx = cb
@@ -305,7 +316,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     B, Cc, H, W = x0.shape
     x0d = x0.permute(0, 2, 3, 1).contiguous().to(_dev()); xt = torch.empty_like(x0d)
     sa, sb = fx["sqrt_alphas_cumprod"].to(_dev()), fx["sqrt_one_minus_alphas_cumprod"].to(_dev())
-    lib.check(L.cb_q_sample(ctx.h, lib.ptr(x0d), lib.ptr(dv(eps)), lib.ptr(dv(tt), torch.int64), lib.ptr(sa), lib.ptr(sb),
+    lib.check(L.cb_q_sample(ctx.h, lib.ptr(x0d), HOLD(eps), HOLD(tt, torch.int64), lib.ptr(sa), lib.ptr(sb),
                             lib.ptr(xt), B, Cc, H * W))
     close("q_sample", xt.permute(0, 3, 1, 2), fx["q_xt"], 1e-6)
     pred = rnd(B, Cc, H, W, seed=9)
@@ -313,7 +324,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     lref = F.mse_loss(eps, pr, reduction="none").mean([1, 2, 3]).mean()
     (gref,) = torch.autograd.grad(lref, [pr])
     loss = torch.zeros(1, device=_dev()); dp = torch.empty_like(x0d)
-    lib.check(L.cb_mse_loss(ctx.h, lib.ptr(dv(pred.permute(0, 2, 3, 1))), lib.ptr(dv(eps)), lib.ptr(loss),
+    lib.check(L.cb_mse_loss(ctx.h, HOLD(pred.permute(0, 2, 3, 1)), HOLD(eps), lib.ptr(loss),
                             lib.ptr(dp), B, Cc, H * W))
     close("mse.loss", loss, lref.reshape(1), 1e-5)
     close("mse.grad", dp.permute(0, 3, 1, 2), gref, 1e-5)
@@ -323,7 +334,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     cat = torch.cat(faces.chunk(2, -1), 0)
     wref, sref = O.face_warp_resize(cat, 112)
     warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
-    lib.check(L.cb_face_warp_resize(ctx.h, lib.ptr(dv(faces)), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
+    lib.check(L.cb_face_warp_resize(ctx.h, HOLD(faces), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
     close("face.warp", warped.permute(0, 3, 1, 2), wref, 1e-4)   # 4-tap bilinear, different association than ATen
     close("face.resize", small.permute(0, 3, 1, 2), sref, 1e-4)
     # row surgery: bit-exact against the reference golden cases (copies only)
@@ -331,7 +342,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
         toks = case["tokens"][None].contiguous().to(_dev())
         T, Cw = case["embedded"].shape
         o = torch.empty(1, T, Cw, device=_dev()); mp = torch.empty(T, dtype=torch.int32, device=_dev())
-        lib.check(L.cb_row_surgery(ctx.h, lib.ptr(dv(case["embedded"][None])), lib.ptr(dv(case["z"][None])),
+        lib.check(L.cb_row_surgery(ctx.h, HOLD(case["embedded"][None]), HOLD(case["z"][None]),
                                    lib.ptr(toks, torch.int64), lib.ptr(o), C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], case["placeholder"]))
         ctx.sync()
         assert torch.equal(o[0].cpu(), case["out"]), f"row surgery case {i} is not bit-exact"
@@ -343,7 +354,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
         o = torch.empty(1, T, Cw, device=_dev()); mp = torch.empty(T, dtype=torch.int32, device=_dev())
         ph = torch.tensor([case["placeholders"]], dtype=torch.int64, device=_dev())
         zcat = dv(torch.cat(case["z"], dim=0)[None])                       # [1][nph*reps][C]
-        lib.check(L.cb_row_surgery_multi(ctx.h, lib.ptr(dv(case["embedded"][None])), lib.ptr(zcat), lib.ptr(toks, torch.int64), lib.ptr(o),
+        lib.check(L.cb_row_surgery_multi(ctx.h, HOLD(case["embedded"][None]), lib.ptr(zcat), lib.ptr(toks, torch.int64), lib.ptr(o),
                                          C.c_void_p(mp.data_ptr()), 1, T, Cw, case["reps"], lib.ptr(ph, torch.int64), nph))
         ctx.sync()
         assert torch.equal(o[0].cpu(), case["out"]), f"multi-placeholder row surgery case {i} is not bit-exact"
@@ -354,7 +365,7 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     for s in range(1, 6):
         gr = torch.randn(1000, generator=g)
         p, m, v = O.adamw_step(p, gr, m, v, s, 1e-2)
-        lib.check(L.cb_adamw_step(ctx.h, lib.ptr(pd), lib.ptr(md), lib.ptr(vd), lib.ptr(dv(gr)), 1000, C.c_void_p(step.data_ptr()),
+        lib.check(L.cb_adamw_step(ctx.h, lib.ptr(pd), lib.ptr(md), lib.ptr(vd), HOLD(gr), 1000, C.c_void_p(step.data_ptr()),
                                   1e-2, 0.9, 0.999, 1e-8, 1e-2))
     close("adamw.p", pd, p, 1e-5)
     assert int(step.item()) == 5
@@ -386,7 +397,7 @@ def test_feeder_augmentations_vs_oracle(cb):
     b = DeviceAugmenter(ds, _dev()).batch([0, 1, 2])
     ctx.sync()
     assert tuple(b["image"].shape) == (3, 64, 64, 3) and tuple(b["image_ori"]["faces"].shape) == (3, 64, 64, 6)
-    assert b["image_ori"]["ids"].dtype == torch.int64 and b["image_ori"]["ids"].tolist() == [[1, 1], [2, 2], [1, 1]]
+    assert b["image_ori"]["ids"].dtype == torch.int64 and b["image_ori"]["ids"].tolist() == [[0, 0], [1, 1], [0, 0]]
     assert float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0 and torch.isfinite(b["image_ori"]["faces"]).all()
     assert all("sks" in c for c in b["caption"])
 
@@ -403,8 +414,8 @@ def test_celeb_head_forward_vs_oracle(cb):
          "embedding_manager.meta_id_net.stylegan_mlp.net.0.bias": torch.randn(es * K, generator=g) * 0.1,
          "celeb_embeddings": torch.randn(es, 1 + K, Wd, generator=g) * 0.05}
     coef = torch.empty(N, es * K, device=_dev()); z = torch.empty(N, es * Wd, device=_dev())
-    lib.check(L.cb_celeb_head_forward(ctx.h, lib.ptr(dv(feat)), lib.ptr(dv(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"])),
-                                      lib.ptr(dv(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"])), lib.ptr(dv(W["celeb_embeddings"])),
+    lib.check(L.cb_celeb_head_forward(ctx.h, HOLD(feat), HOLD(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"]),
+                                      HOLD(W["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"]), HOLD(W["celeb_embeddings"]),
                                       N, I, es, K, Wd, lib.ptr(coef), lib.ptr(z)))
     ctx.sync()
     cref, zref = O.celeb_head(W, torch.nn.functional.normalize(feat, dim=-1, p=2), es, K)

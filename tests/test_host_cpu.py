@@ -237,6 +237,91 @@ def test_reference_yaml_is_drop_in(tmp_path):
         m._state_for_trainer()
 
 
+def test_b2_method_contracts(tmp_path):
+    """SURVEY.md §8 B2, item by item: the attributes, methods, argument names and return types the reference's callers rely on
+    (main_id_embed.py, ddim.py, stable_txt2img.py, extract_pt.py) exist on the host mirror with the reference's meaning"""
+    import inspect
+    import json
+    import celebbasis_amd
+    celebbasis_amd.install_ldm_alias()
+    from celebbasis_amd.ldm.util import instantiate_from_config
+    cfg = json.load(open(REF_PARAMS))
+    m = instantiate_from_config(cfg["model"])
+    em, cs = m.embedding_manager, m.cond_stage_model
+    # LatentDiffusion: `.learning_rate` set by the caller (main_id_embed.py:779)
+    assert hasattr(m, "learning_rate")
+    m.learning_rate = 2 * 5e-3
+    # training_step(batch, idx) -> loss ; on_save_checkpoint(ckpt) ; get_learned_conditioning(c, face_img=None, image_ori=None)
+    assert list(inspect.signature(m.training_step).parameters)[:2] == ["batch", "batch_idx"]
+    assert "return tr.loss_tensor" in inspect.getsource(type(m).training_step)
+    assert list(inspect.signature(m.on_save_checkpoint).parameters)[0] == "checkpoint"
+    glc = inspect.signature(m.get_learned_conditioning).parameters
+    assert list(glc) == ["c", "face_img", "image_ori"] and glc["face_img"].default is None and glc["image_ori"].default is None
+    assert list(inspect.signature(m.apply_model).parameters)[:3] == ["x_noisy", "t", "cond"]
+    assert list(inspect.signature(m.decode_first_stage).parameters)[0] == "z"
+    assert list(inspect.signature(m.q_sample).parameters) == ["x_start", "t", "noise"]
+    with m.ema_scope():
+        pass
+    # buffers DDIMSampler reads (ddim.py:16, 28-34, 120)
+    for name in ("betas", "alphas_cumprod", "alphas_cumprod_prev"):
+        t = getattr(m, name)
+        assert isinstance(t, torch.Tensor) and t.shape == (1000,) and t.dtype == torch.float32
+    assert m.num_timesteps == 1000 and abs(float(m.alphas_cumprod[0]) - 0.99915) < 1e-6
+    assert isinstance(type(m).device, property)
+    # configure_optimizers() -> torch.optim.AdamW over embedding_parameters() + trainable_parameters(), lr = learning_rate, torch defaults
+    opt = m.configure_optimizers()
+    assert isinstance(opt, torch.optim.AdamW)
+    g = opt.param_groups[0]
+    assert g["lr"] == m.learning_rate and g["betas"] == (0.9, 0.999) and g["eps"] == 1e-8 and g["weight_decay"] == 1e-2
+    assert sum(p.numel() for p in g["params"]) == 525312
+    # cond_stage_model.encode(text, embedding_manager=, face_img=, image_ori=) (ddpm.py:602-603)
+    enc = inspect.signature(cs.forward).parameters
+    assert list(enc)[:4] == ["text", "embedding_manager", "face_img", "image_ori"] and cs.encode.__func__ is not None
+    # embedding manager call signature + small API
+    fw = inspect.signature(em.forward).parameters
+    assert list(fw) == ["tokenized_text", "embedded_text", "face_image", "img_ori", "celeb_embeddings"]
+    assert em.embedding_parameters() == []
+    tp = em.trainable_parameters()
+    assert all(isinstance(p, torch.nn.Parameter) for p in tp) and [tuple(p.shape) for p in tp] == [(1024, 512), (1024,)]
+    assert float(em.embedding_neg_loss()) == 0.0
+    assert isinstance(em.id_coefficients, list) and len(em.id_coefficients) == 10 and tuple(em.id_coefficients[0].shape) == (2, 1, 512)
+    assert isinstance(em.id_embeddings, list) and len(em.id_embeddings) == 10 and tuple(em.id_embeddings[0].shape) == (2, 768)
+    assert em.id_coefficients[0] is em.id_coefficients[9]           # one randn block shared by all slots (embedding_manager.py:229-231)
+    # id_embeddings start at the initializer word once the token table is known (embedding_manager.py:239-253)
+    table = torch.randn(49408, 768)
+    em.init_id_embeddings(table)
+    assert torch.equal(em.id_embeddings[4], table[1710].unsqueeze(0).repeat(2, 1))          # 'face' = 1710
+    em.save(str(tmp_path / "e.pt")); em.load(str(tmp_path / "e.pt"))
+    # the same Parameter objects survive a trainer sync (trainable_parameters() stays valid for the caller's optimiser)
+    w0 = em.meta_id_net.weight
+    em.meta_id_net.load_trainable_state_dict({"stylegan_mlp.net.0.weight": torch.zeros(1024, 512), "stylegan_mlp.net.0.bias": torch.ones(1024)})
+    assert em.meta_id_net.weight is w0 and float(w0.abs().sum()) == 0.0
+    # state-dict key prefixes of SD checkpoints (main_id_embed.py:36, strict=False)
+    sd = {"model.diffusion_model.time_embed.0.bias": torch.zeros(1280), "model_ema.decay": torch.zeros(()),
+          "first_stage_model.quant_conv.bias": torch.zeros(8),
+          "cond_stage_model.transformer.text_model.final_layer_norm.bias": torch.zeros(768)}
+    missing, _ = m.load_state_dict(sd, strict=False)
+    assert "model.diffusion_model.time_embed.0.bias" not in missing and "first_stage_model.quant_conv.bias" not in missing
+    assert "cond_stage_model.transformer.text_model.final_layer_norm.bias" not in missing and len(missing) > 100
+    # use_rm_mlp (meta_net.py:173-175): the coefficients themselves become the trainable parameter
+    cfg["model"]["params"]["personalization_config"]["params"]["use_rm_mlp"] = True
+    em2 = instantiate_from_config(cfg["model"]["params"]["personalization_config"], embedder=cs)
+    assert tuple(em2.trainable_parameters()[-1].shape) == (10, 2, 1, 512)
+
+
+def test_safetensors_checkpoint_loader(tmp_path):
+    """main_id_embed.py:25-44: `.safetensors` and `.ckpt` (with or without the 'state_dict' wrapper) give the same state dict"""
+    from safetensors.torch import save_file
+    from celebbasis_amd.main import load_sd_checkpoint
+    sd = {"model.diffusion_model.out.2.bias": torch.arange(4.0), "first_stage_model.quant_conv.weight": torch.randn(8, 8, 1, 1)}
+    save_file(sd, str(tmp_path / "m.safetensors"))
+    torch.save({"state_dict": sd}, tmp_path / "m.ckpt")
+    torch.save(sd, tmp_path / "bare.ckpt")
+    for name in ("m.safetensors", "m.ckpt", "bare.ckpt"):
+        got = load_sd_checkpoint(str(tmp_path / name))
+        assert set(got) == set(sd) and all(torch.equal(got[k], sd[k]) for k in sd), name
+
+
 def test_identity_sharding_and_gloo_merge(tmp_path):
     from celebbasis_amd import sharding
     assert sharding.identities_for_rank(8, 3, 8) == [3]

@@ -264,3 +264,60 @@ def test_celeb_basis_builder_vs_reference(golden_dir):
     pm = B.build_celeb_basis(table, rows, n_components=8, sign="positive_max")
     lead = pm[:, 1:].gather(2, pm[:, 1:].abs().argmax(dim=2, keepdim=True))
     assert torch.all(lead > 0)
+
+
+def _step_fixture_state(fx, tag):
+    """weights (re-drawn from the recorded seeds) + the run's initial trainable / EMA state, under the oracle's names"""
+    rec, max_ids = fx[tag], fx[tag]["id_coef0"].shape[0]
+    sd = fx["seeds"]
+    W = {}
+    W.update(O.init_weights(O.unet_param_shapes(fx["unet"], "model.diffusion_model."), seed=sd["unet"]))
+    W.update(O.init_weights(O.vae_encoder_param_shapes(fx["vae"], "first_stage_model."), seed=sd["vae"]))
+    W.update(O.init_weights(O.clip_param_shapes(fx["clip"], "cond_stage_model.transformer.text_model."), seed=sd["clip"]))
+    W["cond_stage_model.transformer.text_model.embeddings.token_embedding.weight"] = O.formula_table(fx["clip"]["vocab"], fx["clip"]["width"])
+    W.update(O.init_weights(O.frnet_param_shapes(fx["fr"], "embedding_manager.meta_id_net.id_model."), seed=sd["fr"]))
+    W["celeb_embeddings"] = O.init_weights({"celeb_embeddings": (fx["es"], 1 + fx["inner"], fx["clip"]["width"])}, seed=sd["basis"])["celeb_embeddings"]
+    W["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"] = rec["Wm"].clone()
+    W["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"] = rec["bm"].clone()
+    W["id_coefficients"] = rec["id_coef0"].clone(); W["id_embeddings"] = rec["id_emb0"].clone()
+    if rec["coef0"] is not None:
+        W["embedding_manager.meta_id_net.coef"] = rec["coef0"].clone()
+    return W, rec, max_ids
+
+
+def step_fixture_batch(st):
+    """one replay-stream element of step_mini.pt (the images are re-drawn from the recorded seed)"""
+    gi = torch.Generator().manual_seed(st["image_seed"])
+    image = torch.rand(2, 64, 64, 3, generator=gi) * 2 - 1; faces = torch.rand(2, 64, 64, 6, generator=gi) * 2 - 1
+    return dict(image=image, faces=faces, ids=st["ids"], tokens=st["tokens"], t=st["t"], noise=st["noise"], post_noise=st["post_noise"])
+
+
+def test_composed_training_step_vs_reference_run(golden_dir):
+    """SURVEY C-8 item 6 / the composition of the step is no longer "the oracle's own": oracle.train_step on the replay stream
+    recorded from the REFERENCE's LatentDiffusion.forward / p_losses / q_sample / get_loss + torch.optim.AdamW run
+    (tests/golden/step_mini.pt, oracle/gen_golden.py:gen_step) — per-step loss and latent, first-step gradient, final MLP weights
+    and EMA dictionaries; default MLP path and `use_rm_mlp` (with the reference's flatten(ids) pairing across a batch of two ids)."""
+    fx = _load(golden_dir, "step_mini.pt")
+    for tag, rm in (("mlp", False), ("rm_mlp", True)):
+        W, rec, max_ids = _step_fixture_state(fx, tag)
+        st = O.TrainState(W)
+        for i, s in enumerate(rec["steps"]):
+            loss, aux = O.train_step(W, st, step_fixture_batch(s), fx["lr"], fx["unet"], fx["vae"], fx["clip"], fx["fr"], es=fx["es"],
+                                     inner=fx["inner"], scale=fx["scale"], return_aux=True, use_rm_mlp=rm)
+            assert torch.allclose(aux["z0"], s["z0"], atol=2e-6, rtol=1e-5), (tag, i)
+            assert abs(float(loss) - float(s["loss"])) <= 2e-6 * abs(float(s["loss"])), (tag, i, float(loss), float(s["loss"]))
+            assert abs(float(s["loss"]) - float(s["loss_simple"])) < 1e-7                  # logvar == 0, elbo weight 0, neg loss 0
+            if s["grad"] is not None:
+                g = aux["gW"].reshape(s["grad"].shape)
+                assert torch.allclose(g, s["grad"], atol=2e-6 * float(s["grad"].abs().max()), rtol=1e-4), (tag, i)
+        if rm:
+            assert torch.allclose(st.coef, rec["coef_final"], atol=1e-6, rtol=1e-5)
+        else:
+            # AdamW divides by sqrt(v): an element whose gradient is ~0 turns fp32 round-off into an O(lr) difference, so compare
+            # against the size of the UPDATE: at most 1e-2 of the largest weight change, and all but a handful of elements exact
+            d = (st.Wm - rec["W_final"]).abs()
+            upd = float((rec["W_final"] - rec["Wm"]).abs().max())
+            assert float(d.max()) <= 1e-2 * upd and int((d > 1e-5).sum()) <= d.numel() // 1000, (float(d.max()), upd, int((d > 1e-5).sum()))
+            assert torch.allclose(st.bm, rec["b_final"], atol=1e-6, rtol=1e-5)
+        assert (st.id_coef - rec["id_coef_final"]).norm(dim=1).max().item() <= 1e-6
+        assert torch.allclose(st.id_emb, rec["id_emb_final"], atol=1e-5, rtol=1e-5)

@@ -8,6 +8,7 @@
 #                             -> gpurun_out/<tag>_bench_kernel_stats.csv
 #   pmc <tag> [bench args]    two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains other than the kernel
 #                             trace) + tools/pmc_traffic.py           -> gpurun_out/<tag>_pmc_hbm_traffic.json
+#   pmcsq <tag> <script.py>   three --pmc passes (SQ busy / waits, instruction mix, L2 hit + TA busy) of a fixed workload
 #   py <script> [args]        python <script> …                       -> gpurun_out/<script name>.log
 set -u
 mkdir -p gpurun_out
@@ -44,6 +45,16 @@ case "$what" in
     cd $REPO
     python tools/pmc_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/${tag}_pmc_hbm_traffic.json
     find gpurun_out -name "*.csv" -size +8M -delete ;;
+  pmcsq)     # SQ / LDS / cache counters of a fixed workload script: pmcsq <tag> <script.py>
+    tag=$1; script=$2
+    cd /tmp
+    rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $REPO/gpurun_out/pmcsq_${tag}_a -o p --output-format csv -- python $REPO/$script > $REPO/gpurun_out/pmcsq_${tag}_a.log 2>&1
+    rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_MFMA SQ_WAIT_INST_LDS -d $REPO/gpurun_out/pmcsq_${tag}_b -o p --output-format csv -- python $REPO/$script > $REPO/gpurun_out/pmcsq_${tag}_b.log 2>&1
+    rocprofv3 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TA_TA_BUSY_sum TCC_REQ_sum -d $REPO/gpurun_out/pmcsq_${tag}_c -o p --output-format csv -- python $REPO/$script > $REPO/gpurun_out/pmcsq_${tag}_c.log 2>&1
+    cd $REPO
+    python tools/pmc_summary.py gpurun_out/pmcsq_${tag}_a gpurun_out/pmcsq_${tag}_b gpurun_out/pmcsq_${tag}_c > gpurun_out/pmcsq_${tag}.txt 2>&1
+    find gpurun_out -name "*.csv" -size +8M -delete
+    cat gpurun_out/pmcsq_${tag}.txt ;;
   py)
     script=$1; shift
     python "$script" "$@" > gpurun_out/$(basename "$script" .py).log 2>&1; tail -30 gpurun_out/$(basename "$script" .py).log ;;

@@ -1,0 +1,22 @@
+#!/usr/bin/env python
+"""Per-dispatch means of rocprofv3 --pmc passes: tools/pmc_summary.py <dir> [<dir> …] — prints kernel, grid, counter means"""
+import collections
+import csv
+import glob
+import re
+import sys
+
+acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
+for d in sys.argv[1:]:
+    for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(p)):
+            n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cb::", "").replace("cb::", "")
+            if "gemm" not in n and "flash" not in n:
+                continue
+            key = (n, int(r["Grid_Size"]))
+            a = acc[key][r["Counter_Name"]]
+            a[0] += 1; a[1] += float(r["Counter_Value"])
+for key in sorted(acc):
+    print(f"== {key[0]} grid={key[1]}")
+    for c, (n, s) in sorted(acc[key].items()):
+        print(f"   {c:28s} {s / n:16.1f}   (n={n})")
