@@ -474,30 +474,6 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ y, const 
         st4(y + i * 4, make_float4(o[0], o[1], o[2], o[3]));
     }
 }
-void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta, float* stats, float* ws,
-                     int N, int HW, int C, int G, float eps, int silu) {
-    CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
-    int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
-    float* part = ws;
-    float* chn = ws + (size_t)N * nchunk * G * 2;
-    (void)L.count(3);
-    if (L.dry) return;
-    // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
-    // launch-latency bound and would otherwise drown the achieved-bandwidth figure
-    const double esz = (double)dt_size(dt);
-    const bool big = (double)N * HW * C * esz >= 64e6;
-    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_fwd[>=64MB]" : "groupnorm_silu_fwd[<64MB]")
-                                                                   : (big ? "groupnorm_fwd[>=64MB]" : "groupnorm_fwd[<64MB]"),
-                                                             0.0, 3.0 * N * HW * (double)C * esz, L.stream);
-    long nquads = (long)N * HW * (C / 4);
-    CB_DT_SWITCH(dt, T, {
-        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
-        hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
-        hipLaunchKernelGGL((gn_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
-    });
-    if (prof) L.prof->end(&rec, L.stream);
-    CB_HIP(hipGetLastError());
-}
 
 // backward: t = x_hat*gamma+beta ; dt = dy * silu'(t) (or dy) ; s1 = mean(dt*gamma) ; s2 = mean(dt*gamma*x_hat) (per n,g)
 // dx = rstd * (dt*gamma - s1 - x_hat*s2)
@@ -507,6 +483,145 @@ __device__ __forceinline__ float gn_dt(float xh, float gam, float bet, float dy,
     float s = sigmoidf_(t);
     return dy * s * (1.f + t * (1.f - s));
 }
+// ---- one block per (image, group), two passes over the group's [HW][cpg] slab (second pass from L2): the UNet-sized tensors
+// (the 16x16 and 8x8 levels: <= 48 KB per group) are launch-latency bound in the three-kernel form above, so statistics,
+// the per-channel constants and the normalisation go into ONE launch. Element pairs (cpg is even for every width used:
+// C % 64 == 0) are walked in a fixed thread order and reduced by a fixed shuffle / LDS tree: bitwise reproducible.
+__device__ __forceinline__ float2 ld2(const float* p) { return *reinterpret_cast<const float2*>(p); }
+__device__ __forceinline__ float2 ld2(const bf16_t* p) {
+    const unsigned u = *reinterpret_cast<const unsigned*>(p);
+    return make_float2(__uint_as_float(u << 16), __uint_as_float(u & 0xffff0000u));
+}
+__device__ __forceinline__ void st2(float* p, float2 v) { *reinterpret_cast<float2*>(p) = v; }
+__device__ __forceinline__ void st2(bf16_t* p, float2 v) { *reinterpret_cast<unsigned*>(p) = pack_bf16x2(v.x, v.y); }
+constexpr int GNF_THREADS = 1024;
+// block-wide sums of two values; every thread returns the totals
+__device__ __forceinline__ void gnf_reduce2(double& a, double& b, double* sh) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    __syncthreads();                                    // sh may still be read from a previous call
+    if (lane == 0) { sh[2 * wave] = a; sh[2 * wave + 1] = b; }
+    __syncthreads();
+    a = 0; b = 0;
+#pragma unroll
+    for (int w = 0; w < GNF_THREADS / 64; ++w) { a += sh[2 * w]; b += sh[2 * w + 1]; }
+}
+template <typename T>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_fwd_kernel(T* __restrict__ y, const T* __restrict__ x, const float* __restrict__ gamma,
+                                                                    const float* __restrict__ beta, float* __restrict__ stats,
+                                                                    float* __restrict__ chn, int HW, int C, int G, float eps, int silu) {
+    __shared__ double sh[2 * GNF_THREADS / 64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G, cpg = C / G, P = cpg >> 1;
+    const long base = (long)n * HW * C + g * cpg;
+    const int total = HW * P, ra = GNF_THREADS / P, rb = GNF_THREADS - ra * P;
+    const float shift = ld1(x + base);
+    float sa = 0.f, sb = 0.f;
+    int row = threadIdx.x / P, pp = threadIdx.x - row * P;
+    for (int i = threadIdx.x; i < total; i += GNF_THREADS) {
+        const float2 v = ld2(x + base + (long)row * C + 2 * pp);
+        const float d0 = v.x - shift, d1 = v.y - shift;
+        sa += d0 + d1; sb += d0 * d0 + d1 * d1;
+        row += ra; pp += rb; if (pp >= P) { pp -= P; ++row; }
+    }
+    double a = sa, b = sb;
+    gnf_reduce2(a, b, sh);
+    const double cnt = (double)HW * cpg, mloc = a / cnt;
+    double var = b / cnt - mloc * mloc;
+    if (var < 0) var = 0;
+    const float mean = (float)(mloc + (double)shift), rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) { stats[blockIdx.x * 2] = mean; stats[blockIdx.x * 2 + 1] = rstd; }
+    if (threadIdx.x < cpg) {
+        const int c = g * cpg + threadIdx.x;
+        *reinterpret_cast<float4*>(chn + ((long)n * C + c) * 4) = make_float4(mean, rstd, gamma[c], beta[c]);
+    }
+    row = threadIdx.x / P; pp = threadIdx.x - row * P;
+    for (int i = threadIdx.x; i < total; i += GNF_THREADS) {
+        const long off = base + (long)row * C + 2 * pp;
+        const float2 v = ld2(x + off);
+        const int c = g * cpg + 2 * pp;
+        float t0 = (v.x - mean) * rstd * gamma[c] + beta[c], t1 = (v.y - mean) * rstd * gamma[c + 1] + beta[c + 1];
+        if (silu) { t0 = t0 * sigmoidf_(t0); t1 = t1 * sigmoidf_(t1); }
+        st2(y + off, make_float2(t0, t1));
+        row += ra; pp += rb; if (pp >= P) { pp -= P; ++row; }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(GNF_THREADS) void gn_fused_bwd_kernel(T* __restrict__ dx, const T* __restrict__ x, const T* __restrict__ dy,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ stats, int HW, int C, int G, int silu,
+                                                                    float acc_beta) {
+    __shared__ double sh[2 * GNF_THREADS / 64];
+    const int n = blockIdx.x / G, g = blockIdx.x - n * G, cpg = C / G, P = cpg >> 1;
+    const long base = (long)n * HW * C + g * cpg;
+    const int total = HW * P, ra = GNF_THREADS / P, rb = GNF_THREADS - ra * P;
+    const float mean = stats[blockIdx.x * 2], rstd = stats[blockIdx.x * 2 + 1];
+    float sa = 0.f, sb = 0.f;
+    int row = threadIdx.x / P, pp = threadIdx.x - row * P;
+    for (int i = threadIdx.x; i < total; i += GNF_THREADS) {
+        const long off = base + (long)row * C + 2 * pp;
+        const float2 xv = ld2(x + off), dv = ld2(dy + off);
+        const int c = g * cpg + 2 * pp;
+        const float xh0 = (xv.x - mean) * rstd, xh1 = (xv.y - mean) * rstd;
+        const float d0 = gn_dt(xh0, gamma[c], beta[c], dv.x, silu) * gamma[c], d1 = gn_dt(xh1, gamma[c + 1], beta[c + 1], dv.y, silu) * gamma[c + 1];
+        sa += d0 + d1; sb += d0 * xh0 + d1 * xh1;
+        row += ra; pp += rb; if (pp >= P) { pp -= P; ++row; }
+    }
+    double a = sa, b = sb;
+    gnf_reduce2(a, b, sh);
+    const double cnt = (double)HW * cpg;
+    const float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
+    row = threadIdx.x / P; pp = threadIdx.x - row * P;
+    for (int i = threadIdx.x; i < total; i += GNF_THREADS) {
+        const long off = base + (long)row * C + 2 * pp;
+        const float2 xv = ld2(x + off), dv = ld2(dy + off);
+        const int c = g * cpg + 2 * pp;
+        const float xh0 = (xv.x - mean) * rstd, xh1 = (xv.y - mean) * rstd;
+        const float d0 = gn_dt(xh0, gamma[c], beta[c], dv.x, silu) * gamma[c], d1 = gn_dt(xh1, gamma[c + 1], beta[c + 1], dv.y, silu) * gamma[c + 1];
+        float o0 = rstd * (d0 - s1 - xh0 * s2), o1 = rstd * (d1 - s1 - xh1 * s2);
+        if (acc_beta != 0.f) { const float2 old = ld2(dx + off); o0 += acc_beta * old.x; o1 += acc_beta * old.y; }
+        st2(dx + off, make_float2(o0, o1));
+        row += ra; pp += rb; if (pp >= P) { pp -= P; ++row; }
+    }
+}
+// the fused form pays while a group's slab stays small (one block per group = 32 blocks per image, 40-byte row pieces): measured on
+// the config-2 step, threshold 0 / 16 / 48 / 96 / 192 / 512 KB -> 40.72 / 40.54 / 40.10 / 40.51 / 41.17 / 41.83 ms (profiles/README.md)
+static bool gn_use_fused(int HW, int C, int G, size_t esz) {
+    static const long kb = [] { const char* e = getenv("CB_GN_FUSED_KB"); return e ? atol(e) : 48L; }();
+    const int cpg = C / G;
+    return kb > 0 && cpg % 2 == 0 && cpg / 2 <= GNF_THREADS && (long)HW * cpg * (long)esz <= kb * 1024 && (long)HW * (cpg / 2) < (1L << 31);
+}
+void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const float* gamma, const float* beta, float* stats, float* ws,
+                     int N, int HW, int C, int G, float eps, int silu) {
+    CB_CHECK(C % G == 0 && C % 4 == 0 && C <= GN_MAXQ * 1024 && G <= 256, CB_ERR_SHAPE, "groupnorm: C=%d G=%d unsupported", C, G);
+    int rpb = gn_rows_per_block(N, HW), nchunk = cdiv(HW, rpb);
+    float* part = ws;
+    float* chn = ws + (size_t)N * nchunk * G * 2;
+    const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
+    (void)L.count(fused ? 1 : 3);
+    if (L.dry) return;
+    // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
+    // launch-latency bound and would otherwise drown the achieved-bandwidth figure
+    const double esz = (double)dt_size(dt);
+    const bool big = (double)N * HW * C * esz >= 64e6;
+    ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_fwd[>=64MB]" : "groupnorm_silu_fwd[<64MB]")
+                                                                   : (big ? "groupnorm_fwd[>=64MB]" : "groupnorm_fwd[<64MB]"),
+                                                             0.0, 3.0 * N * HW * (double)C * esz, L.stream);
+    long nquads = (long)N * HW * (C / 4);
+    if (fused) {
+        CB_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((gn_fused_fwd_kernel<T>), dim3(N * G), dim3(GNF_THREADS), 0, L.stream, (T*)y, (const T*)x, gamma, beta, stats, chn, HW, C, G, eps, silu);
+        });
+    } else
+    CB_DT_SWITCH(dt, T, {
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
+        hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
+        hipLaunchKernelGGL((gn_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+    });
+    if (prof) L.prof->end(&rec, L.stream);
+    CB_HIP(hipGetLastError());
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const T* __restrict__ x,
                                                               const T* __restrict__ dy, const float* __restrict__ chn, int HW,
@@ -598,13 +713,23 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
     float* part = ws;
     float* chn = ws + (size_t)N * nchunk * G * 2;
     float* gs = chn + (size_t)N * C * 4;
-    (void)L.count(chn_valid ? 3 : 4);
+    const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
+    (void)L.count(fused ? 1 : (chn_valid ? 3 : 4));
     if (L.dry) return;
     const double esz = (double)dt_size(dt);
     const bool big = (double)N * HW * C * esz >= 64e6;
     ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_bwd[>=64MB]" : "groupnorm_silu_bwd[<64MB]")
                                                                    : (big ? "groupnorm_bwd[>=64MB]" : "groupnorm_bwd[<64MB]"),
                                                              0.0, 5.0 * N * HW * (double)C * esz, L.stream);
+    if (fused) {
+        CB_DT_SWITCH(dt, T, {
+            hipLaunchKernelGGL((gn_fused_bwd_kernel<T>), dim3(N * G), dim3(GNF_THREADS), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, gamma, beta,
+                               stats, HW, C, G, silu, acc_beta);
+        });
+        if (prof) L.prof->end(&rec, L.stream);
+        CB_HIP(hipGetLastError());
+        return;
+    }
     // chn_valid: `ws` is the forward call's workspace and still holds its per-channel constants (the tape's case)
     if (!chn_valid) hipLaunchKernelGGL(gn_expand_kernel, dim3(cdiv((long)N * C, 256)), dim3(256), 0, L.stream, chn, stats, gamma, beta, N, C, G);
     long nquads = (long)N * HW * (C / 4);

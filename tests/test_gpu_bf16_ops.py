@@ -152,7 +152,8 @@ def test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, extra):
 
 
 # ------------------------------------------------------------------------------------------------ norms / GEGLU
-@pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 256, 320, 1, 1e-5), (1, 1024, 64, 0, 1e-6), (4, 64, 1280, 1, 1e-5), (1, 4096, 128, 1, 1e-6)])
+@pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 256, 320, 1, 1e-5), (1, 1024, 64, 0, 1e-6), (4, 64, 1280, 1, 1e-5), (1, 4096, 128, 1, 1e-6),
+                                             (1, 131072, 128, 1, 1e-6)])     # both GroupNorm forms (one launch per group below 48 KB per slab, three chip-wide kernels above)
 def test_groupnorm_bf16(cbf, N, HW, C, silu, eps):
     lib, ctx = cbf
     L = lib.load()

@@ -182,7 +182,12 @@ def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux, per_step=True, drift=N
         dl2 = ((dW_hip - dW_ref).norm() / dW_ref.norm().clamp_min(1e-30)).item()
         REPORT[tag + ".mlp.weight_delta"] = dict(rel_l2=dl2, max_abs_err=(dW_hip - dW_ref).abs().max().item(), ref_max=dW_ref.abs().max().item())
         assert dl2 <= 2e-2, f"{tag}: AdamW weight delta rel L2 {dl2:.3e}"
-    close(tag + ".mlp.weight", tr.get_state("mlp.weight"), st.Wm.reshape(-1), 1e-4 if per_step else 1e-3)
+    if per_step:          # a few steps: an element's update is lr * g / (|g| + eps); where |g| ~ eps the quotient is round-off sensitive
+        werr = (tr.get_state("mlp.weight") - st.Wm.reshape(-1)).abs().max().item()
+        REPORT[tag + ".mlp.weight"] = dict(max_abs_err=werr, lr=lr)
+        assert werr <= 0.2 * lr * steps, f"{tag}.mlp.weight: max abs err {werr:.3e} vs lr {lr:g}"
+    else:
+        close(tag + ".mlp.weight", tr.get_state("mlp.weight"), st.Wm.reshape(-1), 1e-3)
     close(tag + ".mlp.bias", tr.get_state("mlp.bias"), st.bm.reshape(-1), 1e-3 if per_step else 2e-2)
     coef_hip = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)
     l2 = (coef_hip - st.id_coef).norm(dim=1).max().item()
@@ -393,10 +398,11 @@ def test_sampler_sd14_vs_oracle(cb, n):
     Wd = O.init_weights(O.vae_decoder_param_shapes(O.VAE_SD14), seed=8)
     d = lib.VAEDecoder(ctx, lib.WeightTable(Wd), lib.vae_cfg(**O.VAE_SD14))
     torch.set_num_threads(min(64, os.cpu_count() or 1))
+    pick = sorted({0, n // 2, n - 1})            # the oracle decodes a subset (first / middle / last image of the chunked decode)
     with torch.no_grad():
         ref, _ = O.ddim_sample(W, cfg, x_T, c, uc, s, scale=10.0)
-        ref_img = O.decode_first_stage(Wd, O.VAE_SD14, ref, 0.18215)
-    img = d.decode(dv(ref), 0.18215)            # decode the oracle's latent so the two checks are independent
+        ref_img = O.decode_first_stage(Wd, O.VAE_SD14, ref[pick], 0.18215)
+    img = d.decode(dv(ref), 0.18215)[pick]      # decode the oracle's latents (all n) so the two checks are independent
     ctx.sync()
     close(f"sampler_sd14[n={n}].samples", x, ref, 1e-3)
     close(f"sampler_sd14[n={n}].image", img, ref_img, 5e-4)

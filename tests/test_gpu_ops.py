@@ -184,7 +184,8 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
 
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 64, 320, 1, 1e-5), (1, 4096, 320, 1, 1e-5), (2, 100, 64, 0, 1e-6),
-                                             (1, 64, 2560, 1, 1e-5), (1, 5000, 128, 1, 1e-6), (2, 256, 960, 0, 1e-6)])
+                                             (1, 64, 2560, 1, 1e-5), (1, 5000, 128, 1, 1e-6), (2, 256, 960, 0, 1e-6),
+                                             (1, 65536, 128, 1, 1e-6)])     # slabs > 48 KB per group take the chip-wide three-kernel path, smaller ones the one-launch kernel
 def test_groupnorm(cb, N, HW, C, silu, eps):
     lib, ctx = cb
     L = lib.load()
