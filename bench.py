@@ -87,11 +87,12 @@ HBM_GROUP_SYMBOLS = {
 
 
 def rocprof_symbol_ms(bf16=False, prefix="r02"):
-    """per-symbol milliseconds per step of the newest committed rocprofv3 kernel trace of this bench
-    (profiles/<prefix>*_bench_kernel_stats.csv); template instances are split by element type (fp32 step vs config-3 step)"""
+    """per-symbol milliseconds per step of the newest committed rocprofv3 kernel trace: profiles/<prefix>*_bench_kernel_stats.csv is
+    the trace of `bench.py --no-config3` (the fp32 step alone), profiles/<prefix>*_config3_kernel_stats.csv the trace of
+    `bench.py --trace-leg config3` (the bf16 bs=4 step alone; its fp32 CLIP / FR-net kernels included)"""
     import csv
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{prefix}*_bench_kernel_stats.csv")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{prefix}*_{'config3' if bf16 else 'bench'}_kernel_stats.csv")))
     if not files:
         return None, {}
     out = {}
@@ -99,8 +100,6 @@ def rocprof_symbol_ms(bf16=False, prefix="r02"):
         rows = [r for r in f if not r.startswith("#")]
     for r in csv.DictReader(rows):
         base = r["name"].split("<")[0]
-        if ("bf16" in r["name"]) != bf16:
-            continue
         out[base] = out.get(base, 0.0) + float(r["ms_per_step"])
     return os.path.basename(files[-1]), out
 
@@ -202,6 +201,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--trace-leg", choices=["all", "config3"], default="all",
+                    help="diagnostics for rocprofv3 traces (tools/gpurun.sh trace): 'config3' runs ONLY the config-3 leg, so that the trace's "
+                         "per-symbol times are not mixed with the fp32 leg's (the JSON line then carries no config-2 value)")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary, cross-step-pipelined measurement")
     ap.add_argument("--no-config3", action="store_true", help="skip the secondary bf16 bs=4 measurement (BASELINE config 3)")
     ap.add_argument("--cpu-steps", type=int, default=2)
@@ -258,14 +260,15 @@ def main():
         b = batches[i % len(batches)]
         tr.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr)
 
-    elapsed = timed_loop(run, args.steps, args.warmup, world, dist, dev, dry)
-    loss = None if dry else float(tr.get_state("loss")[0])
+    only3 = args.trace_leg == "config3"
+    elapsed = 1.0 if only3 else timed_loop(run, args.steps, args.warmup, world, dist, dev, dry)
+    loss = None if (dry or only3) else float(tr.get_state("loss")[0])
 
     # ---- secondary measurement (rank 0, not the headline `value`): the same K steps with the first stage of batch i+1
     # (VAE encode + FR backbone, no gradients) prefetched on its own stream under the UNet of batch i (cb_trainer_prefetch).
     # Every timed iteration still executes one VAE encode, one FR pass and one full step; results are bitwise identical.
     pipelined = None
-    if rank == 0 and world == 1 and not args.no_pipelined and not dry:      # N == 1 only, like the CPU baseline: keeps the N > 1 runs lean
+    if rank == 0 and world == 1 and not args.no_pipelined and not dry and not only3:      # N == 1 only, like the CPU baseline: keeps the N > 1 runs lean
         def nb(i):
             return batches[i % len(batches)]
         b0 = nb(0)
@@ -295,7 +298,7 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * args.steps / elapsed
-        if dry:
+        if dry or only3:
             roofline, phases, st = None, {}, ctx.stats()
         else:
             roofline, phases, st = profile_step(ctx, run, PEAK_FP32_MFMA_TFLOPS)
@@ -320,6 +323,8 @@ def main():
         }
         if dry:
             out["dry"] = True
+        if only3:
+            out["trace_leg"] = "config3"; out["value"] = None; out["ms_per_step"] = None
     # ---- secondary: BASELINE config 3 (bf16 UNet / VAE + fp32 coefficient gradient, bs=4) on its own context, N == 1 only
     if rank == 0 and world == 1 and not args.no_config3 and not dry:
         B3 = 4
@@ -333,11 +338,12 @@ def main():
             tr3.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr3)
         el3 = timed_loop(run3, args.steps, args.warmup, 1, dist, dev, False)
         rf3, ph3, st3 = profile_step(ctx3, run3, PEAK_BF16_MFMA_TFLOPS, bf16=True)
+        rf3["traffic"], rf3["traffic_detail"] = pmc_traffic(rf3["kernel"])
         ms3 = el3 / args.steps * 1e3
         out["config3"] = {"workload": "BASELINE config 3: single identity, SD v1-4 512x512, bs=4, bf16 UNet / VAE (storage + MFMA), fp32 CLIP / "
                                       "coefficient head / gradient / AdamW, full step", "dtype": "bf16", "batch": B3,
                           "steps_per_s": round(args.steps / el3, 4), "samples_per_s": round(B3 * args.steps / el3, 3), "ms_per_step": round(ms3, 3),
-                          "vs_config2_samples_per_s": round(B3 * args.steps / el3 / out["value"], 3),
+                          "vs_config2_samples_per_s": None if only3 else round(B3 * args.steps / el3 / out["value"], 3),
                           "step_tflop": round(st3["gemm_flops"] / 1e12, 4), "step_tflops_per_gpu": round(st3["gemm_flops"] / 1e12 / (ms3 * 1e-3), 2),
                           "kernel_launches_per_step": st3["launches"], "loss": float(tr3.get_state("loss")[0]), "phase_ms": ph3, "roofline": rf3}
         tr3.close(); ctx3.close()

@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     }
 }
 
+
 // D[bh][q] = sum_d dO[q][d] * O[q][d] : one wave per query row
 __global__ __launch_bounds__(256) void flash_dvec_kernel(const FlashArgs a, int BH) {
     long w = blockIdx.x * 4L + (threadIdx.x >> 6);
@@ -646,6 +647,9 @@ void flash_forward(const Launch& L, const FlashArgs& a, int B) {
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
 #define LDSF(x) lds_fwd(x)
+    // Two experiments that did NOT move this kernel (profiles/README.md, round 2): threading the online softmax by hand through the
+    // next tile's score MFMAs (one MFMA + one softmax slice per fenced step: 260 vs 262 us at N = 4096, d = 40) and doubling /
+    // quadrupling the resident waves with a key split at N = 4096 (252 .. 257 us). The MFMA pipe stays 64 % busy either way.
     FL_DISPATCH(dt, flash_fwd_kernel, grid, LDSF, a)
     if (a.ksplit > 1) {
         long total = (long)BH * a.Nq * (a.d / 4);

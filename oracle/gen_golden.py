@@ -327,6 +327,16 @@ def gen_templates():
     raise RuntimeError("imagenet_templates_small not found")
 
 
+def gen_config_params(manifest):
+    """the PARAMETER VALUES of the reference's personalization config (configs/stable-diffusion/aigc_id.yaml), parsed and re-emitted
+    as canonical JSON: data the drop-in tests instantiate the host mirror from (the reference YAML itself cannot travel)"""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(REF, "configs", "stable-diffusion", "aigc_id.yaml")))
+    with open(os.path.join(OUT, "aigc_id_params.json"), "w") as f:
+        json.dump(cfg, f, separators=(",", ":"), sort_keys=True)
+    manifest["aigc_id_params.json"] = "yaml.safe_load(configs/stable-diffusion/aigc_id.yaml) re-emitted as sorted JSON (target strings + parameter values)"
+
+
 def gen_basis(manifest):
     """the reference's own FrozenCLIPEmbedder._get_celeb_embeddings (modules.py:472-624) run unbound on a stand-in `self`:
     real name list (infer_images/wiki_names_v2.txt) with the real BPE ids the reference recorded (infer_images/token_len.txt),
@@ -693,6 +703,9 @@ def main():
         gen_basis(manifest)
     if want("templates"):
         digests["imagenet_templates_small"] = gen_templates()
+        manifest["state_dict_digests.json:imagenet_templates_small"] = "sha256 + count of ldm/data/face_id.py:17-99 imagenet_templates_small (gen_templates)"
+    if want("config"):
+        gen_config_params(manifest)
     if want("frnet"):
         digests["iresnet100"] = gen_frnet(manifest)
     if want("manager"):

@@ -375,7 +375,8 @@ def test_bench_line_contract_of_committed_profile():
     roofline and cpu_baseline objects, and internally consistent numbers"""
     import glob
     import json
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "BENCH_r01_run*.json")), key=lambda p: int(p.split("run")[-1].split(".")[0]))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "BENCH_r0*_run*.json")),
+                   key=lambda p: (int(p.split("BENCH_r")[-1].split("_")[0]), int(p.split("run")[-1].split(".")[0])))
     full = [json.load(open(p)) for p in files]
     full = [d for d in full if d.get("cpu_baseline")]
     assert full, "no committed bench line with a cpu_baseline"
@@ -392,6 +393,11 @@ def test_bench_line_contract_of_committed_profile():
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and isinstance(c["sample"], str)
     assert d["value"] / c["value"] > 50            # the GPU path is two orders of magnitude above the host baseline
+    if "config3" in d:                             # round 2 lines: the config-3 (bf16, bs=4) secondary and the scaling fields
+        c3 = d["config3"]
+        assert c3["dtype"] == "bf16" and c3["batch"] == 4 and c3["roofline"]["peak"] == 2500.0
+        assert abs(c3["samples_per_s"] - 4e3 / c3["ms_per_step"]) < 0.02 * c3["samples_per_s"]
+        assert d["merged_identities"] == d["n_gpus"] and d["identities_per_sec"] > 0
 
 
 def test_feeder_draws_and_lookahead():

@@ -5,7 +5,8 @@
 #   smoke                     __graft_entry__.smoke()
 #   bench [bench.py args]     python bench.py …                       -> gpurun_out/bench.json
 #   trace <tag> [bench args]  rocprofv3 --kernel-trace of bench.py + per-symbol CSV (tools/prof_stats.py)
-#                             -> gpurun_out/<tag>_bench_kernel_stats.csv
+#                             -> gpurun_out/<tag>_bench_kernel_stats.csv   (pass --no-config3 for the fp32 step alone)
+#   trace3 <tag>              the same for the config-3 (bf16, bs=4) leg alone -> gpurun_out/<tag>_config3_kernel_stats.csv
 #   pmc <tag> [bench args]    two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains other than the kernel
 #                             trace) + tools/pmc_traffic.py           -> gpurun_out/<tag>_pmc_hbm_traffic.json
 #   pmcsq <tag> <script.py>   three --pmc passes (SQ busy / waits, instruction mix, L2 hit + TA busy) of a fixed workload
@@ -35,6 +36,15 @@ case "$what" in
     # every measurement leg of bench.py runs warmup + steps + 1 profiled step of its own kernels
     python tools/prof_stats.py "$db" gpurun_out/${tag}_bench_kernel_stats.csv $((STEPS + 3)) | head -60
     find gpurun_out/trace_$tag -size +8M -delete ;;
+  trace3)    # the config-3 (bf16, bs=4) leg alone -> gpurun_out/<tag>_config3_kernel_stats.csv
+    tag=$1; shift
+    STEPS=6
+    cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/trace3_$tag -o bench -- \
+      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --trace-leg config3 "$@" > $REPO/gpurun_out/trace3_$tag.log 2>&1
+    cd $REPO
+    db=$(find gpurun_out/trace3_$tag -name "*.db" | head -1)
+    python tools/prof_stats.py "$db" gpurun_out/${tag}_config3_kernel_stats.csv $((STEPS + 3)) | head -40
+    find gpurun_out/trace3_$tag -size +8M -delete ;;
   pmc)
     tag=$1; shift
     cd /tmp

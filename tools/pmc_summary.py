@@ -1,5 +1,9 @@
 #!/usr/bin/env python
 """Per-dispatch means of rocprofv3 --pmc passes: tools/pmc_summary.py <dir> [<dir> …] — prints kernel, grid, counter means"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import clean  # noqa: E402
 import collections
 import csv
 import glob
@@ -10,7 +14,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for d in sys.argv[1:]:
     for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(p)):
-            n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cb::", "").replace("cb::", "")
+            n = clean(r["Kernel_Name"])
             if "gemm" not in n and "flash" not in n:
                 continue
             key = (n, int(r["Grid_Size"]))

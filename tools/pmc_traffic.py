@@ -8,6 +8,10 @@ Reads the *_counter_collection.csv of both passes, averages per kernel symbol an
 shape can be singled out. FETCH_SIZE / WRITE_SIZE are reported by rocprofv3 in KiB and stored here as reported (bytes);
 see the "note" field for the gfx950 correction the guide prescribes.
 """
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import clean  # noqa: E402
 import collections
 import csv
 import glob
@@ -22,9 +26,9 @@ def load(d, counter):
         for r in csv.DictReader(open(p)):
             if r["Counter_Name"] != counter:
                 continue
-            n = re.sub(r"\(.*", "", r["Kernel_Name"]).replace("void cb::", "").replace("cb::", "")
+            n = clean(r["Kernel_Name"])
             n = n.replace("(cb::_anonymous_namespace_)::", "")
-            if not ("gemm_kernel" in n or "flash" in n or n.startswith("gn_") or "layernorm" in n or "splitk" in n):
+            if not ("gemm_" in n or "flash" in n or n.startswith("gn_") or "layernorm" in n or "splitk" in n):
                 continue
             key = (n, int(r["Grid_Size"]))
             acc[key][0] += 1

@@ -1,5 +1,9 @@
 #!/usr/bin/env python
 """Aggregate a rocprofv3 (rocpd sqlite) kernel trace into a per-kernel stats CSV: tools/prof_stats.py db out.csv nsteps"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import clean  # noqa: E402
 import re
 import sqlite3
 import sys
@@ -12,7 +16,7 @@ tot = sum(r[2] for r in rows)
 lines = [f"# rocprofv3 --kernel-trace; {nsteps} training steps in the trace; total kernel time {tot:.1f} ms = {tot / nsteps:.2f} ms/step",
          "name,calls,total_ms,ms_per_step,avg_us,min_us,max_us,pct"]
 for r in rows:
-    n = re.sub(r"\(.*", "", r[0]).replace("void cb::", "").replace("cb::", "")
+    n = clean(r[0])
     lines.append(f'"{n}",{r[1]},{r[2]:.3f},{r[2] / nsteps:.3f},{r[3]:.2f},{r[4]:.2f},{r[5]:.2f},{100 * r[2] / tot:.2f}')
 open(out, "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:32]))

@@ -1,6 +1,10 @@
 #!/usr/bin/env python
 """Per-(kernel, grid) view of a rocprofv3 (rocpd sqlite) kernel trace: which SHAPES of a templated kernel the time goes to.
     tools/trace_by_grid.py trace.db nsteps [name substring]"""
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from _names import clean  # noqa: E402
 import re
 import sqlite3
 import sys
@@ -18,7 +22,7 @@ g = f"{gx}" + (f"*{gy}*{gz}" if gy and gz else "")
 rows = c.execute(f"select name, {g} as grid, count(*), sum(end-start)/1e6, avg(end-start)/1e3 from kernels group by name, grid order by 4 desc").fetchall()
 print(f"{'ms/step':>8} {'calls/step':>10} {'avg us':>9} {'blocks':>8}  kernel")
 for name, grid, n, tot, avg in rows[:60]:
-    nm = re.sub(r"\(.*", "", name).replace("void cb::", "").replace("cb::", "")
+    nm = clean(name)
     if sub and sub not in nm:
         continue
     print(f"{tot / nsteps:8.3f} {n / nsteps:10.1f} {avg:9.1f} {int(grid) // 256:8d}  {nm}")
