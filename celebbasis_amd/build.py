@@ -15,7 +15,7 @@ BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcelebbasis_hip.so")
 SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
            "cb_abi.hip"]
-HEADERS = ["cb_common.h", "cb_device.h", "cb_gemm_tiles.h", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
+HEADERS = ["cb_common.h", "cb_device.h", "cb_gemm_tiles.h", "cb_plan_table.inc", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
          "-Wno-unused-lambda-capture", "-Wno-unused-result"]
 # Attention kernels: MFMA results feed VALU (softmax) and the next MFMA's B operand directly, so the accumulators belong in

@@ -603,6 +603,107 @@ static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KAr
     if (f32_glds_mode() == 2) launch_glds<float, AK, 64, 3>(pl, grid, s, ka);
     else launch_glds<float, AK, 128, 2>(pl, grid, s, ka);
 }
+
+// ---------------------------------------------------------------- offline autotuner (CB_AUTOTUNE=<file>)
+// For every distinct problem that reaches the LDS-DMA kernel on a real context, time all (tile, split-K) candidates on the
+// launch's own operands — outputs and partials go to scratch buffers, so the step itself is undisturbed and keeps running the
+// analytic plan (the arena was sized for it) — and append "<plan_key> <BM> <BN> <split> <us> | <analytic BM BN split us>" to the file.
+// tools/make_plan_table.py turns the file into cb_plan_table.inc. Batched (attention) problems are left to the model.
+template <typename T> static void launch_problem(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk);
+struct Tuner { FILE* f = nullptr; std::unordered_map<std::string, int> seen; };
+static Tuner* tuner() {
+    static Tuner* t = [] {
+        const char* p = getenv("CB_AUTOTUNE");
+        if (!p || !*p) return (Tuner*)nullptr;
+        Tuner* t = new Tuner;
+        t->f = fopen(p, "a");
+        return t->f ? t : (Tuner*)nullptr;
+    }();
+    return t;
+}
+template <typename T>
+static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
+    Tuner* t = tuner();
+    if (!t || L.dry || a.batch != 1) return;
+    const std::string key = plan_key(a, bk);
+    if (t->seen.count(key)) return;
+    t->seen[key] = 1;
+    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    const int ksteps = cdiv(a.K, bk);
+    const size_t out_elems = (size_t)a.M * (size_t)std::max<long>(a.ldc, a.N);
+    size_t ws_max = 0;
+    for (int sp : splits) if (sp > 1 && ksteps / sp >= 2) ws_max = std::max(ws_max, (size_t)sp * a.M * a.N * sizeof(float));
+    ws_max = std::min(ws_max, (size_t)1 << 30);
+    void* ctmp = nullptr; void* wtmp = nullptr;
+    CB_HIP(hipDeviceSynchronize());                      // the other streams' work would disturb the timings
+    CB_HIP(hipMalloc(&ctmp, out_elems * sizeof(T)));
+    if (ws_max) CB_HIP(hipMalloc(&wtmp, ws_max));
+    GemmArgs b = a;
+    b.C = ctmp; b.beta = 0.f;
+    hipEvent_t e0, e1;
+    CB_HIP(hipEventCreate(&e0)); CB_HIP(hipEventCreate(&e1));
+    auto time_plan = [&](const Plan& pl) {
+        for (int i = 0; i < 2; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk);
+        CB_HIP(hipEventRecord(e0, L.stream));
+        for (int i = 0; i < 5; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk);
+        CB_HIP(hipEventRecord(e1, L.stream));
+        CB_HIP(hipEventSynchronize(e1));
+        float ms = 0.f; CB_HIP(hipEventElapsedTime(&ms, e0, e1));
+        return (double)ms * 1e3 / 5.0;
+    };
+    const Plan model = make_plan(a, bk, speed);
+    const double t_model = (model.splitk <= 1 || (size_t)model.splitk * a.M * a.N * sizeof(float) <= ws_max) ? time_plan(model) : -1.0;
+    double best = 1e30; Plan bp = model;
+    for (int ti = 0; ti < 4; ++ti) {
+        const int BM = tiles[ti][0], BN = tiles[ti][1];
+        if ((BM == 128 && a.M <= 64) || (BN == 128 && a.N <= 64)) continue;
+        for (int sp : splits) {
+            if (sp > 1 && ksteps / sp < 2) break;
+            if (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > ws_max) break;
+            const long blocks = (long)cdiv(a.M, BM) * cdiv(a.N, BN) * sp;
+            if (sp > 1 && blocks > 8192) break;
+            const int kps = (int)cdiv(ksteps, sp) * bk;
+            Plan pl{BM, BN, (int)cdiv(a.M, BM), (int)cdiv(a.N, BN), (int)cdiv(a.K, kps), kps};
+            const double us = time_plan(pl);
+            if (us < best) { best = us; bp = pl; }
+        }
+    }
+    fprintf(t->f, "%s %d %d %d %.2f | %d %d %d %.2f\n", key.c_str(), bp.BM, bp.BN, bp.splitk, best, model.BM, model.BN, model.splitk, t_model);
+    fflush(t->f);
+    CB_HIP(hipEventDestroy(e0)); CB_HIP(hipEventDestroy(e1));
+    CB_HIP(hipFree(ctmp)); if (wtmp) CB_HIP(hipFree(wtmp));
+}
+
+template <> void launch_problem<bf16_t>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
+    KArgs ka;
+    ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
+    if (a.a_kind == LD_ROW) launch_tiles_bf16<AK_ROW>(pl, grid, s, ka);
+    else if (convf) launch_tiles_bf16<AK_CONVF>(pl, grid, s, ka);
+    else launch_tiles_bf16<AK_CONV>(pl, grid, s, ka);
+    if (pl.splitk > 1) {
+        long total = (long)a.M * a.N * a.batch;
+        hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, ka);
+    }
+}
+template <> void launch_problem<float>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
+    KArgs ka;
+    ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
+    const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
+    if (a.a_kind == LD_ROW) launch_tiles_f32<AK_ROW>(pl, grid, s, ka);
+    else if (convf) launch_tiles_f32<AK_CONVF>(pl, grid, s, ka);
+    else launch_tiles_f32<AK_CONV>(pl, grid, s, ka);
+    if (pl.splitk > 1) {
+        long total = (long)a.M * a.N * a.batch;
+        hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, ka);
+    }
+}
+
 // returns false (nothing launched, nothing counted) when the problem is not eligible
 bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     if (!gemm_f32_glds_shape_ok(a)) return false;
@@ -621,6 +722,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
         CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
     }
     if (L.dry) return true;
+    autotune<float>(L, a, bk, f32_glds_speed());
     KArgs ka;
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
@@ -706,6 +808,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         long eb = (long)a.N * a.ldb;
         CB_CHECK(ea * 2 < lim && eb * 2 < lim, CB_ERR_SHAPE, "gemm_bf16: an operand slice exceeds 2 GiB");
     }
+    if (gvariant().glds) autotune<bf16_t>(L, a, bf16_bk(), plan_knobs().bf16_speed);
     KArgs ka;
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;

@@ -5,6 +5,7 @@
 // (row, chunk) mapping, the LDS image and its XOR swizzle are the same for both element types.
 #pragma once
 #include "cb_device.h"
+#include <unordered_map>
 
 namespace cb {
 
@@ -213,6 +214,54 @@ inline const PlanKnobs& plan_knobs() {
     }();
     return k;
 }
+// ---- measured plan table. The analytic model below is within 5-8 % of the per-shape optimum over the step's launches and no
+// setting of its constants closes the gap (profiles/README.md, round 2), so the shapes of the SD v1-4 step (config 2 at bs = 1,
+// config 3 at bs = 4, config 5 at bs = 2, the DDIM batches) carry MEASURED plans: cb_plan_table.inc is generated by
+// tools/make_plan_table.py from an offline autotune run (CB_AUTOTUNE=<file>: every launch of the LDS-DMA kernel times all
+// (tile, split-K) candidates on its own operands into scratch outputs and records the winner; the run itself keeps executing
+// the analytic plans). Unknown shapes fall back to the model. CB_PLAN_TABLE=0 disables the table, CB_PLAN_FILE=<file> adds one.
+struct PlanEntry { int BM, BN, split; };
+inline std::string plan_key(const GemmArgs& a, int bke) {
+    char b[160];
+    const int cf = a.a_kind == LD_CONV ? (a.g.up | (a.g.tr << 1) | (a.g.stride << 2) | (a.g.ks << 5)) : 0;
+    snprintf(b, sizeof b, "%d|%d|%d|%d|%d|%d|%d|%d", bke, (int)a.dt, (int)a.a_kind, a.M, a.N, a.K, a.batch, cf);
+    return b;
+}
+inline void plan_table_parse(std::unordered_map<std::string, PlanEntry>& t, const char* text) {
+    // lines: "<key> <BM> <BN> <split> [anything]"
+    const char* p = text;
+    while (*p) {
+        const char* e = strchr(p, '\n');
+        std::string line(p, e ? (size_t)(e - p) : strlen(p));
+        char key[160]; int bm, bn, sp;
+        if (sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1)
+            t[key] = PlanEntry{bm, bn, sp};
+        if (!e) break;
+        p = e + 1;
+    }
+}
+inline const std::unordered_map<std::string, PlanEntry>& plan_table() {
+    static const std::unordered_map<std::string, PlanEntry> t = [] {
+        std::unordered_map<std::string, PlanEntry> m;
+        const char* off = getenv("CB_PLAN_TABLE");
+        if (off && off[0] == '0') return m;
+        static const char* kEmbedded =
+#include "cb_plan_table.inc"
+            ;
+        plan_table_parse(m, kEmbedded);
+        if (const char* f = getenv("CB_PLAN_FILE")) {
+            if (FILE* fp = fopen(f, "r")) {
+                std::string all; char buf[4096]; size_t n;
+                while ((n = fread(buf, 1, sizeof buf, fp)) > 0) all.append(buf, n);
+                fclose(fp);
+                plan_table_parse(m, all.c_str());
+            }
+        }
+        return m;
+    }();
+    return t;
+}
+
 // diagnostics (tools/tune_gemm.py): restrict the planner to one tile shape / split count; 0 = free. Not thread safe, not for production.
 struct PlanForce { int BM = 0, BN = 0, split = 0; };
 inline PlanForce& plan_force() { static PlanForce f; return f; }
@@ -228,6 +277,17 @@ inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
     const int ksteps = cdiv(a.K, bke);
     double best = 1e300;
     Plan pl{128, 128, 1, 1, 1, ksteps * bke};
+    if (!plan_force().BM && !plan_force().split) {
+        const auto& tab = plan_table();
+        if (!tab.empty()) {
+            auto it = tab.find(plan_key(a, bke));
+            if (it != tab.end() && it->second.split <= ksteps) {
+                const PlanEntry& e = it->second;
+                const int kps = cdiv(ksteps, e.split) * bke;
+                return Plan{e.BM, e.BN, (int)cdiv(a.M, e.BM), (int)cdiv(a.N, e.BN), (int)cdiv(a.K, kps), kps};
+            }
+        }
+    }
     for (int t = 0; t < 4; ++t) {
         const int BM = tiles[t][0], BN = tiles[t][1];
         const PlanForce& pf = plan_force();

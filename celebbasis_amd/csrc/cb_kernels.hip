@@ -455,23 +455,48 @@ __global__ void gn_expand_kernel(float* __restrict__ chn, const float* __restric
     int n = i / C, c = i % C, g = c / (C / G);
     *reinterpret_cast<float4*>(chn + (long)i * 4) = make_float4(stats[(n * G + g) * 2], stats[(n * G + g) * 2 + 1], gamma[c], beta[c]);
 }
-template <typename T>
+// one 16-byte access per thread and pass: 1 quad of fp32, 2 quads of bf16 (C % 8 == 0; otherwise the single-quad form)
+template <typename T> struct GnVec { static constexpr int VQ = 1; };
+template <> struct GnVec<bf16_t> { static constexpr int VQ = 2; };
+__device__ __forceinline__ void gn_ldq(const float* p, float4 (&v)[1]) { v[0] = ld4(p); }
+__device__ __forceinline__ void gn_ldq(const bf16_t* p, float4 (&v)[1]) { v[0] = ld4(p); }
+__device__ __forceinline__ void gn_ldq(const bf16_t* p, float4 (&v)[2]) {
+    const uint4 u = *reinterpret_cast<const uint4*>(p);
+    v[0] = make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u));
+    v[1] = make_float4(__uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u));
+}
+__device__ __forceinline__ void gn_stq(float* p, const float4 (&v)[1]) { st4(p, v[0]); }
+__device__ __forceinline__ void gn_stq(bf16_t* p, const float4 (&v)[1]) { st4(p, v[0]); }
+__device__ __forceinline__ void gn_stq(bf16_t* p, const float4 (&v)[2]) {
+    uint4 u;
+    u.x = pack_bf16x2(v[0].x, v[0].y); u.y = pack_bf16x2(v[0].z, v[0].w); u.z = pack_bf16x2(v[1].x, v[1].y); u.w = pack_bf16x2(v[1].z, v[1].w);
+    *reinterpret_cast<uint4*>(p) = u;
+}
+template <typename T, int VQ>
 __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                         const float* __restrict__ chn, long nquads, int HW, int C, int silu) {
     const int Q = C >> 2;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
-        int q = (int)(i % Q);
-        long n = i / ((long)HW * Q);
-        float4 v = ld4(x + i * 4);
-        const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
-        float in[4] = {v.x, v.y, v.z, v.w}, o[4];
+    const long nunits = nquads / VQ;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < nunits; u += (long)gridDim.x * 256) {
+        const long i = u * VQ;
+        const int q = (int)(i % Q);
+        const long n = i / ((long)HW * Q);
+        float4 v[VQ], r[VQ];
+        gn_ldq(x + i * 4, v);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 kk = k[j];
-            float t = (in[j] - kk.x) * kk.y * kk.z + kk.w;
-            o[j] = silu ? t * sigmoidf_(t) : t;
+        for (int w = 0; w < VQ; ++w) {
+            const float4* k = reinterpret_cast<const float4*>(chn + (n * C + (q + w) * 4) * 4);
+            const float in[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 kk = k[j];
+                const float t = (in[j] - kk.x) * kk.y * kk.z + kk.w;
+                o[j] = silu ? t * sigmoidf_(t) : t;
+            }
+            r[w] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        st4(y + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        gn_stq(y + i * 4, r);
     }
 }
 
@@ -616,7 +641,10 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
     CB_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
         hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
-        hipLaunchKernelGGL((gn_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+        if (GnVec<T>::VQ == 2 && C % 8 == 0)
+            hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), grid1d(nquads / 2, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+        else
+            hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
     });
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
@@ -678,32 +706,38 @@ __global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ g
     float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) { gs[((long)n * C + c) * 2] = s1; gs[((long)n * C + c) * 2 + 1] = s2; }
 }
-template <typename T>
+template <typename T, int VQ>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(T* __restrict__ dx, const T* __restrict__ x,
                                                             const T* __restrict__ dy, const float* __restrict__ chn,
                                                             const float* __restrict__ gs, long nquads, int HW, int C, int silu,
                                                             float acc_beta) {
     const int Q = C >> 2;
-    for (long i = blockIdx.x * 256L + threadIdx.x; i < nquads; i += (long)gridDim.x * 256) {
-        int q = (int)(i % Q);
-        long n = i / ((long)HW * Q);
-        float4 xv = ld4(x + i * 4);
-        float4 dv = ld4(dy + i * 4);
-        const float4* k = reinterpret_cast<const float4*>(chn + (n * C + q * 4) * 4);
-        const float2* s = reinterpret_cast<const float2*>(gs + (n * C + q * 4) * 2);
-        float xi[4] = {xv.x, xv.y, xv.z, xv.w}, di[4] = {dv.x, dv.y, dv.z, dv.w}, o[4];
+    const long nunits = nquads / VQ;
+    for (long u = blockIdx.x * 256L + threadIdx.x; u < nunits; u += (long)gridDim.x * 256) {
+        const long i = u * VQ;
+        const int q = (int)(i % Q);
+        const long n = i / ((long)HW * Q);
+        float4 xv[VQ], dv[VQ], old[VQ], r[VQ];
+        gn_ldq(x + i * 4, xv);
+        gn_ldq(dy + i * 4, dv);
+        if (acc_beta != 0.f) gn_ldq(dx + i * 4, old);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float4 kk = k[j]; float2 ss = s[j];
-            float xh = (xi[j] - kk.x) * kk.y;
-            float dt = gn_dt(xh, kk.z, kk.w, di[j], silu) * kk.z;
-            o[j] = kk.y * (dt - ss.x - xh * ss.y);
+        for (int w = 0; w < VQ; ++w) {
+            const float4* k = reinterpret_cast<const float4*>(chn + (n * C + (q + w) * 4) * 4);
+            const float2* sg = reinterpret_cast<const float2*>(gs + (n * C + (q + w) * 4) * 2);
+            const float xi[4] = {xv[w].x, xv[w].y, xv[w].z, xv[w].w}, di[4] = {dv[w].x, dv[w].y, dv[w].z, dv[w].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float4 kk = k[j]; const float2 ss = sg[j];
+                const float xh = (xi[j] - kk.x) * kk.y;
+                const float dt = gn_dt(xh, kk.z, kk.w, di[j], silu) * kk.z;
+                o[j] = kk.y * (dt - ss.x - xh * ss.y);
+            }
+            if (acc_beta != 0.f) { o[0] += acc_beta * old[w].x; o[1] += acc_beta * old[w].y; o[2] += acc_beta * old[w].z; o[3] += acc_beta * old[w].w; }
+            r[w] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (acc_beta != 0.f) {
-            float4 old = ld4(dx + i * 4);
-            o[0] += acc_beta * old.x; o[1] += acc_beta * old.y; o[2] += acc_beta * old.z; o[3] += acc_beta * old.w;
-        }
-        st4(dx + i * 4, make_float4(o[0], o[1], o[2], o[3]));
+        gn_stq(dx + i * 4, r);
     }
 }
 void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma, const float* beta,
@@ -737,8 +771,12 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
         hipLaunchKernelGGL((gn_bwd_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, (const T*)dy,
                            chn, HW, C, G, nchunk, rpb, silu);
         hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
-        hipLaunchKernelGGL((gn_bwd_apply_kernel<T>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, chn,
-                           gs, nquads, HW, C, silu, acc_beta);
+        if (GnVec<T>::VQ == 2 && C % 8 == 0)
+            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, GnVec<T>::VQ>), grid1d(nquads / 2, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x,
+                               (const T*)dy, chn, gs, nquads, HW, C, silu, acc_beta);
+        else
+            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 1>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, chn,
+                               gs, nquads, HW, C, silu, acc_beta);
     });
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());

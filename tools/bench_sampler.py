@@ -21,9 +21,10 @@ ap.add_argument("--n", type=int, default=1)
 ap.add_argument("--steps", type=int, default=50)
 ap.add_argument("--scale", type=float, default=10.0)
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"], help="UNet / VAE element type (bf16 = the MI355X counterpart of the reference's fp16 autocast sampling)")
 a = ap.parse_args()
 dev = "cuda:0"
-ctx = lib.Context()
+ctx = lib.Context(dtype=a.dtype)
 shapes = {k: v for k, v in synthetic.trainer_shapes().items() if k.startswith("model.diffusion_model.")}
 shapes.update(synthetic.decoder_shapes())
 W = synthetic.synthetic_state(shapes, seed=0, device=dev)
@@ -44,7 +45,7 @@ for r in range(a.reps + 1):
     torch.cuda.synchronize(); t2 = time.perf_counter()
     if r > 0 and (best is None or t2 - t0 < best[0]):
         best = (t2 - t0, t1 - t0, t2 - t1)
-print(json.dumps({"metric": "DDIM sampling seconds per image @ SD v1-4 512x512 fp32", "n_samples": a.n, "ddim_steps": a.steps, "cfg_scale": a.scale,
+print(json.dumps({"metric": f"DDIM sampling seconds per image @ SD v1-4 512x512 {a.dtype}", "dtype": a.dtype, "n_samples": a.n, "ddim_steps": a.steps, "cfg_scale": a.scale,
                   "sec_per_batch": round(best[0], 4), "sec_per_image": round(best[0] / a.n, 4), "ddim_loop_s": round(best[1], 4),
                   "vae_decode_s": round(best[2], 4), "unet_passes_per_s": round(a.steps * 2 * a.n / best[1], 2),
                   "unet_tflops": round(a.steps * 2 * a.n * 0.80327 / best[1], 2), "finite": bool(torch.isfinite(img).all())}))

@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--n-samples", type=int, default=8)
     ap.add_argument("--scale", type=float, default=10.0)
+    ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -42,7 +43,7 @@ def main():
 
     shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
     state = synthetic.synthetic_state(shapes, seed=0)
-    ctx = lib.Context()
+    ctx = lib.Context(dtype=a.precision)
     wt = lib.WeightTable(state)
     tr = lib.Trainer(ctx, wt)
     unet, clip = tr.unet(), tr.clip()                    # views on the trainer's weights: one copy of SD v1-4 per GPU
@@ -118,7 +119,7 @@ def main():
                           "batch": B, "ddim_steps": a.ddim_steps, "n_samples": a.n_samples, "cfg_scale": a.scale, "wall_s": round(el, 2),
                           "rank0_train_s": round(t_train, 2), "rank0_sample_s": round(t_sample, 2),
                           "rank0_train_steps_per_s": round(len(mine) * a.train_steps / max(t_train, 1e-9), 2),
-                          "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()), "finite": finite, "dtype": "f32",
+                          "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()), "finite": finite, "dtype": a.precision,
                           "data": "synthetic"}))
     if world > 1:
         dist.destroy_process_group()
