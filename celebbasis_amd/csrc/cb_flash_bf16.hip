@@ -150,10 +150,10 @@ __device__ __forceinline__ void fb_store_out4(bf16_t* p, const f32x4& v, float b
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-template <int KS, int TK>
+template <int KS, int TK, int DTV>
 __global__ __launch_bounds__(256) void flash_bf16_fwd_kernel(const FlashArgs a) {
     using C = FbCfg<KS, TK>;
-    constexpr int DT = 2 * KS;                       // 16-wide output tiles over the (padded) head dim
+    constexpr int DT = DTV;                          // 16-wide output tiles over the head dim: ceil(d / 16), not the padded 2 * KS
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Ks = lds;                                  // row-major K tile
     char* Vt = lds + C::RBYTES;                      // transposed V tile
@@ -274,10 +274,10 @@ __global__ __launch_bounds__(256) void flash_bf16_dvec_kernel(const FlashArgs a,
 }
 
 // ---------------------------------------------------------------------------------------------- backward: dQ
-template <int KS, int TK>
+template <int KS, int TK, int DTV>
 __global__ __launch_bounds__(256) void flash_bf16_dq_kernel(const FlashArgs a) {
     using C = FbCfg<KS, TK>;
-    constexpr int DT = 2 * KS;
+    constexpr int DT = DTV;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Ks = lds;                                  // row-major K
     char* Vs = lds + C::RBYTES;                      // row-major V
@@ -385,10 +385,10 @@ __global__ __launch_bounds__(256) void flash_bf16_dq_kernel(const FlashArgs a) {
 //   dP[q][key]   = dO V^T        A = dO tile (row-major), B = V regs
 //   dV^T[d][key] += dO^T P       A = dO tile (transposed), B = P regs
 //   dK^T[d][key] += Q^T dS       A = Q tile (transposed),  B = dS regs
-template <int KS, int TK>
+template <int KS, int TK, int DTV>
 __global__ __launch_bounds__(256) void flash_bf16_dkv_kernel(const FlashArgs a) {
     using C = FbCfg<KS, TK>;
-    constexpr int DT = 2 * KS;
+    constexpr int DT = DTV;
     extern __shared__ __attribute__((aligned(16))) char lds[];
     char* Qs = lds;
     char* Ds = lds + C::RBYTES;
@@ -545,9 +545,9 @@ size_t flash_bf16_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit) {
     const int BH = B * a.H;
     long blocks0 = (long)cdiv(a.Nk, FB_ROWS) * BH;
     int ns = 1;
-    if (blocks0 < 128 && a.Nq >= 512 && !a.causal) {
-        ns = (int)((256 + blocks0 - 1) / blocks0);
-        int maxs = a.Nq / 128;                      // at least two 64-query tiles per split
+    if (blocks0 < 256 && a.Nq >= 128 && !a.causal) {     // same rule as the fp32 kernel (cb_flash.hip): aim at ~2 blocks per CU
+        ns = (int)((512 + blocks0 - 1) / blocks0);
+        int maxs = a.Nq / 64;                       // at least one 64-query tile (two 32-query tiles) per split
         if (ns > maxs) ns = maxs;
         if (ns < 1) ns = 1;
     }
@@ -571,15 +571,17 @@ template <int KS, int TK> static size_t fb_lds(int kind) {     // 0 fwd, 1 dq, 2
     return (size_t)2 * C::RBYTES + 2 * C::TBYTES + 2 * TK * sizeof(float);
 }
 
-#define FB_CASE(KSV, TKV, KERNEL, KIND, GRID, ...) \
-    case KSV: hipLaunchKernelGGL((KERNEL<KSV, TKV>), GRID, dim3(256), (fb_lds<KSV, TKV>(KIND)), L.stream, __VA_ARGS__); break;
-#define FB_DISPATCH(KSV, KERNEL, KIND, GRID, ...)                   \
-    switch (KSV) {                                                  \
-        FB_CASE(1, 64, KERNEL, KIND, GRID, __VA_ARGS__)             \
-        FB_CASE(2, 64, KERNEL, KIND, GRID, __VA_ARGS__)             \
-        FB_CASE(3, 64, KERNEL, KIND, GRID, __VA_ARGS__)             \
-        FB_CASE(4, 32, KERNEL, KIND, GRID, __VA_ARGS__)             \
-        default: hipLaunchKernelGGL((KERNEL<5, 32>), GRID, dim3(256), (fb_lds<5, 32>(KIND)), L.stream, __VA_ARGS__); break; \
+// KS = 32-wide k groups of the head dim (contraction depth of S / dP), DT = 16-wide output tiles actually needed (d = 40: 3, not 4;
+// d = 80: 5, not 6): the accumulate phases (P.V, dS.K, dS^T.Q, P^T.dO) skip the padding tiles
+#define FB_GO(KSV, TKV, DTV, KERNEL, KIND, GRID, ...) \
+    hipLaunchKernelGGL((KERNEL<KSV, TKV, DTV>), GRID, dim3(256), (fb_lds<KSV, TKV>(KIND)), L.stream, __VA_ARGS__)
+#define FB_DISPATCH(KSV, KERNEL, KIND, GRID, ...)                                                        \
+    switch (KSV) {                                                                                       \
+        case 1: FB_GO(1, 64, 2, KERNEL, KIND, GRID, __VA_ARGS__); break;                                 \
+        case 2: if (a.d <= 48) FB_GO(2, 64, 3, KERNEL, KIND, GRID, __VA_ARGS__); else FB_GO(2, 64, 4, KERNEL, KIND, GRID, __VA_ARGS__); break; \
+        case 3: if (a.d <= 80) FB_GO(3, 64, 5, KERNEL, KIND, GRID, __VA_ARGS__); else FB_GO(3, 64, 6, KERNEL, KIND, GRID, __VA_ARGS__); break; \
+        case 4: FB_GO(4, 32, 8, KERNEL, KIND, GRID, __VA_ARGS__); break;                                 \
+        default: FB_GO(5, 32, 10, KERNEL, KIND, GRID, __VA_ARGS__); break;                               \
     }
 
 void flash_bf16_forward(const Launch& L, const FlashArgs& a, int B) {
