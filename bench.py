@@ -79,8 +79,8 @@ def pmc_traffic(kernel):
 
 # kernel symbols behind each HBM-bound profiler group (rocprofv3 names, `cb::` stripped as tools/prof_stats.py writes them)
 HBM_GROUP_SYMBOLS = {
-    "groupnorm_fwd": ("gn_partial_kernel", "gn_final_kernel", "gn_apply_kernel"),
-    "groupnorm_bwd": ("gn_bwd_partial_kernel", "gn_bwd_final_kernel", "gn_bwd_apply_kernel"),
+    "groupnorm_fwd": ("gn_partial_kernel", "gn_final_kernel", "gn_apply_kernel", "gn_fused_fwd_kernel"),
+    "groupnorm_bwd": ("gn_bwd_partial_kernel", "gn_bwd_final_kernel", "gn_bwd_apply_kernel", "gn_fused_bwd_kernel"),
     "layernorm_fwd": ("layernorm_fwd_kernel",), "layernorm_bwd": ("layernorm_bwd_kernel",),
     "splitk_reduce_kernel": ("splitk_reduce_kernel",),
 }
@@ -152,7 +152,10 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
     hbm = [p for p in prof if p.get("bytes", 0) > 0 and p["flops"] == 0]    # HBM-bound groups: algorithmic bytes
     prof = [p for p in prof if p["flops"] > 0]                             # MFMA-bound launches (GEMM family + fused attention)
     tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
-    dom = max(prof, key=lambda p: p["ms"])
+    # dominant kernel = the variant that carries the most algorithmic FLOPs of the step. (Ranking by summed live event time is not
+    # robust: an event pair around a ~10 us launch reads ~2x long, so a variant with many short launches can outrank the kernel that
+    # does half of the step's work; the rocprofv3 trace ranks them the same way as the FLOPs do.)
+    dom = max(prof, key=lambda p: p["flops"])
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     src, sym_ms = rocprof_symbol_ms(bf16)
     hb = []

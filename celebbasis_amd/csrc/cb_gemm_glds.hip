@@ -216,27 +216,27 @@ template <int RB, int ESZ> struct GGeo {
     __device__ static __forceinline__ int chunk(int idx) { return (idx & (CPR - 1)) ^ swz(idx >> LOG); }   // logical chunk fetched by slot idx
 };
 
-template <int ROWS, int RB, int ESZ> struct GRows {        // ROW operand: per-slot byte offset of (row, swizzled chunk) or OOB
+template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GRows {        // ROW operand: per-slot byte offset of (row, swizzled chunk) or OOB
     using G = GGeo<RB, ESZ>;
-    static constexpr int N = ROWS * G::CPR / 256;
+    static constexpr int N = ROWS * G::CPR / NTHR;
     int off[N];
     __device__ __forceinline__ void init(long ld, int r0, int R, int tid) {
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int idx = tid + i * 256, row = G::row(idx);
+            const int idx = tid + i * NTHR, row = G::row(idx);
             off[i] = (r0 + row < R) ? (int)(((long)(r0 + row) * ld + G::chunk(idx) * G::EPC) * ESZ) : OOB;
         }
     }
 };
-template <int ROWS, int RB, int ESZ> struct GConvFast {   // plain conv, C % BK == 0: a k-tile lies inside one tap (scalar tap walk)
+template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GConvFast {   // plain conv, C % BK == 0: a k-tile lies inside one tap (scalar tap walk)
     using G = GGeo<RB, ESZ>;
-    static constexpr int N = ROWS * G::CPR / 256;
+    static constexpr int N = ROWS * G::CPR / NTHR;
     int base[N]; unsigned vmask[N];
     __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int tid) {
         const int HWo = g.Ho * g.Wo;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int idx = tid + i * 256, r = r0 + G::row(idx);
+            const int idx = tid + i * NTHR, r = r0 + G::row(idx);
             unsigned m = 0; int b = 0;
             if (r < R) {
                 int n = r / HWo, rem = r - n * HWo, oy = rem / g.Wo, ox = rem - oy * g.Wo;
@@ -254,15 +254,15 @@ template <int ROWS, int RB, int ESZ> struct GConvFast {   // plain conv, C % BK 
         }
     }
 };
-template <int ROWS, int RB, int ESZ> struct GConvGen {    // general gather: per-slot (tap, channel) walk
+template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GConvGen {    // general gather: per-slot (tap, channel) walk
     using G = GGeo<RB, ESZ>;
-    static constexpr int N = ROWS * G::CPR / 256;
+    static constexpr int N = ROWS * G::CPR / NTHR;
     int nb[N], vy0[N], vx0[N], tap[N], ci[N];
     __device__ __forceinline__ void init(const ConvGeom& g, int r0, int R, int kfirst, int tid) {
         const int HWo = g.Ho * g.Wo;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int idx = tid + i * 256, r = r0 + G::row(idx);
+            const int idx = tid + i * NTHR, r = r0 + G::row(idx);
             if (r < R) {
                 int n = r / HWo, rem = r - n * HWo, oy = rem / g.Wo, ox = rem - oy * g.Wo;
                 nb[i] = n * g.H * g.W; vy0[i] = oy * g.stride - g.pad; vx0[i] = ox * g.stride - g.pad;
@@ -275,7 +275,7 @@ template <int ROWS, int RB, int ESZ> struct GConvGen {    // general gather: per
         const int sh = (g.up | g.tr), Hv = g.H << sh, Wv = g.W << sh;
 #pragma unroll
         for (int i = 0; i < N; ++i) {
-            const int k = k0 + G::chunk(tid + i * 256) * G::EPC;
+            const int k = k0 + G::chunk(tid + i * NTHR) * G::EPC;
             const int ky = (g.ks == 3) ? ((tap[i] * 11) >> 5) : 0, kx = tap[i] - ky * g.ks;
             const int vy = vy0[i] + ky, vx = vx0[i] + kx;
             bool ok = (k < Kend) && (nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
@@ -312,10 +312,10 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
-template <typename T, int BM, int BN>
-__device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)[BM / 64][BN / 64], char* lds, int m0, int n0, int wm,
+template <typename T, int BM, int BN, int WM = 2>
+__device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)[BM / WM / 32][BN / 64], char* lds, int m0, int n0, int wm,
                                                    int wn, int lane, int wave, int split, int z, int zb, int zh) {
-    constexpr int TM = BM / 64, TN = BN / 64, WR = BM / 2, WC = BN / 2, CPRW = WC / 8, RPP = 64 / CPRW;
+    constexpr int TM = BM / WM / 32, TN = BN / 64, WR = BM / WM, WC = BN / 2, CPRW = WC / 8, RPP = 64 / CPRW;
     const GemmArgs& a = p.a;
     const int kl = lane >> 5, ml = lane & 31;
     float* S = reinterpret_cast<float*>(lds) + wave * (WR * WC);
@@ -397,12 +397,13 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
 // one tile (past the end of K the lanes are out of range and the DMA writes zeros into a slot nobody reads), so the number of
 // outstanding DMA instructions is constant and "tile t has landed" is the counted wait vmcnt((STAGES-2) * loads per tile)
 // followed by a raw s_barrier (a __syncthreads() would drain the whole queue with vmcnt(0)).
-template <typename T, int BM, int BN, int AK, int RB, int STAGES>
+template <typename T, int BM, int BN, int AK, int RB, int STAGES, int NTHR = 256>
 __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     constexpr int ESZ = El<T>::ESZ;
     using G = GGeo<RB, ESZ>;
     using Frag = typename El<T>::Frag;
-    constexpr int TM = BM / 64, TN = BN / 64, NA = BM * G::CPR / 256, NB = BN * G::CPR / 256, BKT = G::BK;
+    constexpr int WM = NTHR / 128;                       // waves along M (x 2 along N): 2 for the 4-wave tiles, 4 for the 8-wave 256x128 tile
+    constexpr int TM = BM / WM / 32, TN = BN / 64, NA = BM * G::CPR / NTHR, NB = BN * G::CPR / NTHR, BKT = G::BK;
     const GemmArgs& a = p.a;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -425,7 +426,7 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    GRows<BM, RB, ESZ> ra; GRows<BN, RB, ESZ> rb; GConvFast<BM, RB, ESZ> cf; GConvGen<BM, RB, ESZ> cg;
+    GRows<BM, RB, ESZ, NTHR> ra; GRows<BN, RB, ESZ, NTHR> rb; GConvFast<BM, RB, ESZ, NTHR> cf; GConvGen<BM, RB, ESZ, NTHR> cg;
     int tap_u = 0, ci_u = 0;
     if constexpr (AK == AK_ROW) ra.init(a.lda, m0, a.M, tid);
     else if constexpr (AK == AK_CONVF) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
@@ -434,9 +435,9 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     // per-slot k offset of the fetched chunk (loop invariant): the K tail test is one compare per slot
     int kca[NA], kcb[NB];
 #pragma unroll
-    for (int i = 0; i < NA; ++i) kca[i] = G::chunk(tid + i * 256) * G::EPC;
+    for (int i = 0; i < NA; ++i) kca[i] = G::chunk(tid + i * NTHR) * G::EPC;
 #pragma unroll
-    for (int i = 0; i < NB; ++i) kcb[i] = G::chunk(tid + i * 256) * G::EPC;
+    for (int i = 0; i < NB; ++i) kcb[i] = G::chunk(tid + i * NTHR) * G::EPC;
     const __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
     constexpr int A_BUF = BM * RB, B_BUF = BN * RB;
     char* const As = lds;
@@ -464,10 +465,10 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
         char* bd = Bs + buf * B_BUF + wbase;
 #pragma unroll
         for (int i = 0; i < NA; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * 4096), 16, oa[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, oa[i], 0, 0, 0);
 #pragma unroll
         for (int i = 0; i < NB; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(bd + i * 4096), 16, ob[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(bd + i * (NTHR * 16)), 16, ob[i], 0, 0, 0);
     };
 
 #pragma unroll
@@ -482,7 +483,7 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
         asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory");
         __builtin_amdgcn_s_barrier();
         issue(k0 + (STAGES - 1) * BKT, nxt);
-        const char* arow = As + cur * A_BUF + (wm * (BM / 2) + ml) * RB;
+        const char* arow = As + cur * A_BUF + (wm * (BM / WM) + ml) * RB;
         const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * RB;
 #pragma unroll
         for (int s = 0; s < G::CPR / 2; ++s) {                     // one 16-byte chunk per half-wave: 16 bf16 / 8 fp32 of k per step
@@ -512,8 +513,18 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
         nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the zero-fill tiles issued past the end of K
-    gemm_glds_epilogue<T, BM, BN>(p, acc, lds, m0, n0, wm, wn, lane, wave, split, z, zb, zh);
+    gemm_glds_epilogue<T, BM, BN, WM>(p, acc, lds, m0, n0, wm, wn, lane, wave, split, z, zb, zh);
 }
+
+// 8-wave variant: 256x128 tile (4 x 2 waves of 64x64), 128-byte rows, THREE stages = 144 KB of LDS = one block per CU with two
+// k-tiles in flight and 25 % fewer operand bytes per FLOP than the 128x128 tile. For the bf16 problems large enough to fill the
+// chip with it (the planner / plan table decide); dynamic LDS (> 64 KB).
+template <typename T, int AK>
+__global__ __launch_bounds__(512) void gemm_glds256_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds256[];
+    gemm_glds_body<T, 256, 128, AK, 128, 3, 512>(p, lds256);
+}
+constexpr int GLDS256_LDS = 3 * (256 + 128) * 128;
 
 template <typename T, int BM, int BN, int AK, int RB, int STAGES>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const KArgs p) {
@@ -548,6 +559,16 @@ static void launch_glds(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& k
 template <int AK>
 static void launch_tiles_bf16(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     const GVariant& v = gvariant();
+    if (pl.BM == 256) {
+        CB_CHECK(v.glds && v.rb == 128 && pl.BN == 128, CB_ERR_STATE, "gemm_bf16: the 256x128 tile exists for the default LDS-DMA variant only");
+        static const bool once = [] {
+            CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds256_kernel<bf16_t, AK>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS256_LDS));
+            return true;
+        }();
+        (void)once;
+        hipLaunchKernelGGL((gemm_glds256_kernel<bf16_t, AK>), grid, dim3(512), GLDS256_LDS, s, ka);
+        return;
+    }
     if (v.glds) {
         if (v.rb == 128 && v.stages == 2) launch_glds<bf16_t, AK, 128, 2>(pl, grid, s, ka);
         else if (v.rb == 128 && v.stages == 3) launch_glds<bf16_t, AK, 128, 3>(pl, grid, s, ka);
@@ -600,6 +621,7 @@ size_t gemm_f32_glds_ws_bytes(const GemmArgs& a) {
 }
 template <int AK>
 static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    CB_CHECK(pl.BM != 256, CB_ERR_STATE, "gemm: the 256x128 tile is a bf16 variant");
     if (f32_glds_mode() == 2) launch_glds<float, AK, 64, 3>(pl, grid, s, ka);
     else launch_glds<float, AK, 128, 2>(pl, grid, s, ka);
 }
@@ -628,8 +650,9 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     const std::string key = plan_key(a, bk);
     if (t->seen.count(key)) return;
     t->seen[key] = 1;
-    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
+    const int ntile = (sizeof(T) == 2 && bk == 64) ? 5 : 4;           // the 8-wave 256x128 tile: bf16, default ring only
     const int ksteps = cdiv(a.K, bk);
     const size_t out_elems = (size_t)a.M * (size_t)std::max<long>(a.ldc, a.N);
     size_t ws_max = 0;
@@ -655,9 +678,9 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     const Plan model = make_plan(a, bk, speed);
     const double t_model = (model.splitk <= 1 || (size_t)model.splitk * a.M * a.N * sizeof(float) <= ws_max) ? time_plan(model) : -1.0;
     double best = 1e30; Plan bp = model;
-    for (int ti = 0; ti < 4; ++ti) {
+    for (int ti = 0; ti < ntile; ++ti) {
         const int BM = tiles[ti][0], BN = tiles[ti][1];
-        if ((BM == 128 && a.M <= 64) || (BN == 128 && a.N <= 64)) continue;
+        if ((BM >= 128 && a.M <= 64) || (BN == 128 && a.N <= 64) || (BM == 256 && a.M <= 128)) continue;
         for (int sp : splits) {
             if (sp > 1 && ksteps / sp < 2) break;
             if (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > ws_max) break;
@@ -831,7 +854,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_HIP(hipGetLastError());
     if (prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_%skernel<%s%d,%d,%s>", gvariant().glds ? "glds_" : "bf16_", gvariant().glds ? "bf16," : "", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        snprintf(nm, sizeof nm, "gemm_%skernel<%s%d,%d,%s>", pl.BM == 256 ? "glds256_" : (gvariant().glds ? "glds_" : "bf16_"), gvariant().glds ? "bf16," : "", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }

@@ -234,7 +234,7 @@ inline void plan_table_parse(std::unordered_map<std::string, PlanEntry>& t, cons
         const char* e = strchr(p, '\n');
         std::string line(p, e ? (size_t)(e - p) : strlen(p));
         char key[160]; int bm, bn, sp;
-        if (sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && (bm == 64 || bm == 128) && (bn == 64 || bn == 128) && sp >= 1)
+        if (sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && ((bm == 64 || bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (bm != 256 || bn == 128)) && sp >= 1)
             t[key] = PlanEntry{bm, bn, sp};
         if (!e) break;
         p = e + 1;
@@ -270,9 +270,11 @@ inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
     // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
-    static const int tiles[4][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}};
+    // the fifth shape (8-wave 256x128 tile of the bf16 LDS-DMA kernel) is never chosen by the model: only a measured table entry
+    // or cb_debug_force_plan selects it
+    static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
     const PlanKnobs& kn = plan_knobs();
-    const double* eff = kn.eff;
+    const double eff[5] = {kn.eff[0], kn.eff[1], kn.eff[2], kn.eff[3], 1.0};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const int ksteps = cdiv(a.K, bke);
     double best = 1e300;
@@ -288,9 +290,10 @@ inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
             }
         }
     }
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < 5; ++t) {
         const int BM = tiles[t][0], BN = tiles[t][1];
         const PlanForce& pf = plan_force();
+        if (t == 4 && pf.BM != 256) continue;
         if (pf.BM && (pf.BM != BM || pf.BN != BN)) continue;
         if (!pf.BM && BM == 128 && a.M <= 64) continue;
         if (!pf.BM && BN == 128 && a.N <= 64) continue;

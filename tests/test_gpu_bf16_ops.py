@@ -89,6 +89,33 @@ def test_gemm_bf16(cbf, M, N, K, batch, extra):
     close(f"bf16.gemm[{M}x{N}x{K},batch{batch},{extra}]", Cd, ref, TOL)
 
 
+@pytest.fixture
+def tile256(cbf):
+    """pin the planner to the 8-wave 256x128 LDS-DMA tile for one test (cb_debug_force_plan is process-global)"""
+    lib, _ = cbf
+    L = lib.load()
+
+    def pin(split):
+        lib.check(L.cb_debug_force_plan(256, 128, split))
+    yield pin
+    lib.check(L.cb_debug_force_plan(0, 0, 0))
+
+
+@pytest.mark.parametrize("M,N,K,split,extra", [(1024, 256, 640, 1, "bias+res"), (777, 200, 328, 1, "bias"), (512, 320, 2880, 3, "bias+beta")])
+def test_gemm_bf16_tile256(cbf, tile256, M, N, K, split, extra):
+    """the 256x128 tile (three-stage ring, 512 threads): full tiles, ragged M / N / K tails, split-K + reduce"""
+    tile256(split)
+    test_gemm_bf16(cbf, M, N, K, 1, extra)
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,mode", [(2, 32, 32, 64, 160, 3, "same"), (1, 24, 20, 72, 96, 3, "same"), (2, 33, 31, 64, 128, 3, "down"),
+                                                     (2, 16, 16, 64, 128, 3, "up")])
+def test_conv_bf16_tile256(cbf, tile256, N, H, W, Cin, Cout, ks, mode):
+    """implicit-GEMM gathers (fast path, general path, stride 2, fused upsample) and their input gradients on the 256x128 tile"""
+    tile256(1)
+    test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, "bias")
+
+
 def test_gemm_bf16_rejects_unsupported_layouts(cbf):
     """the bf16 GEMM takes k-contiguous, 16-byte-chunked operands only: anything else is an error, never a silent fallback"""
     lib, ctx = cbf
