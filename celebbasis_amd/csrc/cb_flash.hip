@@ -43,7 +43,7 @@ template <int DT> struct FlCfg {
 // per-thread (row, column) decode is loop invariant, so a tile costs ~3 VALU per 16-byte load (the fp32 MFMA shares issue
 // with the vector ALU: VALU in the loop is MFMA time lost).
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int FL_OOB = -16;
+constexpr int FL_OOB = (int)0x80000000;     // stays out of range (>= num_records = 2^31 - 1, unsigned) after any in-slice base is added
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t fl_srd(const float* p) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, 0x7FFFFFFF, 0x00020000);
 }
@@ -72,6 +72,16 @@ template <int DT>
 __device__ __forceinline__ void fl_prefetch(float4 (&reg)[FlTile<DT>::N], __amdgpu_buffer_rsrc_t srd, const FlStream<DT>& st, int row0,
                                             int limit, long ld) {
     const int base = (int)((long)row0 * ld * 4);          // wave-uniform
+    // with the fp32 MFMA every VALU instruction in the loop is MFMA time lost, so a full tile (the common case; wave-uniform test)
+    // costs ONE add per load: padding slots carry the sentinel 2^31, which stays out of range when the base is added
+    if (row0 + FlCfg<DT>::TK <= limit) {
+#pragma unroll
+        for (int j = 0; j < FlTile<DT>::N; ++j) {
+            u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(srd, (int)((unsigned)st.goff[j] + (unsigned)base), 0, 0);
+            reg[j] = make_float4(__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w));
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < FlTile<DT>::N; ++j) {
         bool ok = (st.goff[j] != FL_OOB) && (row0 + st.row[j] < limit);
@@ -81,9 +91,10 @@ __device__ __forceinline__ void fl_prefetch(float4 (&reg)[FlTile<DT>::N], __amdg
 }
 template <int DT>
 __device__ __forceinline__ void fl_store(float* T, const float4 (&reg)[FlTile<DT>::N], const FlStream<DT>& st) {
+    constexpr bool all_used = (FlCfg<DT>::TK * FlTile<DT>::Q) % 256 == 0;     // every thread slot holds a real float4: no per-lane test
 #pragma unroll
     for (int j = 0; j < FlTile<DT>::N; ++j)
-        if (st.loff[j] >= 0) {
+        if (all_used || st.loff[j] >= 0) {
             float* t = T + st.loff[j];                       // S2 is even: 8-byte aligned pairs
             *reinterpret_cast<float2*>(t) = make_float2(reg[j].x, reg[j].y);
             *reinterpret_cast<float2*>(t + 2) = make_float2(reg[j].z, reg[j].w);
