@@ -1,21 +1,20 @@
-// cb_gemm_glds.hip — the LDS-DMA MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X), bf16 (BASELINE config 3) and fp32
-// (config 2: every k-contiguous problem, i.e. all convolutions and Linear forwards), plus the register-staged bf16 kernel it replaced.
+// cb_gemm_glds.hip — the LDS-DMA MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X): bf16 (BASELINE config 3) and fp32
+// (config 2: every problem with two k-contiguous operands — all convolutions, Linear forwards, and Linear input gradients through
+// the transposed weight copy the engine keeps), the measured-plan autotuner, and the register-staged bf16 kernel it replaced.
 //
 //   C[M,N] = alpha * A[M,K] . B[N,K]^T + bias[n] + rowbias[img(m)][n] + R[m][n] + beta * C[m][n]
 //
-// A, B, C, R and rowbias are bf16 in HBM, the accumulator is fp32 (v_mfma_f32_32x32x16_bf16: 2.5 PF dense chip peak), bias
-// and the split-K partials are fp32. Both operands are k-contiguous (activations / conv gathers as A, [out][in] weights as B:
-// the host keeps a transposed copy of a Linear weight for its input gradient instead of an m-contiguous loader), 16-byte
-// aligned with K % 8 == 0, so every load is one branch-free `buffer_load_dwordx4` with hardware zero fill (cb_gemm_tiles.h).
-//
-// Structure = the fp32 kernel's (cb_gemm.hip): 256 threads = 4 wave64 in 2x2, each wave a (BM/2)x(BN/2) sub-tile of 32x32
-// MFMA tiles; a k-tile is 64 bytes per row = 32 bf16 (BK = 32); LDS image [row][4 x 16-byte chunks] XOR-swizzled by
-// (row >> 2) & 3, one conflict-free ds_write_b128 per global load and one conflict-free ds_read_b128 per MFMA operand.
-// A lane (row = lane & 31, kl = lane >> 5) owns the chunks 2*kl and 2*kl+1 of its row; MFMA step `half` feeds chunk 2*kl + half,
-// i.e. the 8 k-slots of half-wave kl hold k = 16*kl + 8*half .. +7 — any assignment of k to MFMA k-slots is a valid contraction
-// as long as A and B use the same one, and they do by construction.
-// What differs from fp32 is the balance: one k-tile is 2 x TM x TN MFMAs of 32 cycles (fp32: 8 x TM x TN of 64), so the kernel
-// is bound by the global->LDS staging, not by the matrix pipe; profiles/README.md (round 2) has the measurements.
+// A, B, C, R and rowbias are T (bf16 or fp32) in HBM, the accumulator is fp32 (v_mfma_f32_32x32x16_bf16: 2.5 PF dense chip peak;
+// v_mfma_f32_32x32x2_f32: 157.3 TF), bias and the split-K partials are fp32. Both operands are k-contiguous (activations / conv
+// gathers as A, [out][in] weights as B), 16-byte aligned with K a whole number of 16-byte chunks, so every load is one branch-free
+// `buffer_load_dwordx4` with hardware zero fill. File layout:
+//   1. `gemm_bf16_kernel` — round 2's first bf16 kernel, register staged like cb_gemm.hip (256 threads = 4 wave64 in 2x2, 64-byte
+//      rows = 32 bf16 per k-tile, LDS image XOR-swizzled by (row >> 2) & 3, one ds_write_b128 per global load); kept selectable
+//      (CB_BF16_GEMM=regs) as the A/B baseline: at bf16 MFMA rates its VGPR -> LDS store pass costs more than the MFMAs it feeds.
+//   2. `gemm_glds_kernel<T, ...>` / `gemm_glds256_kernel` — the LDS-DMA kernels (section "LDS-DMA variant" below): the default for
+//      both element types.
+//   3. host side: variant selection, eligibility of fp32 problems, offline autotuner (CB_AUTOTUNE), launch + split-K reduce.
+// profiles/README.md (round 2) has the measurements behind every choice.
 #include "cb_gemm_tiles.h"
 
 namespace cb {
