@@ -451,3 +451,33 @@ def test_argument_errors_on_a_dry_context(built_lib):
     assert "noise" in str(e.value)
     d = lib.GemmDesc(); d.M, d.N, d.K, d.batch = 0, 8, 8, 1
     assert L.cb_gemm(ctx.h, C.byref(d)) != 0 and b"shape" in L.cb_last_error()
+
+
+def test_plan_table_is_well_formed(tmp_path):
+    """celebbasis_amd/csrc/cb_plan_table.inc (generated by tools/make_plan_table.py from offline autotune records): every entry parses
+    as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (256x128 only for the bf16 64-element k-tile),
+    and the generator reproduces the committed table from the committed records (profiles/r02_autotune.txt)"""
+    import subprocess
+    import sys
+    inc = os.path.join(ROOT, "celebbasis_amd", "csrc", "cb_plan_table.inc")
+    lines = [l.strip() for l in open(inc) if l.strip().startswith('"') and len(l.strip()) > 2]
+    assert len(lines) > 100
+    keys = set()
+    for l in lines:
+        body = l.strip('"').replace("\\n", "")
+        key, bm, bn, sp = body.split()[:4]
+        f = key.split("|")
+        assert len(f) == 8 and key not in keys, key
+        keys.add(key)
+        bm, bn, sp = int(bm), int(bn), int(sp)
+        assert (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64), (256, 128)) and sp >= 1
+        if bm == 256:
+            assert f[0] == "64" and f[1] == "1"          # the 8-wave tile exists for bf16 (dtype code 1), 64-element k-tiles only
+        assert -(-int(f[5]) // int(f[0])) >= sp           # never more splits than k-tiles
+    before = open(inc).read()
+    try:
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py"), os.path.join(ROOT, "profiles", "r02_autotune.txt")],
+                             capture_output=True, text=True, check=True).stdout
+        assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of profiles/r02_autotune.txt"
+    finally:
+        open(inc, "w").write(before)
