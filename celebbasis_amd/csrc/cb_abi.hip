@@ -227,7 +227,8 @@ int cb_pack_conv_weight(cb_ctx* ctx, const float* w, void* out, int O, int I, in
     require(ctx, "ctx");
     Launch L = ctx->c.launch();
     const DType dt = ctx->c.dtype;
-    if (dgrad) k_pack_conv_dgrad(L, dt, out, w, O, I, ks, pad8c(dt, O)); else k_pack_conv(L, dt, out, w, O, I, ks, pad8c(dt, I));
+    if (dgrad == 2) { CB_CHECK(ks == 3, CB_ERR_ARG, "pack: the up-conv gradient pack is defined for 3x3 kernels"); k_pack_conv_up_dgrad(L, dt, out, w, O, I, pad8c(dt, O)); }
+    else if (dgrad) k_pack_conv_dgrad(L, dt, out, w, O, I, ks, pad8c(dt, O)); else k_pack_conv(L, dt, out, w, O, I, ks, pad8c(dt, I));
     CB_END
 }
 int cb_conv2d_fwd(cb_ctx* ctx, const void* x, const void* w_packed, const float* bias, const void* rowbias,
@@ -256,6 +257,7 @@ int cb_conv2d_dgrad(cb_ctx* ctx, const void* dy, const void* wd, void* dx, int N
     require(ctx, "ctx");
     Ctx* c = &ctx->c;
     Conv cv; cv.wd = const_cast<void*>(wd); cv.cin = Cin; cv.cout = Cout; cv.ks = ks;
+    if (mode == CB_CONV_UP_DGRAD4) { cv.wu = cv.wd; mode = CB_CONV_UP; }       // the dgrad = 2 pack: one 4x4 stride-2 conv over dy
     cv.dt = c->dtype; cv.cin_p = pad8c(cv.dt, Cin); cv.cout_p = pad8c(cv.dt, Cout);
     plan_and_run(c, [&]() {
         Graph G(c);

@@ -86,7 +86,7 @@ inline long rup(long a, long b) { return (a + b - 1) / b * b; }
 struct ConvGeom {
     int H = 0, W = 0, C = 0;    // source dims (NHWC), C = channels of the gathered tensor
     int Ho = 0, Wo = 0;         // output spatial dims
-    int ks = 3;                 // kernel size 1 or 3
+    int ks = 3;                 // kernel size 1 or 3 (2 and 4 on the LDS-DMA kernel: the 4x4 stride-2 up-conv input gradient)
     int stride = 1;             // step of the virtual coordinate per output pixel
     int pad = 1;                // top/left padding in virtual coordinates
     int up = 0;                 // 1: nearest-2x upsample fused: source pixel = virtual >> 1
@@ -236,6 +236,7 @@ void k_step_inc(const Launch& L, int* step);
 void k_gemv(const Launch& L, DType dt, void* y, const void* x, const void* W, const float* bias, int M, int N, int K);
 // weight packing (source: the fp32 state-dict tensor; packs are `dt` with the channel counts padded to Ip / Op >= I / O)
 void k_pack_conv(const Launch& L, DType dt, void* out, const float* w_oihw, int O, int I, int ks, int Ip);          // -> [O][ky][kx][Ip]
+void k_pack_conv_up_dgrad(const Launch& L, DType dt, void* out, const float* w, int O, int I, int Op);   // [I][4][4][Op], see cb_kernels.hip
 void k_pack_conv_dgrad(const Launch& L, DType dt, void* out, const float* w_oihw, int O, int I, int ks, int Op);   // -> [I][ky'][kx'][Op], flipped
 void k_pack_fc_nhwc(const Launch& L, float* out, const float* w, int O, int C, int HW);            // [O][C*HW] -> [O][HW*C]
 void k_fold_bn(const Launch& L, float* w_packed, float* bias_out, const float* bn_w, const float* bn_b,

@@ -102,7 +102,8 @@ struct Ten {
 // bf16 operands must be 16-byte chunks of 8 channels: the packs of a conv whose channel count is not a multiple of 8 (the RGB /
 // latent ends of the networks) are zero-padded to cin_p / cout_p and the op pads the activation to match.
 struct Conv { void* w = nullptr; void* wd = nullptr; float* b = nullptr; int cin = 0, cout = 0, ks = 3;
-              DType dt = DT_F32; int cin_p = 0, cout_p = 0; };
+              DType dt = DT_F32; int cin_p = 0, cout_p = 0;
+              void* wu = nullptr; /* CONV_UP layers on the gradient path: [I][4][4][O] pack of the 4x4 stride-2 input-gradient conv */ };
 struct Lin { void* w = nullptr; float* b = nullptr; int in = 0, out = 0;
              DType dt = DT_F32; int in_p = 0;
              void* wT = nullptr; /* [in][out]: bf16 dgrad operand (the bf16 GEMM takes k-contiguous operands only) */ };
@@ -148,7 +149,8 @@ void conv_dgrad(Graph* G, const void* dy, const Conv& cv, ConvMode mode, int N, 
 void plan_and_run(Ctx* ctx, const std::function<void()>& fn);
 
 // weight loading helpers (cb_engine.hip)
-Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias = true);
+Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias = true,
+               bool up_dgrad = false);
 Lin load_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out, bool bias = true);
 Lin load_conv1x1_as_linear(Ctx* ctx, const WTab& wt, const std::string& prefix, int in, int out);
 Lin load_linear_cat(Ctx* ctx, const WTab& wt, const std::vector<std::string>& prefixes, int in, int out_each, bool bias,

@@ -118,7 +118,7 @@ static void finish_linear(Ctx* ctx, Lin* l, float* w32) {
     }
 }
 
-Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias) {
+Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int cout, int ks, bool need_dgrad, bool bias, bool up_dgrad) {
     Conv c; c.cin = cin; c.cout = cout; c.ks = ks;
     c.dt = ctx->load_dt; c.cin_p = pad8(c.dt, cin); c.cout_p = pad8(c.dt, cout);
     Launch L = ctx->launch();
@@ -128,6 +128,10 @@ Conv load_conv(Ctx* ctx, const WTab& wt, const std::string& prefix, int cin, int
     if (need_dgrad) {
         c.wd = ctx->pool.alloc((size_t)cin * ks * ks * c.cout_p * dt_size(c.dt));
         k_pack_conv_dgrad(L, c.dt, c.wd, raw, cout, cin, ks, c.cout_p);
+    }
+    if (up_dgrad && ks == 3) {
+        c.wu = ctx->pool.alloc((size_t)cin * 16 * c.cout_p * dt_size(c.dt));
+        k_pack_conv_up_dgrad(L, c.dt, c.wu, raw, cout, cin, c.cout_p);
     }
     if (bias) c.b = ctx->upload(wt, prefix + ".bias", {cout});
     return c;
@@ -299,6 +303,13 @@ void conv_dgrad(Graph* G, const void* dy, const Conv& cv, ConvMode mode, int N, 
     } else if (mode == CONV_DOWN) {      // transposed stride-2 gather
         dg.Ho = H; dg.Wo = W; dg.tr = 1; dg.pad = 1;
         d.C = dx; d.beta = beta; d.M = N * H * W; d.g = dg;
+        run_gemm(G, d);
+    } else if (cv.wu && (cv.dt == DT_BF16 || cop % 4 == 0)) {
+        // CONV_UP with the combined pack: one 4x4 stride-2 pad-1 conv over dy (2H x 2W) straight into dx (cb_kernels.hip,
+        // pack_conv_up_dgrad_kernel): 16 * Cout MACs per input element instead of 36 * Cout, no temporary, no pooling pass
+        ConvGeom ug; ug.H = Ho; ug.W = Wo; ug.C = cop; ug.ks = 4; ug.stride = 2; ug.pad = 1; ug.Ho = H; ug.Wo = W;
+        d.B = cv.wu; d.K = 16 * cop; d.ldb = d.K;
+        d.C = dx; d.beta = beta; d.M = N * H * W; d.g = ug;
         run_gemm(G, d);
     } else {                              // CONV_UP: dgrad at the upsampled resolution, then 2x2 sum-pool
         dg.Ho = Ho; dg.Wo = Wo;

@@ -429,7 +429,7 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_CHECK(a.beta == 0.f || a.beta == 1.f, CB_ERR_ARG, "gemm: beta must be 0 or 1");
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
-        CB_CHECK(g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
+        CB_CHECK(g.ks >= 1 && g.ks <= 4, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
         CB_CHECK(a.K == g.ks * g.ks * g.C, CB_ERR_SHAPE, "conv: K=%d != %d*%d*%d", a.K, g.ks, g.ks, g.C);
         CB_CHECK(a.M % (g.Ho * g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, g.Ho * g.Wo);
         CB_CHECK(!(g.up && g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
@@ -437,6 +437,8 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     }
     CB_CHECK(a.dt == DT_F32, CB_ERR_ARG, "gemm: the fp32 kernel was handed a bf16 problem");
     if (gemm_f32_glds(L, a, ws, ws_bytes)) return;          // k-contiguous operands: the LDS-DMA kernel (cb_gemm_glds.hip)
+    if (a.a_kind == LD_CONV)
+        CB_CHECK(a.g.ks == 1 || a.g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d exists on the LDS-DMA kernel only (16-byte aligned operands, C %% 4 == 0)", a.g.ks);
     Plan pl = make_plan(a, BK, 1.0);
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
     L.count(pl.splitk > 1 ? 2 : 1);

@@ -240,13 +240,16 @@ template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GConvFast {   // pla
             if (r < R) {
                 int n = r / HWo, rem = r - n * HWo, oy = rem / g.Wo, ox = rem - oy * g.Wo;
                 int vy0 = oy * g.stride - g.pad, vx0 = ox * g.stride - g.pad;
-                if (g.ks == 3) {                                 // validity of the 9 taps = (3 row bits) x (3 column bits)
-                    unsigned xb = 0;
+                unsigned xb = 0, yb = 0;                             // validity of the ks x ks taps = (row bits) x (column bits), ks <= 4
 #pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) xb |= ((unsigned)(vx0 + kx) < (unsigned)g.W) ? (1u << kx) : 0u;
+                for (int k = 0; k < 4; ++k)
+                    if (k < g.ks) {
+                        xb |= ((unsigned)(vx0 + k) < (unsigned)g.W) ? (1u << k) : 0u;
+                        yb |= ((unsigned)(vy0 + k) < (unsigned)g.H) ? (1u << k) : 0u;
+                    }
 #pragma unroll
-                    for (int ky = 0; ky < 3; ++ky) m |= ((unsigned)(vy0 + ky) < (unsigned)g.H) ? (xb << (3 * ky)) : 0u;
-                } else m = ((unsigned)vy0 < (unsigned)g.H && (unsigned)vx0 < (unsigned)g.W) ? 1u : 0u;
+                for (int ky = 0; ky < 4; ++ky)
+                    if (ky < g.ks && ((yb >> ky) & 1u)) m |= xb << (g.ks * ky);
                 b = (((n * g.H + vy0) * g.W + vx0) * g.C + G::chunk(idx) * G::EPC) * ESZ;
             }
             vmask[i] = m; base[i] = b;
@@ -275,7 +278,7 @@ template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GConvGen {    // gen
 #pragma unroll
         for (int i = 0; i < N; ++i) {
             const int k = k0 + G::chunk(tid + i * NTHR) * G::EPC;
-            const int ky = (g.ks == 3) ? ((tap[i] * 11) >> 5) : 0, kx = tap[i] - ky * g.ks;
+            const int ky = conv_tap_row(tap[i], g.ks), kx = tap[i] - ky * g.ks;
             const int vy = vy0[i] + ky, vx = vx0[i] + kx;
             bool ok = (k < Kend) && (nb[i] >= 0) && ((unsigned)vy < (unsigned)Hv) && ((unsigned)vx < (unsigned)Wv);
             ok = ok && !(g.tr && ((vy | vx) & 1));
@@ -450,7 +453,7 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
 #pragma unroll
             for (int i = 0; i < NA; ++i) oa[i] = (ra.off[i] != OOB && k0 + kca[i] < kend) ? ra.off[i] + k0 * ESZ : OOB;
         } else if constexpr (AK == AK_CONVF) {
-            const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0, kx = tap_u - ky * a.g.ks;
+            const int ky = conv_tap_row(tap_u, a.g.ks), kx = tap_u - ky * a.g.ks;
             const int delta = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
             const bool in_k = k0 < kend;                       // C % BK == 0 and K = taps * C: a tile is entirely inside or outside K
 #pragma unroll
@@ -604,7 +607,7 @@ bool gemm_f32_glds_shape_ok(const GemmArgs& a) {
     if ((long)a.N * a.ldb >= lim) return false;
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
-        if (g.C % 4 || (g.ks != 1 && g.ks != 3) || a.K != g.ks * g.ks * g.C) return false;
+        if (g.C % 4 || g.ks < 1 || g.ks > 4 || a.K != g.ks * g.ks * g.C) return false;
         return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C < lim;
     }
     if (a.a_kind != LD_ROW || a.lda % 4 || a.sAb % 4 || a.sAh % 4) return false;
@@ -805,7 +808,8 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_CHECK(a.K % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: K=%d must be a multiple of 8 (16-byte chunks)", a.K);
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
-        CB_CHECK(g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
+        CB_CHECK(g.ks >= 1 && g.ks <= 4, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
+        CB_CHECK(gvariant().glds || g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d needs the LDS-DMA kernel", g.ks);
         CB_CHECK(a.K == g.ks * g.ks * g.C, CB_ERR_SHAPE, "conv: K=%d != %d*%d*%d", a.K, g.ks, g.ks, g.C);
         CB_CHECK(g.C % 8 == 0, CB_ERR_SHAPE, "conv bf16: C=%d must be a multiple of 8 (pad the channel axis)", g.C);
         CB_CHECK(a.M % (g.Ho * g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, g.Ho * g.Wo);

@@ -9,6 +9,11 @@
 
 namespace cb {
 
+// tap index -> kernel row for ks = 1 .. 4 (3: (t * 11) >> 5 == t / 3 for t < 9)
+__host__ __device__ __forceinline__ int conv_tap_row(int tap, int ks) {
+    return ks == 3 ? ((tap * 11) >> 5) : (ks == 4 ? (tap >> 2) : (ks == 2 ? (tap >> 1) : 0));
+}
+
 struct KArgs {
     GemmArgs a;
     int tiles_m, tiles_n;

@@ -1702,6 +1702,34 @@ template <typename T> __global__ void pack_conv_dgrad_kernel(T* __restrict__ out
 void k_pack_conv_dgrad(const Launch& L, DType dt, void* out, const float* w, int O, int I, int ks, int Op) {
     CB_DT_SWITCH(dt, T, LAUNCH((pack_conv_dgrad_kernel<T>), grid1d((long)Op * I * ks * ks), dim3(256), L, (T*)out, w, O, I, ks, Op));
 }
+// Input gradient of "nearest x2 upsample + conv3x3" (openaimodel.py Upsample) as ONE 4x4 stride-2 pad-1 convolution over dy:
+// output pixel i of the low-resolution input receives dy rows {2i-1, 2i, 2i+1, 2i+2} with the 3 kernel rows combined as
+// {w2, w1+w2, w0+w1, w0} (same along x): 16 taps per input pixel instead of 4 positions x 9 taps, 2.25x fewer MACs, no
+// full-resolution temporary and no pooling pass. OIHW -> [I][ty][tx][O] (O padded to Op): the B operand of that conv's GEMM.
+template <typename T> __global__ void pack_conv_up_dgrad_kernel(T* __restrict__ out, const float* __restrict__ w, int O, int I, int Op) {
+    long total = (long)Op * I * 16;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        int co = (int)(i % Op);
+        long r = i / Op;
+        int tx = (int)(r % 4);
+        r /= 4;
+        int ty = (int)(r % 4);
+        long ci = r / 4;
+        float v = 0.f;
+        if (co < O) {
+            const float* wk = w + ((long)co * I + ci) * 9;
+            // taps of combined row t: t = 0 -> {2}, 1 -> {1, 2}, 2 -> {0, 1}, 3 -> {0}
+            const int y0 = ty == 0 ? 2 : (ty == 1 ? 1 : 0), y1 = ty == 3 ? 0 : (ty == 2 ? 1 : 2);
+            const int x0 = tx == 0 ? 2 : (tx == 1 ? 1 : 0), x1 = tx == 3 ? 0 : (tx == 2 ? 1 : 2);
+            for (int ky = y0; ky <= y1; ++ky)
+                for (int kx = x0; kx <= x1; ++kx) v += wk[ky * 3 + kx];
+        }
+        st1(out + i, v);
+    }
+}
+void k_pack_conv_up_dgrad(const Launch& L, DType dt, void* out, const float* w, int O, int I, int Op) {
+    CB_DT_SWITCH(dt, T, LAUNCH((pack_conv_up_dgrad_kernel<T>), grid1d((long)Op * I * 16), dim3(256), L, (T*)out, w, O, I, Op));
+}
 // fc over torch.flatten(NCHW): w[o][c*HW + hw] -> out[o][hw*C + c]   (iresnet.py:176-179)
 __global__ void pack_fc_nhwc_kernel(float* __restrict__ out, const float* __restrict__ w, int O, int C, int HW) {
     long total = (long)O * C * HW;

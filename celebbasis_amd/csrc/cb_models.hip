@@ -95,7 +95,7 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
             if (in_attn(ds)) { b.has_xf = true; b.xf = load_xfmr(ctx, wt, bp + ".1", ch, cfg.num_heads, cfg.context_dim, &kvc); sub = 2; }
             if (level && i == cfg.num_res_blocks) {
                 b.has_up = true;
-                b.up = load_conv(ctx, wt, bp + "." + std::to_string(sub) + ".conv", ch, ch, 3, true);
+                b.up = load_conv(ctx, wt, bp + "." + std::to_string(sub) + ".conv", ch, ch, 3, true, true, /*up_dgrad=*/true);
                 ds /= 2;
             }
             U->out_blocks.push_back(b);

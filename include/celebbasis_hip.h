@@ -84,7 +84,8 @@ int cb_wtab_add(cb_wtab* wt, const char* name, const float* data, int on_device,
 int cb_wtab_destroy(cb_wtab* wt);
 
 /* ---- op level (each replaces one torch op family on the reference hot path) ---------------------- */
-typedef enum { CB_CONV_SAME = 0, CB_CONV_DOWN = 1, CB_CONV_DOWN_ASYM = 2, CB_CONV_UP = 3, CB_CONV_S2_1X1 = 4 } cb_conv_mode;
+typedef enum { CB_CONV_SAME = 0, CB_CONV_DOWN = 1, CB_CONV_DOWN_ASYM = 2, CB_CONV_UP = 3, CB_CONV_S2_1X1 = 4,
+               CB_CONV_UP_DGRAD4 = 5 /* cb_conv2d_dgrad only: CB_CONV_UP's input gradient from the dgrad = 2 pack */ } cb_conv_mode;
 typedef enum { CB_LD_ROW = 0, CB_LD_COL = 1 } cb_operand_layout;
 
 /* C[M,N] = alpha * A.B + bias[n] + R + beta*C, batched; ROW = K contiguous, COL = M/N contiguous.
@@ -106,7 +107,9 @@ int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
  * launch of this process; (0, 0, 0) releases it. Process-global, not thread safe — never call it in production code. */
 int cb_debug_force_plan(int BM, int BN, int split);
 
-/* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped. */
+/* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped; dgrad=2 (3x3 only):
+ * [I][4][4][O], the input gradient of "nearest x2 upsample + conv3x3" (openaimodel.py Upsample) as ONE 4x4 stride-2 pad-1 conv over dy
+ * (kernel rows combined as {w2, w1+w2, w0+w1, w0}): 2.25x fewer MACs than differentiating at the upsampled resolution. */
 /* the source is the float32 state-dict tensor; the pack is in the context's dtype. bf16 packs pad the contiguous channel axis to a
  * multiple of 8: [O][ky][kx][ceil8(I)] resp. [I][ky'][kx'][ceil8(O)] (zero filled). */
 int cb_pack_conv_weight(cb_ctx* ctx, const float* w_oihw, void* out, int O, int I, int ks, int dgrad);

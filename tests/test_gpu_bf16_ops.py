@@ -176,6 +176,14 @@ def test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, extra):
             lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(dyd, BF), lib.ptr(wpd, BF), lib.ptr(dx, BF), N, H, W, Cin, Cout, ks, MODES[mode], beta))
             ctx.sync()
             close(tag + f".dgrad[beta{beta}]", dx.float().permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), TOL)
+        if mode == "up":       # the combined 4x4 stride-2 gradient conv (dgrad = 2 pack)
+            wpu = torch.empty(Cin * 16 * cout_p, dtype=BF, device=_dev())
+            lib.check(L.cb_pack_conv_weight(ctx.h, lib.ptr(wd), lib.ptr(wpu, BF), Cout, Cin, ks, 2))
+            dx = d16(dx0)
+            dyd = d16(nhwc(dy))
+            lib.check(L.cb_conv2d_dgrad(ctx.h, lib.ptr(dyd, BF), lib.ptr(wpu, BF), lib.ptr(dx, BF), N, H, W, Cin, Cout, ks, 5, 1.0))
+            ctx.sync()
+            close(tag + ".dgrad4x4[beta1.0]", dx.float().permute(0, 3, 1, 2), dx_ref + dx0.permute(0, 3, 1, 2), TOL)
 
 
 # ------------------------------------------------------------------------------------------------ norms / GEGLU

@@ -143,6 +143,7 @@ def torch_conv(x_nchw, w, b, mode):
     (2, 16, 16, 32, 32, 3, "down", "none"),
     (2, 16, 16, 32, 32, 3, "down_asym", "none"),
     (2, 8, 8, 32, 32, 3, "up", "none"),
+    (1, 9, 7, 36, 20, 3, "up", "none"),             # odd sizes, channels % 32 != 0: the general gather of the 4x4 gradient conv
     (2, 14, 14, 32, 64, 1, "s2_1x1", "none"),
 ])
 def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
@@ -180,6 +181,14 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
             lib.check(L.cb_conv2d_dgrad(ctx.h, HOLD(nhwc(dy)), lib.ptr(wpd), lib.ptr(dx), N, H, W, Cin, Cout, ks, MODES[mode], beta))
             ctx.sync()
             close(tag + f".dgrad(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
+        if mode == "up":       # the same gradient as ONE 4x4 stride-2 conv over dy (dgrad = 2 pack, what the UNet's Upsample layers use)
+            wpu = torch.empty(Cin * 16 * Cout, device=_dev())
+            lib.check(L.cb_pack_conv_weight(ctx.h, lib.ptr(wd), lib.ptr(wpu), Cout, Cin, ks, 2))
+            for beta in (0.0, 1.0):
+                dx = dx0.clone().to(_dev())
+                lib.check(L.cb_conv2d_dgrad(ctx.h, HOLD(nhwc(dy)), lib.ptr(wpu), lib.ptr(dx), N, H, W, Cin, Cout, ks, 5, beta))
+                ctx.sync()
+                close(tag + f".dgrad4x4(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
 
 
 # ------------------------------------------------------------------------------------------------ norms

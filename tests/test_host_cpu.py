@@ -55,8 +55,9 @@ def test_dry_training_step_accounting(built_lib):
     ctx.reset_stats(); u.forward(x, t, c, need_grad=False); fwd = gf()
     ctx.reset_stats(); u.forward(x, t, c, need_grad=True); both = gf()
     assert abs(fwd - 803.3) < 0.5, fwd                       # UNet forward 803.3 GFLOP
-    # backward to the context: 865.9 GFLOP by autograd; +17 GFLOP here because the stride-2 dgrad gathers all 9 taps
-    assert abs((both - fwd) - 865.9) < 18.0, both - fwd
+    # backward to the context: 865.9 GFLOP by autograd; here +17.0 (the stride-2 dgrad gathers all 9 taps) and -37.8 (the three
+    # Upsample layers' input gradients run as one 4x4 stride-2 conv over dy: 16 instead of 36 taps per input element) = 845.1
+    assert abs((both - fwd) - 845.1) < 0.5, both - fwd
     v = lib.VAE(ctx, wt, lib.vae_cfg(), prefix="first_stage_model.")
     ctx.reset_stats(); v.encode(torch.zeros(1, 512, 512, 3)); assert abs(gf() - 1116.7) < 0.5
     f = lib.FrNet(ctx, wt, prefix="embedding_manager.meta_id_net.id_model.")
@@ -64,7 +65,7 @@ def test_dry_training_step_accounting(built_lib):
     tr = lib.Trainer(ctx, wt)
     ctx.reset_stats(); tr.step(1, None, None, None, None, None, None, 5e-3)
     st = ctx.stats()
-    assert 2850 < st["gemm_flops"] / 1e9 < 2900             # ~2.86 TFLOP / step (SURVEY §8 d)
+    assert 2820 < st["gemm_flops"] / 1e9 < 2860             # 2.84 TFLOP / step (SURVEY §8 d: 2.86 by autograd's count, -37.8 G in the up-conv gradients)
     assert st["arena_peak_bytes"] < 40 * 2 ** 30 and st["pool_bytes"] < 24 * 2 ** 30
     ctx.reset_stats(); tr.step(4, None, None, None, None, None, None, 5e-3)
     assert ctx.stats()["gemm_flops"] / 1e9 > 4 * 2800        # scales with the batch
