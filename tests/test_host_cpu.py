@@ -482,3 +482,24 @@ def test_plan_table_is_well_formed(tmp_path):
         assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of profiles/r02_autotune.txt"
     finally:
         open(inc, "w").write(before)
+
+
+def test_upsample_conv_gradient_identity():
+    """the algebra behind CB_CONV_UP_DGRAD4 / pack_conv_up_dgrad_kernel, checked against torch autograd on the CPU (float64): the input
+    gradient of `conv3x3(nearest_upsample_x2(x))` (openaimodel.py Upsample) equals ONE 4x4 stride-2 pad-1 convolution over dy whose kernel
+    rows / columns are the 3x3 kernel's combined as {w2, w1+w2, w0+w1, w0}"""
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(0)
+    N, C, Co, H, W = 2, 5, 7, 6, 9
+    x = torch.randn(N, C, H, W, dtype=torch.float64, generator=g).requires_grad_(True)
+    w = torch.randn(Co, C, 3, 3, dtype=torch.float64, generator=g)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), w, padding=1)
+    dy = torch.randn(y.shape, dtype=torch.float64, generator=g)
+    (dx_ref,) = torch.autograd.grad((y * dy).sum(), x)
+
+    def comb(t, dim):
+        w0, w1, w2 = t.select(dim, 0), t.select(dim, 1), t.select(dim, 2)
+        return torch.stack([w2, w1 + w2, w0 + w1, w0], dim=dim)
+    w4 = comb(comb(w, 2), 3)                                          # [Co, C, 4, 4]
+    dx = F.conv2d(dy, w4.transpose(0, 1), stride=2, padding=1)
+    assert dx.shape == dx_ref.shape and (dx - dx_ref).abs().max().item() < 1e-12
