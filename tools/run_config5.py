@@ -5,7 +5,7 @@ VAE decode), exactly the two halves `01_start_train.sh` + `02_start_test.sh` run
 Synthetic weights / faces (no checkpoints or datasets offline). One JSON line with the end-to-end wall-clock.
 
     python tools/run_config5.py --identities 4 --train-steps 100                                   # 1 GPU, scaled down
-    python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/run_config5.py --identities 32
+    python tools/run_config5.py --gpus 8 --identities 32                                           # 8 ranks (launches itself under torch.distributed.run)
 """
 import argparse
 import ctypes as C
@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=0, help="ranks of this node; > 1 without a launcher environment: re-executes itself under "
+                                                         "torch.distributed.run (same rule as bench.py); 0 = take WORLD_SIZE as it is")
     ap.add_argument("--identities", type=int, default=4, help="total identities of the job (config 5: 32)")
     ap.add_argument("--train-steps", type=int, default=800, help="steps per identity (aigc_id.yaml:135 max_steps 800)")
     ap.add_argument("--batch", type=int, default=2)
@@ -30,7 +32,18 @@ def main():
     ap.add_argument("--scale", type=float, default=10.0)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:            # `python tools/run_config5.py --gpus 8`: become the launcher
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        os.execvp(cmd[0], cmd)
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus and world != a.gpus:
+        raise SystemExit(f"run_config5.py --gpus {a.gpus} was started with WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -113,6 +126,8 @@ def main():
     if world > 1:
         dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
     if rank == 0:
+        n_merged = int((merged.abs().sum(dim=1) > 0).sum().item())
+        assert n_merged == a.identities, f"checkpoint merge returned {n_merged} of {a.identities} identities"
         el = float(elapsed.item())
         print(json.dumps({"metric": "config 5 end-to-end: personalise + DDIM sample, identities/sec", "value": round(a.identities / el, 5),
                           "unit": "identities/s", "n_gpus": world, "identities": a.identities, "train_steps_per_identity": a.train_steps,
