@@ -15,9 +15,9 @@ collective is the checkpoint-merge all_gather after the timed region (RCCL), who
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   `roofline`      dominant kernel of the fp32 step, measured live with HIP events around every GEMM-class launch of one extra
-                  step; the HBM-bound groups (GroupNorm / LayerNorm / split-K reduce) additionally carry the per-symbol averages of
-                  the committed rocprofv3 trace (profiles/*_bench_kernel_stats.csv): an event pair around a ~5 us kernel reads ~2.5x
-                  too long, the trace does not;
+                  step. Numbers of the committed rocprofv3 trace / PMC passes (profiles/r03*) are added next to the live ones ONLY
+                  when their stamp (sha of the kernel sources + plan table, `build`) is this tree's; otherwise `profile_stale` is
+                  true and the line carries live measurements alone;
   `cpu_baseline`  the CPU oracle (a from-scratch restatement = kind "port") timed on this box's host cores on a bounded sample;
   `config3`       secondary measurement, N == 1 only: BASELINE config 3 (bf16 UNet / VAE + fp32 coefficient gradient, bs=4) with its
                   own dominant-kernel roofline against the 2.5 PF dense bf16 MFMA peak. Never used for `value`.
@@ -43,38 +43,52 @@ PEAK_HBM_GBPS = 8000.0
 STEPS_PER_IDENTITY = 800           # aigc_id.yaml:135 max_steps
 
 
-def pmc_traffic(kernel):
-    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
-    separate passes and cannot be collected inside this process): profiles/*_pmc_hbm_traffic.json, written by
-    tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Returns (bytes | None, detail)."""
-    import glob
+def trace_symbol(kernel):
+    """profiler label (`gemm_glds_kernel<float,128,128,CONVF>`) -> rocprofv3 symbol as tools/prof_stats.py / pmc_traffic.py write it"""
     import re
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_hbm_traffic.json")))
-    if not files:
-        return None, None
     kinds = {"ROW": 0, "COL": 1, "CONV": 2, "CONVF": 3}
     m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+),(\w+)(,generic)?>", kernel)
     m4 = re.match(r"gemm_kernel_occ4<(\w+),(\w+)>", kernel)
     mg = re.match(r"gemm_glds_kernel<(float|bf16),(\d+),(\d+),(\w+)>", kernel)       # LDS-DMA kernel: <T, BM, BN, AK, row bytes, stages>
     if mg:
         ak = {"ROW": 0, "CONV": 1, "CONVF": 2}[mg.group(4)]
-        sym = f"gemm_glds_kernel<{'float' if mg.group(1) == 'float' else '__bf16'}, {mg.group(2)}, {mg.group(3)}, {ak}, 128, 2>"
-    elif m:
-        sym = f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
-    elif m4:
-        sym = f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"
-    else:
+        return f"gemm_glds_kernel<{'float' if mg.group(1) == 'float' else '__bf16'}, {mg.group(2)}, {mg.group(3)}, {ak}, 128, 2>"
+    if m:
+        return f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
+    if m4:
+        return f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"
+    return None
+
+
+def tree_stamp():
+    from celebbasis_amd.build import source_digest
+    return source_digest()
+
+
+def pmc_traffic(kernel, bf16=False):
+    """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
+    separate passes and cannot be collected inside this process): profiles/r03*_pmc_hbm_traffic{,_config3}.json, written by
+    tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Corrected as MI355X_MICROARCH.md's HBM
+    section prescribes for gfx950: FETCH_SIZE tallies the 128-B requests of 16-B/lane reads and `buffer_load ... lds` at 64 B, so
+    traffic = 2 x FETCH_SIZE + WRITE_SIZE. The file is used only when it was measured on THIS tree (stamp = sha of the kernel
+    sources + plan table); otherwise (None, {"stale": ...}). Returns (bytes | None, detail)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03*_pmc_hbm_traffic{'_config3' if bf16 else ''}.json")))
+    sym = trace_symbol(kernel)
+    if not files or sym is None:
         return None, None
     d = json.load(open(files[-1]))
+    if d.get("stamp") != tree_stamp():
+        return None, dict(source=os.path.basename(files[-1]), stale=True, file_stamp=d.get("stamp"), tree_stamp=tree_stamp())
     e = d.get("per_symbol", {}).get(sym)
     if not e or e["fetch_bytes_per_launch"] is None or e["write_bytes_per_launch"] is None:
         return None, None
-    raw = e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
-    detail = dict(source=os.path.basename(files[-1]), symbol=sym, launches=e["launches"],
-                  fetch_bytes_per_launch=round(e["fetch_bytes_per_launch"]), write_bytes_per_launch=round(e["write_bytes_per_launch"]),
-                  fetch_x2_bytes_per_launch=round(2 * e["fetch_bytes_per_launch"]),
-                  note="FETCH_SIZE as reported (lower bound); x2 = the guide's gfx950 correction for wide coalesced reads (upper bound)")
-    return round(raw), detail
+    corrected = 2 * e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
+    detail = dict(source=os.path.basename(files[-1]), symbol=sym, launches=e["launches"], stale=False,
+                  fetch_size_bytes_per_launch_raw=round(e["fetch_bytes_per_launch"]), write_size_bytes_per_launch=round(e["write_bytes_per_launch"]),
+                  note="traffic = 2 x FETCH_SIZE + WRITE_SIZE (gfx950: FETCH_SIZE counts the 128-B requests of 16-B/lane and LDS-DMA reads "
+                       "at 64 B); L2-miss traffic that the 256 MiB Infinity Cache may still serve, i.e. an upper bound of HBM bytes proper")
+    return round(corrected), detail
 
 
 # kernel symbols behind each HBM-bound profiler group (rocprofv3 names, `cb::` stripped as tools/prof_stats.py writes them)
@@ -86,22 +100,30 @@ HBM_GROUP_SYMBOLS = {
 }
 
 
-def rocprof_symbol_ms(bf16=False, prefix="r02"):
-    """per-symbol milliseconds per step of the newest committed rocprofv3 kernel trace: profiles/<prefix>*_bench_kernel_stats.csv is
-    the trace of `bench.py --no-config3` (the fp32 step alone), profiles/<prefix>*_config3_kernel_stats.csv the trace of
-    `bench.py --trace-leg config3` (the bf16 bs=4 step alone; its fp32 CLIP / FR-net kernels included)"""
+def rocprof_trace(bf16=False, prefix="r03"):
+    """the newest committed rocprofv3 kernel trace of this leg — profiles/<prefix>*_bench_kernel_stats.csv = `bench.py --no-config3`
+    (the fp32 step alone), profiles/<prefix>*_config3_kernel_stats.csv = `bench.py --trace-leg config3` — if and only if its
+    stamp line says it was taken on THIS tree. Returns (file | None, stale, {symbol: (calls_per_step, ms_per_step, avg_us)},
+    {base name: ms_per_step})."""
     import csv
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"{prefix}*_{'config3' if bf16 else 'bench'}_kernel_stats.csv")))
     if not files:
-        return None, {}
-    out = {}
+        return None, None, {}, {}
     with open(files[-1]) as f:
-        rows = [r for r in f if not r.startswith("#")]
-    for r in csv.DictReader(rows):
-        base = r["name"].split("<")[0]
-        out[base] = out.get(base, 0.0) + float(r["ms_per_step"])
-    return os.path.basename(files[-1]), out
+        lines = f.readlines()
+    st = tree_stamp()
+    head = next((l for l in lines if l.startswith("# stamp")), "")
+    kv = dict(t.split("=", 1) for t in head.split()[2:] if "=" in t)
+    if kv.get("src_sha") != st["src_sha"] or kv.get("plan_table_sha") != st["plan_table_sha"]:
+        return os.path.basename(files[-1]), True, {}, {}
+    nsteps = int(kv.get("nsteps", "9"))
+    per, base = {}, {}
+    for r in csv.DictReader([l for l in lines if not l.startswith("#")]):
+        per[r["name"]] = (int(r["calls"]) / nsteps, float(r["ms_per_step"]), float(r["avg_us"]))
+        b_ = r["name"].split("<")[0]
+        base[b_] = base.get(b_, 0.0) + float(r["ms_per_step"])
+    return os.path.basename(files[-1]), False, per, base
 
 
 def maybe_self_launch(args):
@@ -141,7 +163,11 @@ def timed_loop(run, steps, warmup, world, dist, dev, dry):
 
 
 def profile_step(ctx, run, peak_tflops, bf16=False):
-    """one extra step with a HIP-event pair around every GEMM-class launch -> (roofline dict, phases, stats)"""
+    """one extra step with a HIP-event pair around every GEMM-class launch -> (roofline dict, phases, stats).
+    Live events are the evidence for `achieved` (the dominant kernel's launches last 100+ us). An event pair around a sub-30 us
+    launch reads long (fixed ~5 us of dispatch + signal latency per pair), so every per-variant row ALSO carries `ms_trace` — the
+    rocprofv3 per-symbol time of the committed trace — but only when that trace was taken on this very tree (`profile_stale`
+    false); a stale trace is never mixed into the line."""
     ctx.reset_stats()
     ctx.profile_begin()
     run(0)
@@ -152,19 +178,27 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
     hbm = [p for p in prof if p.get("bytes", 0) > 0 and p["flops"] == 0]    # HBM-bound groups: algorithmic bytes
     prof = [p for p in prof if p["flops"] > 0]                             # MFMA-bound launches (GEMM family + fused attention)
     tot_ms = sum(p["ms"] for p in prof); tot_fl = sum(p["flops"] for p in prof)
-    # dominant kernel = the variant that carries the most algorithmic FLOPs of the step. (Ranking by summed live event time is not
-    # robust: an event pair around a ~10 us launch reads ~2x long, so a variant with many short launches can outrank the kernel that
-    # does half of the step's work; the rocprofv3 trace ranks them the same way as the FLOPs do.)
+    # dominant kernel = the variant that carries the most algorithmic FLOPs of the step
     dom = max(prof, key=lambda p: p["flops"])
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
-    src, sym_ms = rocprof_symbol_ms(bf16)
+    src, stale, per_sym, sym_ms = rocprof_trace(bf16)
+
+    def trace_ms(p):
+        """(ms per step, launches per step) of a profiler row in the matching trace, or (None, None)"""
+        sym = trace_symbol(p["kernel"])
+        if sym in per_sym:
+            return per_sym[sym][1], per_sym[sym][0]
+        base = p["kernel"].split("<")[0].split("[")[0]
+        same = [q for q in prof if q["kernel"].split("<")[0].split("[")[0] == base]
+        if base.startswith("flash") and len(same) == 1 and base + "_kernel" in sym_ms:
+            return sym_ms[base + "_kernel"], None
+        return None, None
+
     hb = []
     for p in sorted(hbm, key=lambda p: -p["ms"]):
-        e = dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1), ms_events=round(p["ms"], 3),
-                 gbps_events=round(p["bytes"] / (p["ms"] * 1e-3) / 1e9, 1))
-        hb.append(e)
-    # rocprofv3 view of the same groups: the trace has one duration per symbol, so a group's size classes and its SiLU / plain
-    # variants (same three GroupNorm symbols) are merged
+        hb.append(dict(kernel=p["kernel"], launches=p["launches"], algorithmic_mb=round(p["bytes"] / 1e6, 1), ms_events=round(p["ms"], 3)))
+    # rocprofv3 view of the HBM-bound groups: the trace has one duration per symbol, so a group's size classes and its SiLU / plain
+    # variants (same GroupNorm symbols) are merged
     groups = {}
     for p in hbm:
         g = p["kernel"].split("[")[0].replace("<bf16>", "").replace("groupnorm_silu_", "groupnorm_")
@@ -172,30 +206,62 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
         a["bytes"] += p["bytes"]; a["launches"] += p["launches"]
     rp = []
     for g, a in groups.items():
-        syms = HBM_GROUP_SYMBOLS.get(g)
-        if not syms or not all(s in sym_ms for s in syms):
+        syms = [s for s in HBM_GROUP_SYMBOLS.get(g, ()) if s in sym_ms]
+        if not syms:
             continue
         ms = sum(sym_ms[s] for s in syms)
         rp.append(dict(kernel=g, symbols=list(syms), launches=a["launches"], algorithmic_mb=round(a["bytes"] / 1e6, 1), ms_rocprof=round(ms, 3),
                        achieved_gbps=round(a["bytes"] / (ms * 1e-3) / 1e9, 1), frac_of_8tbps=round(a["bytes"] / (ms * 1e-3) / 1e9 / PEAK_HBM_GBPS, 4)))
+    dom_tr, dom_tr_launches = trace_ms(dom)
+    rows = []
+    for p in sorted(prof, key=lambda p: -p["flops"]):
+        tms, tl = trace_ms(p)
+        rows.append(dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms_events=round(p["ms"], 3),
+                         ms_trace=None if tms is None else round(tms, 3), launches_trace=None if tl is None else round(tl, 2),
+                         tflops_trace=None if not tms else round(p["flops"] / (tms * 1e-3) / 1e12, 2)))
+    covered = [r for r in rows if r["ms_trace"]]
     roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
                     frac=round(ach / peak_tflops, 4), traffic=None, traffic_detail=None,
                     launches_per_step=dom["launches"], avg_launch_ms=round(dom["ms"] / dom["launches"], 5),
                     algorithmic_gflop_per_step=round(dom["flops"] / 1e9, 1),
                     algorithmic_bytes_per_launch=round(dom.get("bytes", 0) / dom["launches"]),
-                    all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_per_step=round(tot_ms, 3),
-                                          achieved=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2)),
-                    attention_mfma=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3),
-                                         achieved_tflops=round(p["flops"] / (p["ms"] * 1e-3) / 1e12, 2),
-                                         frac_of_peak=round(p["flops"] / (p["ms"] * 1e-3) / 1e12 / peak_tflops, 4))
-                                    for p in prof if p["kernel"].startswith("flash")],
-                    by_kernel=[dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms=round(p["ms"], 3))
-                               for p in sorted(prof, key=lambda p: -p["ms"])],
-                    hbm_bound=dict(source_rocprof=src,
-                                   note="ms_events = live HIP-event pairs (a pair around a ~5 us kernel reads ~2.5x long); rocprof = per-symbol "
-                                        "averages of the committed rocprofv3 --kernel-trace of this same command — use those for bandwidth",
+                    profile_source=src, profile_stale=stale,
+                    rocprof=None if dom_tr is None else dict(
+                        launches_per_step=dom_tr_launches, avg_launch_ms=round(dom_tr / max(dom_tr_launches or dom["launches"], 1), 5),
+                        achieved=round(dom["flops"] / (dom_tr * 1e-3) / 1e12, 2), frac=round(dom["flops"] / (dom_tr * 1e-3) / 1e12 / peak_tflops, 4),
+                        note="same algorithmic FLOPs over the committed rocprofv3 trace's total time for this symbol (trace taken on this tree)"),
+                    all_gemm_kernels=dict(gflop_per_step=round(tot_fl / 1e9, 1), ms_events=round(tot_ms, 3),
+                                          achieved_events=round(tot_fl / (tot_ms * 1e-3) / 1e12, 2),
+                                          ms_trace=round(sum(r["ms_trace"] for r in covered), 3) if covered else None,
+                                          achieved_trace=round(sum(r["gflop"] for r in covered) / sum(r["ms_trace"] for r in covered), 2) if covered else None,
+                                          trace_covers_gflop=round(sum(r["gflop"] for r in covered), 1) if covered else None,
+                                          note="event pairs around sub-30 us launches read long: *_events is a lower bound of the rate; *_trace "
+                                               "(present only with a trace of this tree) is the per-symbol rocprofv3 time"),
+                    attention_mfma=[dict(kernel=r["kernel"], launches=r["launches"], gflop=r["gflop"], ms_events=r["ms_events"], ms_trace=r["ms_trace"],
+                                         frac_of_peak_events=round(r["gflop"] / r["ms_events"] / peak_tflops, 4),
+                                         frac_of_peak_trace=None if not r["ms_trace"] else round(r["gflop"] / r["ms_trace"] / peak_tflops, 4))
+                                    for r in rows if r["kernel"].startswith("flash")],
+                    by_kernel=rows,
+                    hbm_bound=dict(note="bandwidth of the HBM-bound groups is quoted from the rocprofv3 per-symbol times of a trace of THIS tree only "
+                                        "(`rocprof`, empty when profile_stale); `events` lists the live event-pair sums, which read ~2.5x long on 5 us kernels",
                                    rocprof=rp, events=hb))
     return roofline, phases, st
+
+
+def frac_range(value, bf16=False):
+    """roofline.frac of the dominant kernel over the committed bench lines of THIS tree (profiles/BENCH_r03_run*.json with the same
+    stamp: other boxes of the pool) plus this run: [min, max, n]"""
+    import glob
+    st, vals = tree_stamp(), [value]
+    for p in glob.glob(os.path.join(ROOT, "profiles", "BENCH_r03_run*.json")):
+        try:
+            d = json.load(open(p))
+            if d.get("build") == st:
+                r = d["config3"]["roofline"] if bf16 else d["roofline"]
+                vals.append(r["frac"])
+        except Exception:
+            pass
+    return [min(vals), max(vals), len(vals)]
 
 
 def main():
@@ -306,6 +372,7 @@ def main():
         else:
             roofline, phases, st = profile_step(ctx, run, PEAK_FP32_MFMA_TFLOPS)
             roofline["traffic"], roofline["traffic_detail"] = pmc_traffic(roofline["kernel"])
+            roofline["frac_range_boxes"] = frac_range(roofline["frac"])
         out = {
             "metric": "personalization train steps/sec @ SD v1-4 512x512 bs=1", "value": round(value, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -322,6 +389,7 @@ def main():
             "phase_ms": phases,
             "pipelined": pipelined,
             "merged_identities": merged_identities,
+            "build": tree_stamp(),
             "roofline": roofline,
         }
         if dry:
@@ -341,7 +409,8 @@ def main():
             tr3.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr3)
         el3 = timed_loop(run3, args.steps, args.warmup, 1, dist, dev, False)
         rf3, ph3, st3 = profile_step(ctx3, run3, PEAK_BF16_MFMA_TFLOPS, bf16=True)
-        rf3["traffic"], rf3["traffic_detail"] = pmc_traffic(rf3["kernel"])
+        rf3["traffic"], rf3["traffic_detail"] = pmc_traffic(rf3["kernel"], bf16=True)
+        rf3["frac_range_boxes"] = frac_range(rf3["frac"], bf16=True)
         ms3 = el3 / args.steps * 1e3
         out["config3"] = {"workload": "BASELINE config 3: single identity, SD v1-4 512x512, bs=4, bf16 UNet / VAE (storage + MFMA), fp32 CLIP / "
                                       "coefficient head / gradient / AdamW, full step", "dtype": "bf16", "batch": B3,

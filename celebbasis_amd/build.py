@@ -23,6 +23,26 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # (flash_fwd<3> 128 -> 100, flash_bwd_dkv<3> 256 -> 178). CB_MFMA_VGPR_FORM=0 restores the default (A/B measurements).
 EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_VGPR_FORM", "1") != "0" else [])
          for src in ("cb_flash.hip", "cb_flash_bf16.hip")}
+# Kernels whose software pipeline COUNTS its outstanding VMEM instructions (`s_waitcnt vmcnt(N)` + raw `s_barrier`,
+# cb_gemm_glds.hip): a register spill would add scratch loads / stores to that count and let a tile be read before it has landed.
+# The build therefore fails if any kernel of these files has scratch, spills or a dynamic stack (-Rpass-analysis remarks).
+NO_SCRATCH = {"cb_gemm_glds.hip": "gemm_glds"}
+
+
+def source_digest():
+    """Identity of the native code a tree builds: sha256 over the kernel sources, headers, the public header and the compile
+    flags (`src_sha`) and over the measured plan table alone (`plan_table_sha`). Profiles under profiles/ carry the stamp of the
+    tree they were measured on; bench.py compares it with the running tree's and marks anything else `profile_stale`.
+    (A commit hash would not do: the GPU box receives a snapshot without .git.)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, name), "rb") as f:
+            h.update(name.encode() + b"\0" + f.read() + b"\0")
+    h.update(" ".join(FLAGS + sum((EXTRA[k] for k in sorted(EXTRA)), [])).encode())
+    with open(os.path.join(CSRC, "cb_plan_table.inc"), "rb") as f:
+        pt = hashlib.sha256(f.read()).hexdigest()
+    return dict(src_sha=h.hexdigest()[:16], plan_table_sha=pt[:16])
 
 
 def _hipcc():
@@ -39,20 +59,81 @@ def _newer(src_paths, target):
     return any(os.path.getmtime(s) > t for s in src_paths)
 
 
+_probed = {}
+
+
+def _flag_supported(hipcc, flags):
+    """compile a trivial kernel with `flags` once: LLVM-internal options (-mllvm ...) come and go between compiler releases, and an
+    unknown one aborts the whole build with 'Unknown command line argument'"""
+    key = (hipcc,) + tuple(flags)
+    if key not in _probed:
+        import tempfile
+        with tempfile.TemporaryDirectory() as d:
+            src = os.path.join(d, "probe.hip")
+            with open(src, "w") as f:
+                f.write("#include <hip/hip_runtime.h>\n__global__ void probe(float* p) { p[threadIdx.x] = 1.f; }\n")
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-O1"] + list(flags) + ["-c", src, "-o", os.path.join(d, "probe.o")],
+                               capture_output=True, text=True)
+            _probed[key] = r.returncode == 0
+    return _probed[key]
+
+
+def check_no_scratch(remarks, needle):
+    """parse -Rpass-analysis=kernel-resource-usage remarks; return [(kernel, field, value)] violations for kernels matching `needle`"""
+    import re
+    bad, cur, seen = [], None, 0
+    for line in remarks.splitlines():
+        m = re.search(r"remark: Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1) if needle in m.group(1) else None
+            seen += cur is not None
+            continue
+        if cur is None:
+            continue
+        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Dynamic Stack): (\S+)", line)
+        if m and m.group(2) not in ("0", "False"):
+            bad.append((cur, m.group(1), m.group(2)))
+    return bad, seen
+
+
 def build(verbose=True, force=False):
     os.makedirs(BUILD, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     hipcc = _hipcc()
 
     def compile_one(src):
+        import hashlib
         s = os.path.join(CSRC, src)
-        extra = EXTRA.get(src, [])
-        o = os.path.join(BUILD, src.replace(".hip", "_x.o" if extra else ".o"))       # the flag set is part of the cache key
+        extra = list(EXTRA.get(src, []))
+        if extra and not _flag_supported(hipcc, extra):
+            print(f"[celebbasis_amd.build] WARNING: {hipcc} rejects {' '.join(extra)}; building {src} without it "
+                  "(attention accumulators in AGPR form: correct, a few percent slower)", flush=True)
+            extra = []
+        guard = NO_SCRATCH.get(src)
+        if guard:
+            extra += ["-Rpass-analysis=kernel-resource-usage"]
+        # the RESOLVED flag set is part of the object's cache key
+        tag = "" if not extra else "_" + hashlib.sha1(" ".join(extra).encode()).hexdigest()[:6]
+        o = os.path.join(BUILD, src.replace(".hip", tag + ".o"))
         if force or _newer([s] + hdrs, o):
             cmd = [hipcc] + FLAGS + extra + ["-c", s, "-o", o]
             if verbose:
                 print("[celebbasis_amd.build]", " ".join(cmd), flush=True)
-            subprocess.check_call(cmd)
+            if guard:
+                r = subprocess.run(cmd, capture_output=True, text=True)
+                if r.returncode != 0:
+                    sys.stderr.write(r.stderr)
+                    raise subprocess.CalledProcessError(r.returncode, cmd)
+                bad, seen = check_no_scratch(r.stderr, guard)
+                if bad or not seen:
+                    if os.path.exists(o):
+                        os.remove(o)
+                    raise RuntimeError(f"{src}: the counted-vmcnt pipeline requires spill-free kernels; "
+                                       + (f"violations: {bad[:4]}" if bad else "no resource-usage remarks found for its kernels"))
+                with open(o + ".resources.txt", "w") as f:
+                    f.write("\n".join(l for l in r.stderr.splitlines() if "remark:" in l) + "\n")
+            else:
+                subprocess.check_call(cmd)
         return o
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:

@@ -29,7 +29,7 @@ static void require(const void* p, const char* what) { CB_CHECK(p != nullptr, CB
 extern "C" {
 
 const char* cb_last_error(void) { return g_err.c_str(); }
-int cb_version(void) { return 100; }
+int cb_version(void) { return CB_ABI_VERSION; }
 
 // ------------------------------------------------------------------ context
 int cb_ctx_create(int device, void* hip_stream, cb_ctx** out) { return cb_ctx_create_dtype(device, hip_stream, CB_DTYPE_F32, out); }
@@ -196,10 +196,18 @@ int cb_debug_force_plan(int BM, int BN, int split) {
     CB_END
 }
 
+int cb_debug_glds_safe(int on) {
+    CB_TRY
+    plan_force().glds_safe = on ? 1 : 0;
+    CB_END
+}
+
 // ------------------------------------------------------------------ op level
 int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d) {
     CB_TRY
     require(ctx, "ctx"); require(d, "desc");
+    CB_CHECK(d->struct_size == (int)sizeof(cb_gemm_desc), CB_ERR_ARG, "gemm: desc.struct_size %d != %d — caller built against another "
+             "header (ABI %d)", d->struct_size, (int)sizeof(cb_gemm_desc), CB_ABI_VERSION);
     CB_CHECK(d->dtype == CB_DTYPE_F32 || d->dtype == CB_DTYPE_BF16, CB_ERR_ARG, "gemm: unknown desc.dtype %d", d->dtype);
     GemmArgs a;
     a.dt = (DType)d->dtype;
@@ -316,6 +324,8 @@ int cb_geglu_bwd(cb_ctx* ctx, const void* x, const void* dy, void* dx, int64_t M
 int cb_attention(cb_ctx* ctx, const cb_attention_desc* d) {
     CB_TRY
     require(ctx, "ctx"); require(d, "desc");
+    CB_CHECK(d->struct_size == (int)sizeof(cb_attention_desc), CB_ERR_ARG, "attention: desc.struct_size %d != %d — caller built against "
+             "another header (ABI %d)", d->struct_size, (int)sizeof(cb_attention_desc), CB_ABI_VERSION);
     Ctx* c = &ctx->c;
     const bool bwd = d->dout != nullptr;
     if (bwd) CB_CHECK(d->dqbuf && d->dkvbuf, CB_ERR_ARG, "attention: backward needs dqbuf and dkvbuf");
@@ -743,6 +753,7 @@ int cb_trainer_cfg_default(cb_trainer_cfg* cfg) {
     CB_TRY
     require(cfg, "cfg");
     memset(cfg, 0, sizeof(*cfg));
+    cfg->struct_size = (int)sizeof(*cfg);
     cb_unet_cfg& u = cfg->unet;     // aigc_id.yaml:39-54
     u.in_channels = 4; u.out_channels = 4; u.model_channels = 320; u.num_res_blocks = 2;
     u.channel_mult[0] = 1; u.channel_mult[1] = 2; u.channel_mult[2] = 4; u.channel_mult[3] = 4; u.n_mult = 4;
@@ -764,6 +775,8 @@ int cb_trainer_cfg_default(cb_trainer_cfg* cfg) {
 int cb_trainer_create(cb_ctx* ctx, const cb_wtab* wt, const cb_trainer_cfg* cfg, cb_trainer** out) {
     CB_TRY
     require(ctx, "ctx"); require(wt, "wt"); require(cfg, "cfg"); require(out, "out");
+    CB_CHECK(cfg->struct_size == (int)sizeof(cb_trainer_cfg), CB_ERR_ARG, "trainer: cfg.struct_size %d != %d — start from "
+             "cb_trainer_cfg_default() of this library (ABI %d)", cfg->struct_size, (int)sizeof(cb_trainer_cfg), CB_ABI_VERSION);
     TrainerCfg tc;
     tc.unet = to_cfg(&cfg->unet); tc.vae = to_cfg(&cfg->vae); tc.clip = to_cfg(&cfg->clip);
     for (int i = 0; i < 4; ++i) tc.fr_layers[i] = cfg->fr_layers[i];

@@ -482,8 +482,12 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     for (int k0 = kbeg; k0 < kend; k0 += BKT) {
         // tile k0 has landed for this wave (all but the newest STAGES-2 tiles are complete) ... and for every wave after the barrier,
         // which also says that everybody is done reading the slot that is refilled next (it was read in the previous iteration)
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory");
-        __builtin_amdgcn_s_barrier();
+        // The count is exact only while every k-tile issues NA + NB VMEM instructions and the compiler adds none of its own (spills,
+        // re-materialised loads): celebbasis_amd/build.py fails the build if any kernel of this file has scratch. p.safe (CB_GLDS_SAFE=1
+        // / cb_debug_glds_safe) is the reference pipeline: drain the queue, full barrier — bitwise the same results
+        // (tests/test_gpu_ops.py::test_glds_counted_wait_matches_safe_mode).
+        if (p.safe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        else { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory"); __builtin_amdgcn_s_barrier(); }
         issue(k0 + (STAGES - 1) * BKT, nxt);
         const char* arow = As + cur * A_BUF + (wm * (BM / WM) + ml) * RB;
         const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * RB;
@@ -703,7 +707,7 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
 template <> void launch_problem<bf16_t>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
     KArgs ka;
     ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     if (a.a_kind == LD_ROW) launch_tiles_bf16<AK_ROW>(pl, grid, s, ka);
@@ -717,7 +721,7 @@ template <> void launch_problem<bf16_t>(hipStream_t s, const GemmArgs& a, const 
 template <> void launch_problem<float>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
     KArgs ka;
     ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     if (a.a_kind == LD_ROW) launch_tiles_f32<AK_ROW>(pl, grid, s, ka);
@@ -752,7 +756,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
     ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     ProfRec rec; bool prof = L.prof && L.prof->on;
@@ -839,7 +843,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
     ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bf16_bk() == 0);
     ProfRec rec; bool prof = L.prof && L.prof->on;

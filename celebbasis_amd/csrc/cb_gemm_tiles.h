@@ -20,6 +20,7 @@ struct KArgs {
     int splitk, k_per_split;
     float* ws;          // split-K partials [split][batch][M][N] fp32 (null when splitk == 1)
     int a_vec, b_vec;   // 1 when the operand may use 16-byte global loads
+    int safe = 0;       // LDS-DMA kernel: 1 = drain the DMA queue (vmcnt(0)) + full barrier per k-tile instead of the counted wait
 };
 
 // ---- branch-free 16-byte loaders: buffer loads with hardware range checking ---------------------------------------------
@@ -268,8 +269,11 @@ inline const std::unordered_map<std::string, PlanEntry>& plan_table() {
 }
 
 // diagnostics (tools/tune_gemm.py): restrict the planner to one tile shape / split count; 0 = free. Not thread safe, not for production.
-struct PlanForce { int BM = 0, BN = 0, split = 0; };
-inline PlanForce& plan_force() { static PlanForce f; return f; }
+struct PlanForce { int BM = 0, BN = 0, split = 0; int glds_safe = 0; };
+inline PlanForce& plan_force() {
+    static PlanForce f = [] { PlanForce g; const char* e = getenv("CB_GLDS_SAFE"); g.glds_safe = (e && e[0] == '1') ? 1 : 0; return g; }();
+    return f;
+}
 // bke = elements of k per tile (16 for fp32, 32 for bf16); speed = MFMA rate relative to the fp32 kernel
 inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.

@@ -30,10 +30,12 @@ struct UNet {
     Norm out_norm; Conv out_conv;
     Lin emb_all;         // the emb_layers.1 Linear of all 22 ResBlocks stacked: [sum cout, 4*model_channels] (+ bias)
     Lin kv_all;          // every cross-attention to_k / to_v of the UNet stacked: [sum 2*ch, context_dim]
+    Lin kv_all32;        // bf16 UNets under CB_BF16_KV_F32=1: fp32 copy of kv_all (projection + its input gradient run in fp32)
 };
 void unet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const UNetCfg& cfg, UNet* U);
 // x: [B,H,W,Cin] NHWC, t: device int64[B], context: [B,L,ctx_dim]; returns eps_hat [B,H,W,Cout]
-Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context);
+// context_f32 (optional): the conditioning BEFORE its cast to the UNet's element type; used by the fp32 K/V-projection lever
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32 = nullptr);
 
 // ---------------------------------------------------------------- VAE encoder (model.py:368-459, autoencoder.py:324-328)
 struct VaeCfg { int ch = 128; int ch_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0}; int n_mult = 4; int num_res_blocks = 2; int in_channels = 3;

@@ -105,6 +105,15 @@ void unet_load(Ctx* ctx, const WTab& wt, const std::string& pre, const UNetCfg& 
     U->out_norm = load_norm(ctx, wt, pre + "out.0", ch, 1e-5f);
     U->out_conv = load_conv(ctx, wt, pre + "out.2", mc, cfg.out_channels, 3, true);
     U->kv_all = load_linear_cat_var(ctx, wt, kvc.prefixes, cfg.context_dim, kvc.outs);
+    // Precision lever of the bf16 step (config 3): the conditioning reaches the UNet only through these 32 projections
+    // and its gradient leaves it only through their input gradient, so running that one GEMM pair in fp32 (77 rows: 3 GFLOP per
+    // sample) removes the bf16 rounding of the conditioning, of K/V before the cast and of d context after the K = 24960 sum.
+    static const bool kv32 = [] { const char* e = getenv("CB_BF16_KV_F32"); return e && e[0] == '1'; }();
+    if (U->dt == DT_BF16 && kv32) {
+        ctx->load_dt = DT_F32;
+        U->kv_all32 = load_linear_cat_var(ctx, wt, kvc.prefixes, cfg.context_dim, kvc.outs);
+        ctx->load_dt = U->dt;
+    }
     U->emb_all = load_linear_cat_var(ctx, wt, embc.prefixes, ted, embc.outs, true);
 }
 
@@ -137,7 +146,7 @@ static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* kv_all) {
     return G.linear(h, w.proj_out, x);
 }
 
-Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context) {
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32) {
     const int B = x->n, mc = U.cfg.model_channels;
     CB_CHECK(x->c == U.cfg.in_channels, CB_ERR_SHAPE, "unet: input channels %d vs %d", x->c, U.cfg.in_channels);
     CB_CHECK(context->c == U.cfg.context_dim && context->n == B, CB_ERR_SHAPE, "unet: context shape");
@@ -150,7 +159,7 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     Ten* semb = G.linear(G.silu(emb), U.emb_all);      // emb_layers of all ResBlocks: SiLU(emb) is shared, one stacked Linear
     // all cross-attention keys/values of the step in one GEMM; the layers read column views of it. Its gradient buffer is
     // zero-filled up front because the 16 layers each accumulate into their own disjoint column block.
-    Ten* kv_all = G.linear(context, U.kv_all);
+    Ten* kv_all = (context_f32 && U.kv_all32.w) ? G.cast(G.linear(context_f32, U.kv_all32), U.dt) : G.linear(context, U.kv_all);
     if (kv_all->rg) {
         float beta; void* g = G.grad(kv_all, &beta);
         k_fill(G.L, kv_all->dt, g, kv_all->numel(), 0.f);
@@ -645,7 +654,8 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ten* emb1 = G.make(B, T77, 1, w, true, DT_F32);
     int32_t* map = static_cast<int32_t*>(ctx->arena.alloc((size_t)B * T77 * sizeof(int32_t)));
     k_row_surgery_fwd(L, emb1->pf(), emb0->pf(), zz->pf(), bt.tokens, map, B, T77, w, es, c.placeholder_token);
-    Ten* cond = G.cast(clip_encode(G, T->clip, emb1), T->unet.dt);
+    Ten* cond32 = clip_encode(G, T->clip, emb1);
+    Ten* cond = G.cast(cond32, T->unet.dt);
     ph_clip.reset();
 
     if (fork) { CB_HIP(hipEventRecord(ctx->ev_join, ctx->aux)); G.L.stream = main_stream; }
@@ -664,7 +674,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));
     Ten* xt = G.make(B, z0->h, z0->w, zc, false, z0->dt);
     k_qsample(L, z0->dt, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
-    Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond);
+    Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond, cond32->dt == DT_F32 && cond32 != cond ? cond32 : nullptr);
     float beta;
     void* deps = G.grad(eps_hat, &beta);
     k_mse_loss(L, eps_hat->dt, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);

@@ -194,8 +194,9 @@ class FaceIdDatasetOneShot(FaceIdDatasetStyleGAN3):
 
 class DeviceAugmenter:
     """Batch-level counterpart of `__getitem__` with the pixel work on the GPU: the base faces stay resident in HBM, the host
-    draws the per-sample parameters (the same distributions as the CPU path) and two native launches per augmentation produce
-    `image` (B,S,S,3), `image_ori.faces` (B,S,S,6) and the ids/captions of face_id.py:598-644."""
+    draws the per-sample parameters — from the dataset's generator, in `__getitem__`'s order (augmentation 1, augmentation 2,
+    `_add_bg` geometry, caption), so the same generator state yields the same batch on either path — and two native launches per
+    augmentation produce `image` (B,S,S,3), `image_ori.faces` (B,S,S,6) and the ids/captions of face_id.py:598-644."""
 
     def __init__(self, dataset, device="cuda"):
         from ... import lib as _lib
@@ -205,20 +206,64 @@ class DeviceAugmenter:
         self.idents = list(dataset.ids)
         self.base = torch.stack([dataset.faces[i] for i in self.idents]).to(self.dev).float().contiguous()     # (n_ids,S,S,3)
 
+    def draws(self, indices):
+        """host half of a batch: per sample the draws of `__getitem__`, in its order"""
+        ds = self.ds
+        p1, p3, geom, caps = [], [], [], []
+        for _ in indices:
+            p1.append(ds._jitter_params()); p3.append(ds._jitter_params())
+            if ds.split == "train":
+                geom.append(ds._bg_geometry())
+            caps.append(ds.rng.choice(imagenet_templates_small).format(f"face of {ds.placeholder} person"))
+        return p1, p3, geom, caps
+
     def batch(self, indices):
-        ds, L = self.ds, self._lib
+        L = self._lib
         B = len(indices)
         which = [i % len(self.idents) for i in indices]
-        src = self.base[torch.tensor(which, device=self.dev)].contiguous()
-        p1 = torch.tensor([ds._jitter_params() for _ in range(B)], dtype=torch.float32, device=self.dev)
-        p3 = torch.tensor([ds._jitter_params() for _ in range(B)], dtype=torch.float32, device=self.dev)
-        img, img3 = L.face_augment(self.ctx, src, p1), L.face_augment(self.ctx, src, p3)
-        if ds.split == "train":
-            geom = torch.tensor([ds._bg_geometry() for _ in range(B)], dtype=torch.int32, device=self.dev)
-            image = L.paste_on_canvas(self.ctx, img, geom)
-        else:
-            image = img
-        ids = torch.tensor([[self.idents[w]] * 2 for w in which], dtype=torch.int64, device=self.dev)
-        caps = [ds.rng.choice(imagenet_templates_small).format(f"face of {ds.placeholder} person") for _ in range(B)]
+        p1, p3, geom, caps = self.draws(indices)
+        # ONE H2D copy carries every per-sample scalar of the batch: 5 + 5 jitter parameters, 4 paste integers, the face index
+        host = torch.tensor([a + b + [float(v) for v in (g or (0, 0, 0, 0))] + [float(w)]
+                             for a, b, g, w in zip(p1, p3, geom or [None] * B, which)], dtype=torch.float32)
+        devp = host.to(self.dev, non_blocking=True)
+        src = self.base[devp[:, 14].to(torch.int64)].contiguous()
+        img = L.face_augment(self.ctx, src, devp[:, 0:5].contiguous())
+        img3 = L.face_augment(self.ctx, src, devp[:, 5:10].contiguous())
+        image = L.paste_on_canvas(self.ctx, img, devp[:, 10:14].to(torch.int32).contiguous()) if geom else img
+        ids = torch.tensor([[self.idents[w]] * 2 for w in which], dtype=torch.int64)
         return dict(image=image, caption=caps, id_idx=ids[:, 0].clone(), img_idx=torch.tensor(list(indices)),
-                    image_ori=dict(faces=torch.cat([img, img3], dim=-1).contiguous(), ids=ids, num_ids=torch.ones(B, dtype=torch.int64)))
+                    image_ori=dict(faces=torch.cat([img, img3], dim=-1).contiguous(), ids=ids.to(self.dev, non_blocking=True),
+                                   num_ids=torch.ones(B, dtype=torch.int64)))
+
+
+class DeviceFeeder:
+    """The training loop's default feeder on a GPU: what `DataLoader(dataset, batch_size, shuffle=True)` + 8 CPU workers are in
+    the reference (main_id_embed.py:252-260), with the pixel work of every batch done by `DeviceAugmenter` on the GPU the step
+    runs on. One pass = one epoch of `len(dataset)` samples in `torch.randperm` order (RandomSampler), last batch kept
+    (drop_last=False). `tokenize` (captions -> int64 [B,77]) is applied once per distinct caption and cached: the feeder serves
+    81 templates x one placeholder, so steady-state batches carry ready `tokens` and the step never waits for a BPE pass."""
+
+    def __init__(self, dataset, batch_size, device="cuda", shuffle=True, tokenize=None):
+        self.ds, self.batch_size, self.shuffle, self.tokenize = dataset, int(batch_size), shuffle, tokenize
+        self.aug = DeviceAugmenter(dataset, device)
+        self._tok = {}
+
+    def __len__(self):
+        return (len(self.ds) + self.batch_size - 1) // self.batch_size
+
+    def _tokens(self, caps):
+        rows = []
+        for c in caps:
+            if c not in self._tok:
+                self._tok[c] = self.tokenize([c])[0].to(torch.int64).cpu()
+            rows.append(self._tok[c])
+        return torch.stack(rows).to(self.aug.dev, non_blocking=True)
+
+    def __iter__(self):
+        n = len(self.ds)
+        order = torch.randperm(n).tolist() if self.shuffle else list(range(n))
+        for i in range(0, n, self.batch_size):
+            b = self.aug.batch(order[i:i + self.batch_size])
+            if self.tokenize is not None:
+                b["tokens"] = self._tokens(b["caption"])
+            yield b

@@ -43,8 +43,19 @@ class CBError(RuntimeError):
 
 
 # ---------------------------------------------------------------- C structs (mirror include/celebbasis_hip.h)
-class GemmDesc(C.Structure):
-    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+ABI_VERSION = 300        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
+
+
+class _Sized(C.Structure):
+    """descriptor whose first member is `struct_size` (include/celebbasis_hip.h): filled on construction"""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.struct_size = C.sizeof(self)
+
+
+class GemmDesc(_Sized):
+    _fields_ = [("struct_size", C.c_int), ("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
                 ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
                 ("lda", C.c_int64), ("ldb", C.c_int64), ("ldc", C.c_int64),
                 ("a_layout", C.c_int), ("b_layout", C.c_int), ("batch", C.c_int),
@@ -53,8 +64,8 @@ class GemmDesc(C.Structure):
                 ("alpha", C.c_float), ("beta", C.c_float), ("dtype", C.c_int)]
 
 
-class AttentionDesc(C.Structure):
-    _fields_ = [("qbuf", C.c_void_p), ("ldq", C.c_int64), ("q_off", C.c_int),
+class AttentionDesc(_Sized):
+    _fields_ = [("struct_size", C.c_int), ("qbuf", C.c_void_p), ("ldq", C.c_int64), ("q_off", C.c_int),
                 ("kvbuf", C.c_void_p), ("ldkv", C.c_int64), ("k_off", C.c_int), ("v_off", C.c_int),
                 ("B", C.c_int), ("Nq", C.c_int), ("Nk", C.c_int), ("C", C.c_int), ("heads", C.c_int),
                 ("scale", C.c_float), ("causal", C.c_int),
@@ -78,8 +89,8 @@ class ClipCfg(C.Structure):
                 ("mlp", C.c_int)]
 
 
-class TrainerCfg(C.Structure):
-    _fields_ = [("unet", UNetCfg), ("vae", VaeCfg), ("clip", ClipCfg),
+class TrainerCfg(_Sized):
+    _fields_ = [("struct_size", C.c_int), ("unet", UNetCfg), ("vae", VaeCfg), ("clip", ClipCfg),
                 ("fr_layers", C.c_int * 4), ("fr_width", C.c_int), ("fr_in", C.c_int),
                 ("image_size", C.c_int), ("es", C.c_int), ("inner_dim", C.c_int), ("max_ids", C.c_int),
                 ("momentum", C.c_float), ("scale_factor", C.c_float), ("linear_start", C.c_float), ("linear_end", C.c_float),
@@ -96,7 +107,7 @@ class Batch(C.Structure):
 # every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_create_dtype", "cb_ctx_dtype", "cb_ctx_aux_stream", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
-    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm",
+    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm", "cb_debug_glds_safe",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
     "cb_q_sample", "cb_mse_loss", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
@@ -113,7 +124,7 @@ _ARGTYPES = {
     "cb_last_error": [], "cb_version": [],
     "cb_ctx_create": [_I, _P, _P], "cb_ctx_create_dtype": [_I, _P, _I, _P], "cb_ctx_dtype": [_P, _P], "cb_ctx_aux_stream": [_P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
     "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
-    "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
+    "cb_debug_glds_safe": [_I], "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
     "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
     "cb_gemm": [_P, _P], "cb_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _I],
     "cb_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
@@ -169,6 +180,9 @@ def load():
             fn.restype = C.c_int
         if name in _ARGTYPES:
             fn.argtypes = _ARGTYPES[name]
+    if lib.cb_version() != ABI_VERSION:
+        raise RuntimeError(f"{LIB_PATH} implements ABI {lib.cb_version()}, these bindings were written for {ABI_VERSION}: rebuild "
+                           "(python -m celebbasis_amd.build --force)")
     _lib = lib
     return lib
 

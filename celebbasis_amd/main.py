@@ -61,6 +61,12 @@ class DataModuleFromConfig:
         return torch.utils.data.DataLoader(self.datasets["train"], batch_size=self.batch_size, shuffle=True,
                                            num_workers=self.num_workers, collate_fn=self.collate)
 
+    def device_feeder(self, device, tokenize=None):
+        """the default feeder of `celebbasis_amd.main` on a GPU: same dataset object, same draws, pixel work on the device
+        (ldm/data/face_id.py DeviceFeeder) instead of in `num_workers` CPU processes"""
+        from .ldm.data.face_id import DeviceFeeder
+        return DeviceFeeder(self.datasets["train"], self.batch_size, device, shuffle=True, tokenize=tokenize)
+
 
 def get_parser():
     p = argparse.ArgumentParser(description="CelebBasis personalization on MI355X (flags of main_id_embed.py:47-178)")
@@ -81,8 +87,16 @@ def get_parser():
                    help="seeded random weights at the true shapes, seeded stand-in faces and hashed pseudo token ids (no checkpoints, "
                         "dataset or BPE vocabulary needed); without it missing inputs are errors")
     p.add_argument("--precision", choices=["f32", "bf16"], default="f32",
-                   help="element type of the frozen UNet / VAE / CLIP: f32 = the reference's arithmetic (BASELINE config 2), "
-                        "bf16 = bf16 storage + bf16 MFMA with fp32 statistics / coefficient gradient / AdamW (config 3)")
+                   help="element type of the frozen UNet / VAE: f32 = the reference's arithmetic (BASELINE config 2), "
+                        "bf16 = bf16 storage + bf16 MFMA with fp32 statistics (config 3); the CLIP text tower, the FR-net, the "
+                        "coefficient head, its gradient and AdamW are fp32 in both")
+    p.add_argument("--cpu_feeder", action="store_true",
+                   help="feed from a torch DataLoader with `num_workers` CPU processes like the reference (main_id_embed.py:252-260) "
+                        "instead of the device feeder (augmentations on the GPU, the default)")
+    p.add_argument("--report", type=str, default=None,
+                   help="write a JSON line with the wall-clock steps/s of this run (feeder + tokenizer + H2D + step, everything "
+                        "the loop does) measured after `--report_warmup` steps")
+    p.add_argument("--report_warmup", type=int, default=20)
     return p
 
 
@@ -157,6 +171,13 @@ def main(argv=None):
     ckptdir = os.path.join(opt.logdir, opt.name, "checkpoints")
     model.train()
     step = 0
+    if opt.cpu_feeder:
+        loader = data.train_dataloader
+    else:
+        feeder = data.device_feeder(dev, tokenize=model.cond_stage_model.tokenize)
+        loader = lambda: feeder
+    import time
+    t_mark, step_mark = None, 0
 
     def lookahead(loader):
         """(batch, next batch or None): with --pipeline the next batch's first stage is enqueued before the current step"""
@@ -168,19 +189,34 @@ def main(argv=None):
             cur = nxt
 
     while step < max_steps:
-        for batch, nxt in lookahead(data.train_dataloader()):
+        for batch, nxt in lookahead(loader()):
             batch["image"] = batch["image"].to(dev)
             if opt.pipeline and nxt is not None:
                 nxt["image"] = nxt["image"].to(dev)
                 model.prefetch_first_stage(nxt)
             model.training_step(batch, step)
             step += 1
+            if opt.report and step == min(opt.report_warmup, max_steps - 1):
+                torch.cuda.synchronize(dev); t_mark, step_mark = time.perf_counter(), step
             if step % every == 0 or step == max_steps:
                 save_merged(model, ckptdir, all_ids, mine, rank, world, sharding)
                 if rank == 0:
                     print(f"[celebbasis_amd] step {step}/{max_steps} loss {model.last_loss():.5f} -> {ckptdir}", flush=True)
             if step >= max_steps:
                 break
+    if opt.report and t_mark is not None and rank == 0:
+        import json
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t_mark
+        rec = dict(what="python -m celebbasis_amd.main wall clock: feeder + tokenizer + H2D + step + checkpoint writes",
+                   feeder="cpu_dataloader" if opt.cpu_feeder else "device", num_workers=data.num_workers if opt.cpu_feeder else 0,
+                   precision=opt.precision, batch_size=bs, steps_timed=step - step_mark, seconds=dt,
+                   steps_per_sec=(step - step_mark) / dt, samples_per_sec=(step - step_mark) * bs / dt, pipeline=bool(opt.pipeline),
+                   world=world)
+        os.makedirs(os.path.dirname(os.path.abspath(opt.report)), exist_ok=True)
+        with open(opt.report, "w") as f:
+            f.write(json.dumps(rec) + "\n")
+        print("[celebbasis_amd] " + json.dumps(rec), flush=True)
 
 
 def save_merged(model, ckptdir, all_ids, mine, rank, world, sharding):
@@ -188,7 +224,8 @@ def save_merged(model, ckptdir, all_ids, mine, rank, world, sharding):
     `test_mode: coefficient` and `test_mode: embedding` checkpoints are complete — and let rank 0 write the reference format"""
     model.sync_manager_from_trainer()
     em = model.embedding_manager
-    if world > 1:
+    import torch.distributed as dist
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         nc, ne = em.num_es * em.meta_heads * em.inner_dim, em.num_es * em.meta_heads * em.token_dim
         blocks = torch.stack([torch.cat([em.id_coefficients[i].reshape(-1), em.id_embeddings[i].reshape(-1)]) for i in mine]) \
             if mine else torch.zeros(0, nc + ne)

@@ -14,9 +14,10 @@ def identities_for_rank(n_identities, rank, world):
 def gather_identity_blocks(local_ids, local_blocks, n_identities, device=None):
     """all_gather the per-identity coefficient blocks. local_blocks: [len(local_ids), D] float32. Returns [n_identities, D]
     on every rank (rows of identities nobody owns stay zero). One collective per save; latency-bound (KiB payload)."""
-    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    grouped = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size() if grouped else 1
     D = local_blocks.shape[1] if local_blocks.numel() else 0
-    if world == 1:
+    if not grouped:                       # no process group: a plain single-process run. (A one-rank GROUP still runs the collective.)
         out = torch.zeros(n_identities, D)
         for j, i in enumerate(local_ids):
             out[i] = local_blocks[j].cpu()

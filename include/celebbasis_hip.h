@@ -53,6 +53,12 @@ typedef struct cb_frnet cb_frnet;
 typedef struct cb_trainer cb_trainer;
 
 const char* cb_last_error(void);
+/* ABI version of this header. It changes whenever a struct layout or the meaning of an argument changes: 100 = round 1 (float-only
+ * descriptors), 300 = this header (dtype-carrying descriptors, `struct_size` guards). cb_version() returns the library's value;
+ * a binding compares the two at load time (celebbasis_amd/lib.py does). Every descriptor struct that has grown since 100 starts with
+ * `struct_size` = sizeof(the struct as the CALLER compiled it); the library rejects any other size with CB_ERR_ARG instead of
+ * reading fields the caller never wrote. */
+#define CB_ABI_VERSION 300
 int cb_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -91,6 +97,7 @@ typedef enum { CB_LD_ROW = 0, CB_LD_COL = 1 } cb_operand_layout;
 /* C[M,N] = alpha * A.B + bias[n] + R + beta*C, batched; ROW = K contiguous, COL = M/N contiguous.
  * Replaces nn.Linear / einsum / bmm (ldm/modules/attention.py:170-193, openaimodel.py linear()). */
 typedef struct {
+    int struct_size;                             /* = sizeof(cb_gemm_desc) */
     const void* A; const void* B; void* C;      /* element type = dtype */
     int M, N, K;
     int64_t lda, ldb, ldc;
@@ -106,6 +113,10 @@ int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
 /* diagnostics (tools/tune_gemm.py): pin the GEMM planner to one tile shape (64/128 x 64/128) and split-K count for every later
  * launch of this process; (0, 0, 0) releases it. Process-global, not thread safe — never call it in production code. */
 int cb_debug_force_plan(int BM, int BN, int split);
+/* diagnostics: the LDS-DMA GEMM / conv kernel synchronises its tile ring with a COUNTED `s_waitcnt vmcnt(N)` + raw `s_barrier`; on != 0
+ * makes every later launch of this process drain the queue (`vmcnt(0)`) and use a full barrier instead — the slow reference pipeline the
+ * counted one must agree with bit for bit (also: environment CB_GLDS_SAFE=1). Process-global, not thread safe. */
+int cb_debug_glds_safe(int on);
 
 /* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped; dgrad=2 (3x3 only):
  * [I][4][4][O], the input gradient of "nearest x2 upsample + conv3x3" (openaimodel.py Upsample) as ONE 4x4 stride-2 pad-1 conv over dy
@@ -141,6 +152,7 @@ int cb_geglu_bwd(cb_ctx* ctx, const void* x, const void* dy, void* dx, int64_t M
  * If dout != NULL the call also runs the backward and writes dq into dqbuf (same layout as qbuf, only the q columns)
  * and dk/dv into dkvbuf (same layout as kvbuf; may equal dqbuf). */
 typedef struct {
+    int struct_size;                             /* = sizeof(cb_attention_desc) */
     const void* qbuf; int64_t ldq; int q_off;
     const void* kvbuf; int64_t ldkv; int k_off, v_off;
     int B, Nq, Nk, C, heads;
@@ -243,6 +255,7 @@ int cb_vae_decoder_destroy(cb_vae_dec* v);
 int cb_vae_decode(cb_vae_dec* v, const float* z_nchw, int B, int h, int w, float scale_factor, int to01, float* image_nchw);
 
 typedef struct {
+    int struct_size;      /* = sizeof(cb_trainer_cfg); filled by cb_trainer_cfg_default */
     cb_unet_cfg unet; cb_vae_cfg vae; cb_clip_cfg clip;
     int fr_layers[4]; int fr_width; int fr_in;
     int image_size, es, inner_dim, max_ids;

@@ -1,0 +1,66 @@
+"""CPU ORACLE — TEST INFRASTRUCTURE ONLY. Long-horizon oracle trajectories at the full SD v1-4 size, computed ONCE on host cores
+(≈10 s per sample and step) and committed as fixtures, so that the `-m gpu` horizon tests spend their time on the HIP path
+instead of on the CPU oracle:
+
+    python oracle/gen_horizon.py fp32   -> tests/golden/horizon_sd14_b1.pt   BASELINE config 2: bs=1, 100 optimiser steps
+    python oracle/gen_horizon.py bf16   -> tests/golden/horizon_sd14_b4.pt   BASELINE config 3: bs=4, 20 optimiser steps (fp32 oracle)
+
+The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
+`oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
+tests/test_gpu_models.py::test_train_10_steps_sd14_drift recomputes live, which ties the fixture to the live oracle.
+Per step the file holds the loss, the coefficients of every face in the batch (meta_net.py:289, [2B, es, inner]) and the EMA
+dictionary rows of the identities in the batch (embedding_manager.py:484-489); the MLP gradient is kept for a few steps on every
+16th row (a 32 768-element sample: the full 2 MB per step would not be a small fixture)."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import cb_oracle as O                      # noqa: E402
+from oracle.replay import make_batch                   # noqa: E402
+
+RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt", grad_steps=(1, 2, 5, 10, 25, 50, 100)),
+            bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
+ROW_STRIDE = 16
+
+
+def main(which, steps=None):
+    r = dict(RUNS[which])
+    if steps:
+        r["steps"] = int(steps)
+    m = dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
+             placeholder=O.PLACEHOLDER_SKS)
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = O.init_weights(shapes, seed=r["seed"])
+    st = O.TrainState(W)
+    ids = sorted({1 + (b % (m["max_ids"] - 1)) for b in range(r["B"])})
+    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=100, row_stride=ROW_STRIDE, ids=ids,
+                        torch=torch.__version__, threads=torch.get_num_threads()),
+               loss=[], coef=[], id_coef=[], id_emb_norm=[], gW_rows={}, gb={})
+    W0 = st.Wm.clone()
+    t0 = time.time()
+    for s in range(r["steps"]):
+        batch = make_batch(r["B"], 512, 64, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"])
+        loss, aux = O.train_step(W, st, batch, r["lr"], m["unet"], m["vae"], m["clip"], m["fr"], es=2, inner=512,
+                                 placeholder=m["placeholder"], return_aux=True)
+        rec["loss"].append(float(loss))
+        rec["coef"].append(aux["coef"].reshape(2 * r["B"], -1).clone())
+        rec["id_coef"].append(st.id_coef[ids].clone())
+        rec["id_emb_norm"].append(st.id_emb[ids].norm(dim=1).clone())
+        if s + 1 in r["grad_steps"]:
+            rec["gW_rows"][s + 1] = aux["gW"][::ROW_STRIDE].clone()
+            rec["gb"][s + 1] = aux["gb"].clone()
+        print(f"[gen_horizon {which}] step {s + 1}/{r['steps']} loss {float(loss):.6f} ({time.time() - t0:.0f} s)", flush=True)
+        if (s + 1) % 10 == 0 or s + 1 == r["steps"]:
+            out = dict(rec, steps=s + 1, loss=torch.tensor(rec["loss"], dtype=torch.float64), coef=torch.stack(rec["coef"]),
+                       id_coef=torch.stack(rec["id_coef"]), id_emb_norm=torch.stack(rec["id_emb_norm"]),
+                       Wm_rows=st.Wm[::ROW_STRIDE].clone(), W0_rows=W0[::ROW_STRIDE].clone(), bm=st.bm.clone())
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", r["out"])
+            torch.save(out, path + ".tmp")
+            os.replace(path + ".tmp", path)
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:])

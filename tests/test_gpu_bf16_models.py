@@ -19,7 +19,7 @@ import os
 import pytest
 import torch
 
-from test_gpu_models import MINI, close, dv, make_batch, trainer_cfg
+from test_gpu_models import MINI, close, dv, load, make_batch, run_horizon, trainer_cfg
 
 pytestmark = pytest.mark.gpu
 REPORT = {}
@@ -48,7 +48,7 @@ def cosine(a, b):
     return (a @ b / (a.norm() * b.norm()).clamp_min(1e-30)).item()
 
 
-def run_steps_bf16(lib, ctx, m, B, steps, lr, seed, taps, per_step=True):
+def run_steps_bf16(lib, ctx, m, B, steps, lr, seed, taps, per_step=True, bar=None):
     from oracle import cb_oracle as O
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
     W = O.init_weights(shapes, seed=seed)
@@ -83,7 +83,8 @@ def run_steps_bf16(lib, ctx, m, B, steps, lr, seed, taps, per_step=True):
     l2 = (coef_hip - st.id_coef).norm(dim=1).max().item()
     travelled = (st.id_coef - coef0).norm(dim=1).max().item()
     REPORT[tag + f".id_coefficients.L2[{steps} steps]"] = dict(l2=l2, travelled=travelled, relative=l2 / max(travelled, 1e-30))
-    assert l2 <= COEF_BAR_BF16, f"{tag}: coefficient L2 distance {l2:.3e} exceeds the config-3 bar {COEF_BAR_BF16:.0e}"
+    bar = COEF_BAR_BF16 if bar is None else bar
+    assert l2 <= bar, f"{tag}: coefficient L2 distance {l2:.3e} exceeds the bar {bar:.0e}"
     assert steps < 10 or l2 <= 2e-2 * travelled, f"{tag}: coefficient drift {l2:.3e} vs travelled {travelled:.3e}"
     close(tag + ".id_embeddings", tr.get_state("id_embeddings"), st.id_emb.reshape(-1), 1e-3)
     assert int(tr.get_state("step").item()) == steps
@@ -124,6 +125,15 @@ def test_train_40_steps_mini_bf16_coefficient_bar(cbf):
     run_steps_bf16(lib, ctx, MINI, B=2, steps=40, lr=5e-3, seed=7, taps=False, per_step=False)
 
 
+@pytest.mark.xfail(strict=False, reason="config 3 (bf16 UNet / VAE) measures 1.9e-3 .. 2.3e-3 after 40 mini steps: north_star's 1e-3 bar, stated for "
+                                        "the fp32 config 2, is NOT met by the bf16 path; kept as an expected failure so the gap stays visible")
+def test_train_40_steps_mini_bf16_north_star_1e3_bar(cbf):
+    """the same 40-step run held to north_star's fp32 bar (1e-3 L2): expected to fail, reported, never silently relaxed"""
+    lib, ctx = cbf
+    torch.set_num_threads(min(32, os.cpu_count() or 1))
+    run_steps_bf16(lib, ctx, MINI, B=2, steps=40, lr=5e-3, seed=7, taps=False, per_step=False, bar=1e-3)
+
+
 def test_train_step_sd14_bf16_bs4_vs_oracle(cbf):
     """BASELINE config 3 shapes: SD v1-4, 512x512, bs=4, bf16 UNet / VAE / CLIP + fp32 coefficient gradient: one full step"""
     from oracle import cb_oracle as O
@@ -132,6 +142,16 @@ def test_train_step_sd14_bf16_bs4_vs_oracle(cbf):
                 placeholder=O.PLACEHOLDER_SKS)
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     run_steps_bf16(lib, ctx, full, B=4, steps=1, lr=2e-2, seed=5, taps=True)
+
+
+def test_train_20_steps_sd14_bf16_bs4_horizon(cbf, golden_dir):
+    """BASELINE config 3 over a horizon AT FULL SIZE: 20 optimiser steps of SD v1-4 512x512 bs=4 with the bf16 UNet / VAE against
+    the fp32 oracle trajectory committed in tests/golden/horizon_sd14_b4.pt. The drift table (gpurun_out/horizon_sd14_b4_bf16.json,
+    committed copy profiles/r03_sd14_bf16_horizon20.json) is the real-width evidence COEF_BAR_BF16 is justified by."""
+    lib, ctx = cbf
+    fx = load(golden_dir, "horizon_sd14_b4.pt")
+    s = run_horizon(lib, ctx, fx, 20, "horizon_sd14_b4_bf16", REPORT, dict(coef_l2_max=COEF_BAR_BF16, loss_rel_max=2e-2))
+    REPORT["bf16.sd14.coef_l2_within_north_star_1e-3"] = s["coef_l2_max"] <= 1e-3
 
 
 def test_sampler_mini_bf16_vs_oracle(cbf):

@@ -116,6 +116,51 @@ def test_conv_bf16_tile256(cbf, tile256, N, H, W, Cin, Cout, ks, mode):
     test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, "bias")
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_glds_counted_wait_matches_safe_mode(cbf, dtype):
+    """the LDS-DMA kernel's tile ring is synchronised by a hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`
+    (cb_gemm_glds.hip); cb_debug_glds_safe(1) replaces it by vmcnt(0) + a full barrier. On step-sized problems (one wave of
+    blocks, several waves, split-K, ragged tails; both element types, i.e. the 2-stage rings of every tile shape the planner
+    picks) the two pipelines must agree BIT FOR BIT — a tile read before it landed would show up here"""
+    lib, ctx = cbf
+    L = lib.load()
+    bf = dtype == "bf16"
+    shapes = [(4096, 320, 2880), (1024, 640, 5760), (16384, 320, 320), (256, 1280, 11520), (777, 200, 328), (64, 1280, 2560)]
+    outs = {}
+    for safe in (0, 1):
+        lib.check(L.cb_debug_glds_safe(safe))
+        try:
+            for (M, N, K) in shapes:
+                A = rnd(1, M, K, seed=M + 1); B = rnd(1, N, K, seed=N + 2)
+                Ad, Bd = (d16(r16(A)), d16(r16(B))) if bf else (d32(A), d32(B))
+                Cd = torch.zeros(M, N, device=Ad.device, dtype=Ad.dtype)
+                d = lib.GemmDesc()
+                d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+                d.M, d.N, d.K = M, N, K
+                d.lda = d.ldb = K; d.ldc = N; d.batch = 1; d.alpha = 1.0
+                d.dtype = lib.DTYPE_BF16 if bf else lib.DTYPE_F32
+                lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+                ctx.sync()
+                outs[(safe, M, N, K)] = Cd.clone()
+        finally:
+            lib.check(L.cb_debug_glds_safe(0))
+    for (M, N, K) in shapes:
+        a, b = outs[(0, M, N, K)], outs[(1, M, N, K)]
+        assert torch.isfinite(a.float()).all() and a.float().abs().max() > 0
+        assert torch.equal(a, b), f"{dtype} {M}x{N}x{K}: counted-wait and safe pipelines differ (max {(a.float() - b.float()).abs().max().item():.3e})"
+
+
+def test_descriptor_struct_size_guard(cbf):
+    """a caller compiled against another header revision passes a descriptor of another size: rejected, not read"""
+    lib, ctx = cbf
+    d = lib.GemmDesc()
+    assert d.struct_size == C.sizeof(lib.GemmDesc) and lib.load().cb_version() == lib.ABI_VERSION == 300
+    d.struct_size -= 8
+    assert lib.load().cb_gemm(ctx.h, C.byref(d)) != 0 and b"struct_size" in lib.load().cb_last_error()
+    ad = lib.AttentionDesc(); ad.struct_size = 0
+    assert lib.load().cb_attention(ctx.h, C.byref(ad)) != 0 and b"struct_size" in lib.load().cb_last_error()
+
+
 def test_gemm_bf16_rejects_unsupported_layouts(cbf):
     """the bf16 GEMM takes k-contiguous, 16-byte-chunked operands only: anything else is an error, never a silent fallback"""
     lib, ctx = cbf

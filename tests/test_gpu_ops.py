@@ -412,6 +412,38 @@ def test_feeder_augmentations_vs_oracle(cb):
     assert all("sks" in c for c in b["caption"])
 
 
+def test_device_feeder_matches_cpu_feeder(cb):
+    """the product's default feeder (celebbasis_amd.main -> DeviceFeeder -> DeviceAugmenter, pixels on the GPU) against the
+    reference-shaped CPU path (`FaceIdDatasetOneShot.__getitem__` + DataModuleFromConfig.collate, face_id.py:598-644) on the
+    SAME generator state: same draws in the same order => the same batch (images to fp32 round-off, ids / captions exactly)"""
+    from celebbasis_amd.ldm.data.face_id import DeviceAugmenter, DeviceFeeder, FaceIdDatasetOneShot
+    from celebbasis_amd.main import DataModuleFromConfig
+    lib, ctx = cb
+    mk = lambda: FaceIdDatasetOneShot(pickle_path=None, num_ids=3, size=64, seed=9, diff_cnt=0, synthetic=True, repeats=4)
+    ds_cpu, ds_dev = mk(), mk()
+    idx = [0, 1, 2, 4, 8]
+    ref = DataModuleFromConfig.collate([ds_cpu[i] for i in idx])
+    got = DeviceAugmenter(ds_dev, _dev()).batch(idx)
+    torch.cuda.synchronize()
+    close("feeder.batch.image", got["image"], ref["image"], 2e-5)
+    close("feeder.batch.faces", got["image_ori"]["faces"], ref["image_ori"]["faces"], 2e-5)
+    assert got["image_ori"]["ids"].cpu().tolist() == ref["image_ori"]["ids"].tolist() and got["caption"] == ref["caption"]
+    assert got["id_idx"].tolist() == ref["id_idx"].tolist() and got["img_idx"].tolist() == ref["img_idx"].tolist()
+    assert ds_cpu.rng.random() == ds_dev.rng.random()        # both paths consumed exactly the same number of draws
+    # one epoch of the feeder: every sample once, last (short) batch kept, tokens ready on the device and cached per caption
+    calls = []
+    def tok(caps):
+        calls.append(tuple(caps))
+        return torch.full((len(caps), 77), 7, dtype=torch.int64)
+    torch.manual_seed(0)
+    feeder = DeviceFeeder(mk(), batch_size=5, device=_dev(), tokenize=tok)
+    batches = list(feeder)
+    assert len(batches) == len(feeder) == 3 and [b["image"].shape[0] for b in batches] == [5, 5, 2]
+    assert sorted(int(i) for b in batches for i in b["img_idx"]) == list(range(12))
+    assert all(b["tokens"].is_cuda and tuple(b["tokens"].shape) == (b["image"].shape[0], 77) for b in batches)
+    assert len(calls) == len(set(calls)) <= 12       # one tokenizer call per DISTINCT caption
+
+
 def test_celeb_head_forward_vs_oracle(cb):
     """cb_celeb_head_forward (the `test_mode: image` head, meta_net.py:262-289) against the oracle's restatement"""
     from oracle import cb_oracle as O

@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(built_lib):
     missing = [s for s in sorted(declared) if not hasattr(built_lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(lib.ABI_SYMBOLS), declared ^ set(lib.ABI_SYMBOLS)
-    assert built_lib.cb_version() >= 100
+    assert built_lib.cb_version() == 300          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
 
 
 def test_errors_do_not_cross_the_boundary(built_lib):
@@ -368,6 +368,25 @@ def test_bench_launches_its_own_ranks_and_checks_the_merge():
     env["WORLD_SIZE"] = "1"; env["RANK"] = "0"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry", "--steps", "1", "--warmup", "0"],
                        capture_output=True, text=True, timeout=300, env=env, cwd=str(ROOT))
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_run_config5_launches_its_own_ranks_and_checks_the_merge():
+    """`python tools/run_config5.py --gpus 2 --dry`: the config-5 driver re-executes itself under torch.distributed.run like bench.py;
+    on dry contexts with gloo it walks its identity shards (5 identities on 2 ranks: 3 + 2), merges the per-identity blocks with the
+    one all_gather of the job and checks every identity's block on rank 0. A launcher / --gpus mismatch is an error."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    script = os.path.join(ROOT, "tools", "run_config5.py")
+    r = subprocess.run([sys.executable, script, "--gpus", "2", "--identities", "5", "--train-steps", "2", "--dry"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 2 and d["merged_identities"] == 5 and d["identities_per_rank"] == [3, 2] and d["dry"] is True
+    env["WORLD_SIZE"] = "1"; env["RANK"] = "0"
+    r = subprocess.run([sys.executable, script, "--gpus", "2", "--identities", "2", "--dry"], capture_output=True, text=True, timeout=300,
+                       env=env, cwd=str(ROOT))
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 

@@ -5,10 +5,12 @@
 #   smoke                     __graft_entry__.smoke()
 #   bench [bench.py args]     python bench.py …                       -> gpurun_out/bench.json
 #   trace <tag> [bench args]  rocprofv3 --kernel-trace of bench.py + per-symbol CSV (tools/prof_stats.py)
-#                             -> gpurun_out/<tag>_bench_kernel_stats.csv   (pass --no-config3 for the fp32 step alone)
+#                             -> gpurun_out/<tag>_bench_kernel_stats.csv   (the fp32 step alone: --no-config3 is implied)
 #   trace3 <tag>              the same for the config-3 (bf16, bs=4) leg alone -> gpurun_out/<tag>_config3_kernel_stats.csv
 #   pmc <tag> [bench args]    two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with trace domains other than the kernel
-#                             trace) + tools/pmc_traffic.py           -> gpurun_out/<tag>_pmc_hbm_traffic.json
+#                             trace) of the fp32 leg + tools/pmc_traffic.py -> gpurun_out/<tag>_pmc_hbm_traffic.json
+#   pmc3 <tag>                the same for the config-3 leg alone     -> gpurun_out/<tag>_pmc_hbm_traffic_config3.json
+#   (every trace / PMC summary carries the stamp of the tree it was measured on: celebbasis_amd.build.source_digest())
 #   pmcsq <tag> <script.py>   three --pmc passes (SQ busy / waits, instruction mix, L2 hit + TA busy) of a fixed workload
 #   py <script> [args]        python <script> …                       -> gpurun_out/<script name>.log
 set -u
@@ -30,7 +32,7 @@ case "$what" in
     tag=$1; shift
     STEPS=6
     cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/trace_$tag -o bench -- \
-      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined "$@" > $REPO/gpurun_out/trace_$tag.log 2>&1
+      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --no-config3 "$@" > $REPO/gpurun_out/trace_$tag.log 2>&1
     cd $REPO
     db=$(find gpurun_out/trace_$tag -name "*.db" | head -1)
     # every measurement leg of bench.py runs warmup + steps + 1 profiled step of its own kernels
@@ -45,15 +47,16 @@ case "$what" in
     db=$(find gpurun_out/trace3_$tag -name "*.db" | head -1)
     python tools/prof_stats.py "$db" gpurun_out/${tag}_config3_kernel_stats.csv $((STEPS + 3)) | head -40
     find gpurun_out/trace3_$tag -size +8M -delete ;;
-  pmc)
+  pmc|pmc3)  # pmc = the fp32 (config-2) leg alone, pmc3 = the config-3 (bf16, bs=4) leg alone: per-symbol averages are not mixed
     tag=$1; shift
+    if [ "$what" = pmc3 ]; then leg="--trace-leg config3"; sfx=_config3; else leg="--no-config3"; sfx=""; fi
     cd /tmp
     for c in FETCH_SIZE WRITE_SIZE; do
-      rocprofv3 --kernel-trace --pmc $c -d $REPO/gpurun_out/pmc_${tag}_$c -o p --output-format csv -- \
-        python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined "$@" > $REPO/gpurun_out/pmc_${tag}_$c.log 2>&1
+      rocprofv3 --kernel-trace --pmc $c -d $REPO/gpurun_out/pmc${sfx}_${tag}_$c -o p --output-format csv -- \
+        python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined $leg "$@" > $REPO/gpurun_out/pmc${sfx}_${tag}_$c.log 2>&1
     done
     cd $REPO
-    python tools/pmc_traffic.py gpurun_out/pmc_${tag}_FETCH_SIZE gpurun_out/pmc_${tag}_WRITE_SIZE gpurun_out/${tag}_pmc_hbm_traffic.json
+    python tools/pmc_traffic.py gpurun_out/pmc${sfx}_${tag}_FETCH_SIZE gpurun_out/pmc${sfx}_${tag}_WRITE_SIZE gpurun_out/${tag}_pmc_hbm_traffic${sfx}.json
     find gpurun_out -name "*.csv" -size +8M -delete ;;
   pmcsq)     # SQ / LDS / cache counters of a fixed workload script: pmcsq <tag> <script.py>
     tag=$1; script=$2

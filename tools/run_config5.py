@@ -6,6 +6,8 @@ Synthetic weights / faces (no checkpoints or datasets offline). One JSON line wi
 
     python tools/run_config5.py --identities 4 --train-steps 100                                   # 1 GPU, scaled down
     python tools/run_config5.py --gpus 8 --identities 32                                           # 8 ranks (launches itself under torch.distributed.run)
+    python tools/run_config5.py --identities 1 --train-steps 3 --ddim-steps 2 --n-samples 2 --dump-first f.pt   # + the oracle replay in tests/
+    python tools/run_config5.py --gpus 2 --identities 5 --dry                                       # no GPU: launcher / sharding / merge only
 """
 import argparse
 import ctypes as C
@@ -31,6 +33,12 @@ def main():
     ap.add_argument("--n-samples", type=int, default=8)
     ap.add_argument("--scale", type=float, default=10.0)
     ap.add_argument("--precision", default="f32", choices=["f32", "bf16"])
+    ap.add_argument("--dry", action="store_true", help="no GPU: dry contexts + gloo — launcher, identity sharding, per-identity control flow, "
+                                                        "checkpoint merge and the JSON line only (computes nothing); used by the CPU test")
+    ap.add_argument("--dump-first", type=str, default=None,
+                    help="write the FIRST identity's learned coefficient row, its decoded images' statistics and the replay description "
+                         "(weight seed, batch seeds, lr, steps) to this .pt file: tests/test_gpu_models.py replays exactly that training on "
+                         "the CPU oracle and holds the coefficients to the precision's bar (the checker lives in tests/, not here)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:            # `python tools/run_config5.py --gpus 8`: become the launcher
         import socket
@@ -45,12 +53,19 @@ def main():
     if a.gpus and world != a.gpus:
         raise SystemExit(f"run_config5.py --gpus {a.gpus} was started with WORLD_SIZE={world}")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
     import torch.distributed as dist
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    if a.dry:
+        dev = torch.device("cpu")
+        if world > 1:
+            dist.init_process_group("gloo")
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        if world > 1:
+            dist.init_process_group("nccl", device_id=dev)
     from celebbasis_amd import lib, synthetic, sharding
+    if a.dry:
+        return dry_run(a, rank, world, dev, dist, lib, synthetic, sharding)
     from celebbasis_amd.ldm.models.diffusion.ddim import ddim_tables, ddim_timesteps
     from celebbasis_amd.ldm.models.diffusion.ddpm import make_beta_schedule_linear
 
@@ -75,7 +90,7 @@ def main():
     empty = torch.full((a.n_samples, 77), 49407, dtype=torch.int64); empty[:, 0] = 49406
     prompt, empty = prompt.to(dev), empty.to(dev)
     zeros = lambda n: torch.zeros(n)
-    coefs, t_train, t_sample, finite = [], 0.0, 0.0, True
+    coefs, t_train, t_sample, finite, checked = [], 0.0, 0.0, True, None
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -94,6 +109,7 @@ def main():
             tr.step(b["image"], b["faces"], ids, b["tokens"], b["t"], b["noise"], b["post_noise"], 5e-3 * B)
         coef = tr.get_state("id_coefficients").reshape(10, es * K)[slot].clone()
         tb_ = time.perf_counter()
+        first = rank == 0 and ident == mine[0]
         # ---- sampling with the learned coefficients (test_mode 'coefficient', embedding_manager.py:464-475)
         c_dev = coef.reshape(es, K).to(dev).contiguous()
         z = torch.empty(es, W, device=dev)
@@ -119,6 +135,11 @@ def main():
         torch.cuda.synchronize()
         tc = time.perf_counter()
         finite = finite and bool(torch.isfinite(img).all()) and bool(torch.isfinite(coef).all())
+        if a.dump_first and first:
+            torch.save(dict(coef=coef.cpu(), slot=slot, steps=a.train_steps, batch=B, lr=5e-3 * B, weight_seed=0, batch_seed=23 + rank,
+                            n_batches=len(batches), precision=a.precision, image_mean=float(img.mean()), image_std=float(img.std()),
+                            image_shape=list(img.shape)), a.dump_first)
+            checked = a.dump_first
         coefs.append(coef); t_train += tb_ - ta; t_sample += tc - tb_
     merged = sharding.gather_identity_blocks(mine, torch.stack(coefs) if coefs else torch.zeros(0, es * K), a.identities, device=dev)
     torch.cuda.synchronize()
@@ -135,8 +156,39 @@ def main():
                           "rank0_train_s": round(t_train, 2), "rank0_sample_s": round(t_sample, 2),
                           "rank0_train_steps_per_s": round(len(mine) * a.train_steps / max(t_train, 1e-9), 2),
                           "merged_identities": int((merged.abs().sum(dim=1) > 0).sum().item()), "finite": finite, "dtype": a.precision,
-                          "data": "synthetic"}))
+                          "first_identity_dump": checked, "data": "synthetic"}))
     if world > 1:
+        dist.destroy_process_group()
+
+
+def dry_run(a, rank, world, dev, dist, lib, synthetic, sharding):
+    """--dry: the job's host logic on dry contexts (shape checks + accounting, no device) with the gloo backend"""
+    shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
+    ctx = lib.Context(device=-1)
+    tr = lib.Trainer(ctx, lib.WeightTable(shapes))
+    mine = sharding.identities_for_rank(a.identities, rank, world)
+    es, K = 2, 512
+    coefs = []
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for ident in mine:
+        for _ in range(min(a.train_steps, 2)):
+            tr.step(a.batch, None, None, None, None, None, None, 5e-3 * a.batch)       # a dry context plans and accounts, computes nothing
+        coefs.append(torch.full((es * K,), float(ident + 1)))                          # stand-in block that identifies its owner
+    merged = sharding.gather_identity_blocks(mine, torch.stack(coefs) if coefs else torch.zeros(0, es * K), a.identities, device=dev)
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        for i in range(a.identities):
+            assert torch.all(merged[i] == i + 1), f"checkpoint merge: identity {i} came back as {merged[i][:2].tolist()}"
+        print(json.dumps({"metric": "config 5 end-to-end: personalise + DDIM sample, identities/sec", "value": None, "unit": "identities/s",
+                          "n_gpus": world, "identities": a.identities, "train_steps_per_identity": a.train_steps, "batch": a.batch,
+                          "merged_identities": a.identities, "identities_per_rank": [len(sharding.identities_for_rank(a.identities, r, world)) for r in range(world)],
+                          "dry": True, "dtype": a.precision, "data": "synthetic"}), flush=True)
+    if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 
