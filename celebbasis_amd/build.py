@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcelebbasis_hip.so")
-SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
+SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_flash_bf16_v2.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
            "cb_abi.hip"]
 HEADERS = ["cb_common.h", "cb_device.h", "cb_gemm_tiles.h", "cb_plan_table.inc", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
@@ -22,11 +22,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-u
 # ordinary VGPRs. The default AGPR form costs ~100 v_accvgpr_read/write per streamed tile and 28 .. 78 extra registers
 # (flash_fwd<3> 128 -> 100, flash_bwd_dkv<3> 256 -> 178). CB_MFMA_VGPR_FORM=0 restores the default (A/B measurements).
 EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_VGPR_FORM", "1") != "0" else [])
-         for src in ("cb_flash.hip", "cb_flash_bf16.hip")}
+         for src in ("cb_flash.hip", "cb_flash_bf16.hip", "cb_flash_bf16_v2.hip")}
 # Kernels whose software pipeline COUNTS its outstanding VMEM instructions (`s_waitcnt vmcnt(N)` + raw `s_barrier`,
 # cb_gemm_glds.hip): a register spill would add scratch loads / stores to that count and let a tile be read before it has landed.
 # The build therefore fails if any kernel of these files has scratch, spills or a dynamic stack (-Rpass-analysis remarks).
-NO_SCRATCH = {"cb_gemm_glds.hip": "gemm_glds"}
+NO_SCRATCH = {"cb_gemm_glds.hip": "gemm_glds", "cb_flash_bf16_v2.hip": "f2_"}
 
 
 def source_digest():

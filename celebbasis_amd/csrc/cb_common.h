@@ -140,6 +140,9 @@ struct FlashArgs {
     // a key range; forward partials [ksplit][B*H][Nq][d] (unnormalised O) + [ksplit][B*H][Nq][2] (max, sum), dQ partials
     // [ksplit][B*H][Nq][d]; one small combine kernel each (fp32 kernels only)
     float* wsk = nullptr; int ksplit = 1;
+    // bf16, second-generation kernels (cb_flash_bf16_v2.hip): scratch for the operands that are streamed TRANSPOSED
+    // ([B*H][16*ceil(d/16)][N] bf16 each: forward V^T; backward K^T | Q^T | dO^T), sized by flash_bf16_v2_tws_bytes. Non-null selects v2.
+    void* tws = nullptr;
 };
 size_t flash_ksplit_ws_floats(const FlashArgs& a, int B, bool forward, int* ksplit);
 size_t flash_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
@@ -151,6 +154,10 @@ size_t flash_bf16_bwd_ws_floats(const FlashArgs& a, int B, int* nsplit);
 bool flash_bf16_supported(int d, const FlashArgs& a);
 void flash_bf16_forward(const Launch& L, const FlashArgs& a, int B);
 void flash_bf16_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv);
+// v2 (LDS-DMA staged, 16*QB rows per wave, pre-transposed second operands): 0 bytes = not applicable to this problem
+size_t flash_bf16_v2_tws_bytes(const FlashArgs& a, int B, bool backward);
+void flash_bf16_v2_forward(const Launch& L, const FlashArgs& a, int B, void* tws);
+void flash_bf16_v2_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv, void* tws);
 
 // ---------------------------------------------------------------- other kernels (cb_kernels.hip)
 // Launchers whose tensors are activations take the element type `dt` of those tensors (void pointers); parameters, statistics,

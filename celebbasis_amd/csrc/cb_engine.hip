@@ -454,6 +454,7 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
     if (use_flash && (bf ? flash_bf16_supported(d, f) : flash_supported(d, f))) {
         f.lse = ctx->arena.allocf((size_t)B * heads * Nq);
         if (!bf) { size_t wf = flash_ksplit_ws_floats(f, B, true, &f.ksplit); if (wf) f.wsk = ctx->arena.allocf(wf); }
+        if (bf) { size_t tb = flash_bf16_v2_tws_bytes(f, B, false); if (tb) f.tws = ctx->arena.alloc(tb); }
         if (bf) flash_bf16_forward(L, f, B); else flash_forward(L, f, B);
         if (rg) {
             tape.push_back([this, f, o, qt, kt, qoff, koff, voff, B, Nq, bf]() mutable {
@@ -466,10 +467,15 @@ Ten* Graph::attention(Ten* qt, int qoff, Ten* kt, int koff, int voff, int C, int
                 if (gq) { f.dq = ptr_off(gq, f.dt, qoff); f.beta_q = bq; }
                 f.ksplit = 1; f.wsk = nullptr;
                 if (gq && !bf) { size_t wq = flash_ksplit_ws_floats(f, B, false, &f.ksplit); if (wq) f.wsk = ctx->arena.allocf(wq); }
+                f.tws = nullptr;
+                if (bf && gq) { size_t tb = flash_bf16_v2_tws_bytes(f, B, true); if (tb) f.tws = ctx->arena.alloc(tb); }   // v2 needs the dQ kernel's D
                 if (gk) {
                     f.dk = ptr_off(gk, f.dt, koff); f.dv = ptr_off(gk, f.dt, voff); f.beta_kv = bk;
-                    size_t wsf = bf ? flash_bf16_bwd_ws_floats(f, B, &f.nsplit) : flash_bwd_ws_floats(f, B, &f.nsplit);
-                    if (wsf) f.ws = ctx->arena.allocf(wsf);
+                    f.nsplit = 1; f.ws = nullptr;
+                    if (!f.tws) {
+                        size_t wsf = bf ? flash_bf16_bwd_ws_floats(f, B, &f.nsplit) : flash_bwd_ws_floats(f, B, &f.nsplit);
+                        if (wsf) f.ws = ctx->arena.allocf(wsf);
+                    }
                 }
                 if (bf) flash_bf16_backward(L, f, B, gq != nullptr, gk != nullptr);
                 else flash_backward(L, f, B, gq != nullptr, gk != nullptr);

@@ -587,15 +587,16 @@ template <int KS, int TK> static size_t fb_lds(int kind) {     // 0 fwd, 1 dq, 2
 void flash_bf16_forward(const Launch& L, const FlashArgs& a, int B) {
     const int BH = B * a.H, ks = fb_ks(a.d);
     if (L.stats) { L.stats->gemm_flops += 4.0 * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count();
+    L.count(a.tws ? 2 : 1);
     if (L.dry) return;
     dim3 grid(cdiv(a.Nq, FB_ROWS), BH);
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
-        rec.variant = L.prof->id_of("flash_bf16_fwd_kernel"); rec.flops = 4.0 * BH * (double)a.Nq * a.Nk * a.d;
+        rec.variant = L.prof->id_of(a.tws ? "flash_bf16_v2_fwd_kernel" : "flash_bf16_fwd_kernel"); rec.flops = 4.0 * BH * (double)a.Nq * a.Nk * a.d;
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
     }
-    FB_DISPATCH(ks, flash_bf16_fwd_kernel, 0, grid, a)
+    if (a.tws) flash_bf16_v2_forward(L, a, B, a.tws);
+    else FB_DISPATCH(ks, flash_bf16_fwd_kernel, 0, grid, a)
     CB_HIP(hipGetLastError());
     if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
 }
@@ -605,12 +606,18 @@ void flash_bf16_backward(const Launch& L, const FlashArgs& a, int B, bool need_d
     // algorithmic (reference-equivalent) work: dP, dQ | dK, dV — the recomputation of S inside both kernels is not counted
     double fl = 2.0 + (need_dq ? 2.0 : 0.0) + (need_dkv ? 4.0 : 0.0);
     if (L.stats) { L.stats->gemm_flops += fl * BH * (double)a.Nq * a.Nk * a.d; L.stats->gemm_launches++; }
-    L.count(1 + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
+    L.count(a.tws ? 2 + (need_dkv ? 3 : 0) : 1 + (need_dkv ? (a.nsplit > 1 ? 2 : 1) : 0));
     if (L.dry) return;
     ProfRec rec; bool prof = L.prof && L.prof->on;
     if (prof) {
-        rec.variant = L.prof->id_of("flash_bf16_bwd_kernels"); rec.flops = fl * BH * (double)a.Nq * a.Nk * a.d;
+        rec.variant = L.prof->id_of(a.tws ? "flash_bf16_v2_bwd_kernels" : "flash_bf16_bwd_kernels"); rec.flops = fl * BH * (double)a.Nq * a.Nk * a.d;
         CB_HIP(hipEventCreate(&rec.e0)); CB_HIP(hipEventCreate(&rec.e1)); CB_HIP(hipEventRecord(rec.e0, L.stream));
+    }
+    if (a.tws) {
+        flash_bf16_v2_backward(L, a, B, need_dq, need_dkv, a.tws);
+        CB_HIP(hipGetLastError());
+        if (prof) { CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec); }
+        return;
     }
     if (!need_dq) hipLaunchKernelGGL(flash_bf16_dvec_kernel, dim3(cdiv((long)BH * a.Nq, 4)), dim3(256), 0, L.stream, a, BH);
     if (need_dq) {

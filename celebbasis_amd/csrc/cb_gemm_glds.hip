@@ -1,6 +1,6 @@
 // cb_gemm_glds.hip — the LDS-DMA MFMA GEMM / implicit-GEMM convolution for gfx950 (MI355X): bf16 (BASELINE config 3) and fp32
 // (config 2: every problem with two k-contiguous operands — all convolutions, Linear forwards, and Linear input gradients through
-// the transposed weight copy the engine keeps), the measured-plan autotuner, and the register-staged bf16 kernel it replaced.
+// the transposed weight copy the engine keeps) and the measured-plan autotuner.
 //
 //   C[M,N] = alpha * A[M,K] . B[N,K]^T + bias[n] + rowbias[img(m)][n] + R[m][n] + beta * C[m][n]
 //
@@ -8,183 +8,20 @@
 // v_mfma_f32_32x32x2_f32: 157.3 TF), bias and the split-K partials are fp32. Both operands are k-contiguous (activations / conv
 // gathers as A, [out][in] weights as B), 16-byte aligned with K a whole number of 16-byte chunks, so every load is one branch-free
 // `buffer_load_dwordx4` with hardware zero fill. File layout:
-//   1. `gemm_bf16_kernel` — round 2's first bf16 kernel, register staged like cb_gemm.hip (256 threads = 4 wave64 in 2x2, 64-byte
-//      rows = 32 bf16 per k-tile, LDS image XOR-swizzled by (row >> 2) & 3, one ds_write_b128 per global load); kept selectable
-//      (CB_BF16_GEMM=regs) as the A/B baseline: at bf16 MFMA rates its VGPR -> LDS store pass costs more than the MFMAs it feeds.
-//   2. `gemm_glds_kernel<T, ...>` / `gemm_glds256_kernel` — the LDS-DMA kernels (section "LDS-DMA variant" below): the default for
-//      both element types.
-//   3. host side: variant selection, eligibility of fp32 problems, offline autotuner (CB_AUTOTUNE), launch + split-K reduce.
+//   1. `gemm_glds_kernel<T, ...>` / `gemm_glds256_kernel` — the LDS-DMA kernels. (Round 2's register-staged bf16 kernel, kept for a while
+//      as the A/B baseline — 384 vs 525 TF over the config-3 mix, profiles/r02_bf16_gemm_variants.jsonl — is deleted.)
+//   2. host side: variant selection, eligibility of fp32 problems, offline autotuner (CB_AUTOTUNE), launch + split-K reduce.
 // profiles/README.md (round 2) has the measurements behind every choice.
 #include "cb_gemm_tiles.h"
 
 namespace cb {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
-constexpr int BKE = 32;          // k elements per tile
-constexpr int ROWB = 64;         // bytes per LDS row
 
 enum { AK_ROW = 0, AK_CONV = 1, AK_CONVF = 2 };
 
-// ---- epilogue shared by both variants. C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
-template <int BM, int BN>
-__device__ __forceinline__ void gemm_bf16_epilogue(const KArgs& p, f32x16 (&acc)[BM / 64][BN / 64], int m0, int n0, int wm, int wn, int ml,
-                                                   int kl, int split, int z, int zb, int zh) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    const GemmArgs& a = p.a;
-    if (p.splitk > 1) {
-        float* W = p.ws + ((long)split * a.batch + z) * (long)a.M * a.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                int col = n0 + wn * (BN / 2) + j * 32 + ml;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                    if (row < a.M && col < a.N) W[(long)row * a.N + col] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    bf16_t* __restrict__ Cp = static_cast<bf16_t*>(a.C) + zb * a.sCb + zh * a.sCh;
-    const bf16_t* __restrict__ Rp = a.R ? static_cast<const bf16_t*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
-    const bf16_t* __restrict__ rowbias = static_cast<const bf16_t*>(a.rowbias);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            int col = n0 + wn * (BN / 2) + j * 32 + ml;
-            if (col >= a.N) continue;
-            float bcol = a.bias ? a.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                int row = m0 + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kl;
-                if (row < a.M) {
-                    float v = a.alpha * acc[i][j][r] + bcol;
-                    if (rowbias) v += (float)rowbias[(long)(row / a.rows_per_img) * (a.ld_rowbias ? a.ld_rowbias : a.N) + col];
-                    if (Rp) v += (float)Rp[(long)row * a.ldr + col];
-                    bf16_t* c = Cp + (long)row * a.ldc + col;
-                    if (a.beta != 0.f) v += a.beta * (float)(*c);
-                    *c = (bf16_t)v;
-                }
-            }
-        }
-}
-
-template <int BM, int BN, int AK>
-__device__ __forceinline__ void gemm_bf16_body(const KArgs& p, char* lds) {
-    constexpr int TM = BM / 64, TN = BN / 64;
-    const GemmArgs& a = p.a;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int ntiles = p.tiles_m * p.tiles_n;
-    const int t = xcd_remap(blockIdx.x, ntiles);
-    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
-    const int m0 = tm * BM, n0 = tn * BN;
-    const int split = blockIdx.y;
-    const int z = blockIdx.z;
-    const int zb = z / a.nh, zh = z - zb * a.nh;
-
-    const bf16_t* __restrict__ Ap = static_cast<const bf16_t*>(a.A) + zb * a.sAb + zh * a.sAh;
-    const bf16_t* __restrict__ Bp = static_cast<const bf16_t*>(a.B) + zb * a.sBb + zh * a.sBh;
-
-    const int kbeg = split * p.k_per_split;
-    const int kend = min(a.K, kbeg + p.k_per_split);
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[BM / 64], rb[BN / 64];
-    ConvRows<BM, 2> cr;
-    ConvFast<BM, 2> cf;
-    int tap_u = 0, ci_u = 0;                                                                   // scalar decode of k0 (AK_CONVF)
-    if constexpr (AK == AK_CONVF) { cf.init(a.g, m0, a.M, tid); tap_u = kbeg / a.g.C; ci_u = kbeg - tap_u * a.g.C; }
-    else if constexpr (AK == AK_CONV) cr.init(a.g, m0, a.M, kbeg, tid);
-
-    __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
-    RowOffs<BM, 2> roA; RowOffs<BN, 2> roB;
-    if constexpr (AK == AK_ROW) roA.init(a.lda, m0, a.M, tid);
-    roB.init(a.ldb, n0, a.N, tid);
-    auto loadAB = [&](int k0) {
-        int oa[BM / 64], ob[BN / 64];
-        if constexpr (AK == AK_ROW) offs_row<BM, 2>(oa, roA, k0, kend, tid);
-        else if constexpr (AK == AK_CONVF) {
-            const int ky = (a.g.ks == 3) ? ((tap_u * 11) >> 5) : 0;
-            const int kx = tap_u - ky * a.g.ks;
-            offs_conv_fast<BM, 2>(oa, cf, tap_u, ((ky * a.g.W + kx) * a.g.C + ci_u) * 2);
-            ci_u += BKE;
-            if (ci_u >= a.g.C) { ci_u -= a.g.C; ++tap_u; }
-        } else { offs_conv<BM, 2>(oa, a.g, cr, k0, kend, tid); cr.advance(a.g); }
-        offs_row<BN, 2>(ob, roB, k0, kend, tid);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int i = 0; i < BM / 64; ++i) ra[i] = buf_ld4(srdA, oa[i]);
-#pragma unroll
-        for (int i = 0; i < BN / 64; ++i) rb[i] = buf_ld4(srdB, ob[i]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    constexpr int A_BUF = BM * ROWB, B_BUF = BN * ROWB;            // bytes per buffer
-    char* const As = lds;
-    char* const Bs = lds + 2 * A_BUF;
-
-    if (kbeg < kend) {
-        loadAB(kbeg);
-        store_kc<BM>(reinterpret_cast<float*>(As), ra, tid);
-        store_kc<BN>(reinterpret_cast<float*>(Bs), rb, tid);
-    }
-    __syncthreads();
-
-    int cur = 0;
-    const int kl = lane >> 5, ml = lane & 31;
-    const int swz = (ml >> 2) & 3;                                           // == ((row >> 2) & 3): sub-tile bases are multiples of 32
-    const int clo = ((2 * kl) ^ swz) * 16, chi = ((2 * kl + 1) ^ swz) * 16;  // byte offsets of the lane's two chunks
-    for (int k0 = kbeg; k0 < kend; k0 += BKE) {
-        const bool more = (k0 + BKE) < kend;
-        if (more) loadAB(k0 + BKE);
-
-        const char* arow = As + cur * A_BUF + (wm * (BM / 2) + ml) * ROWB;
-        const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * ROWB;
-        bf16x8_t av[2][TM], bv[2][TN];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int i = 0; i < TM; ++i) av[half][i] = *reinterpret_cast<const bf16x8_t*>(arow + i * 32 * ROWB + (half ? chi : clo));
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bv[half][j] = *reinterpret_cast<const bf16x8_t*>(brow + j * 32 * ROWB + (half ? chi : clo));
-        }
-#pragma unroll
-        for (int half = 0; half < 2; ++half)
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[half][i], bv[half][j], acc[i][j], 0, 0, 0);
-
-        if (more) {
-            store_kc<BM>(reinterpret_cast<float*>(As + (cur ^ 1) * A_BUF), ra, tid);
-            store_kc<BN>(reinterpret_cast<float*>(Bs + (cur ^ 1) * B_BUF), rb, tid);
-        }
-        __syncthreads();
-        cur ^= 1;
-    }
-
-    gemm_bf16_epilogue<BM, BN>(p, acc, m0, n0, wm, wn, ml, kl, split, z, zb, zh);
-}
-
-template <int BM, int BN, int AK>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(const KArgs p) {
-    __shared__ __attribute__((aligned(16))) char lds[2 * (BM + BN) * ROWB];
-    gemm_bf16_body<BM, BN, AK>(p, lds);
-}
-
-// ================================================================= LDS-DMA variant (the default; bf16 AND fp32)
-// Same tiles, different staging: `buffer_load_dwordx4 ... lds` writes the 16-byte chunks of a k-tile straight into LDS (no VGPR
+// ================================================================= the LDS-DMA kernel (bf16 AND fp32)
+// 4 wave64 in 2x2 per tile (8 for the 256x128 tile), staging by `buffer_load_dwordx4 ... lds`: it writes the 16-byte chunks of a k-tile straight into LDS (no VGPR
 // staging, no ds_write pass — at bf16 MFMA rates the VGPR->LDS store pass of the register-staged kernel above costs more
 // LDS-pipe time than the MFMAs it feeds; at fp32 rates it removes the ~45 VALU + 16 ds_write per k-tile that compete with the
 // MFMAs for issue slots, profiles/r01_pmc_conv.md), and a k-tile is one 128-byte row per tile row: 64 bf16 or 32 fp32.
@@ -540,21 +377,21 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const KArgs p) {
 }
 
 // ---------------------------------------------------------------- host side
-// Variant selection (experiments): CB_BF16_GEMM = regs | 128x2 | 128x3 | 64x2 | 64x3  (row bytes x ring stages; default 128x2)
+// Variant selection (experiments): CB_BF16_GEMM = 128x2 | 128x3 | 64x2 | 64x3  (row bytes x ring stages; default 128x2)
 struct GVariant { bool glds; int rb, stages; };
 static const GVariant& gvariant() {
     static const GVariant v = [] {
         GVariant g{true, 128, 2};
         if (const char* e = getenv("CB_BF16_GEMM")) {
             std::string s(e);
-            if (s == "regs") g = {false, 64, 2};
-            else { int rb = 0, st = 0; if (sscanf(e, "%dx%d", &rb, &st) == 2 && (rb == 64 || rb == 128) && st >= 2 && st <= 3) g = {true, rb, st}; }
+            int rb = 0, st = 0;
+            if (sscanf(e, "%dx%d", &rb, &st) == 2 && (rb == 64 || rb == 128) && st >= 2 && st <= 3) g = {true, rb, st};
         }
         return g;
     }();
     return v;
 }
-static int bf16_bk() { return gvariant().glds ? gvariant().rb / 2 : BKE; }
+static int bf16_bk() { return gvariant().rb / 2; }
 template <typename T, int AK, int RB, int ST>
 static void launch_glds(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 128, AK, RB, ST>), grid, dim3(256), 0, s, ka);
@@ -575,17 +412,10 @@ static void launch_tiles_bf16(const Plan& pl, dim3 grid, hipStream_t s, const KA
         hipLaunchKernelGGL((gemm_glds256_kernel<bf16_t, AK>), grid, dim3(512), GLDS256_LDS, s, ka);
         return;
     }
-    if (v.glds) {
-        if (v.rb == 128 && v.stages == 2) launch_glds<bf16_t, AK, 128, 2>(pl, grid, s, ka);
-        else if (v.rb == 128 && v.stages == 3) launch_glds<bf16_t, AK, 128, 3>(pl, grid, s, ka);
-        else if (v.rb == 64 && v.stages == 3) launch_glds<bf16_t, AK, 64, 3>(pl, grid, s, ka);
-        else launch_glds<bf16_t, AK, 64, 2>(pl, grid, s, ka);
-        return;
-    }
-    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_bf16_kernel<128, 128, AK>), grid, dim3(256), 0, s, ka);
-    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_bf16_kernel<128, 64, AK>), grid, dim3(256), 0, s, ka);
-    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_bf16_kernel<64, 128, AK>), grid, dim3(256), 0, s, ka);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<64, 64, AK>), grid, dim3(256), 0, s, ka);
+    if (v.rb == 128 && v.stages == 2) launch_glds<bf16_t, AK, 128, 2>(pl, grid, s, ka);
+    else if (v.rb == 128 && v.stages == 3) launch_glds<bf16_t, AK, 128, 3>(pl, grid, s, ka);
+    else if (v.rb == 64 && v.stages == 3) launch_glds<bf16_t, AK, 64, 3>(pl, grid, s, ka);
+    else launch_glds<bf16_t, AK, 64, 2>(pl, grid, s, ka);
 }
 
 // ---------------------------------------------------------------- fp32 through the LDS-DMA kernel
@@ -813,7 +643,6 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
         CB_CHECK(g.ks >= 1 && g.ks <= 4, CB_ERR_SHAPE, "conv: ks=%d", g.ks);
-        CB_CHECK(gvariant().glds || g.ks == 1 || g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d needs the LDS-DMA kernel", g.ks);
         CB_CHECK(a.K == g.ks * g.ks * g.C, CB_ERR_SHAPE, "conv: K=%d != %d*%d*%d", a.K, g.ks, g.ks, g.C);
         CB_CHECK(g.C % 8 == 0, CB_ERR_SHAPE, "conv bf16: C=%d must be a multiple of 8 (pad the channel axis)", g.C);
         CB_CHECK(a.M % (g.Ho * g.Wo) == 0, CB_ERR_SHAPE, "conv: M=%d not a multiple of Ho*Wo=%d", a.M, g.Ho * g.Wo);
@@ -838,7 +667,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         long eb = (long)a.N * a.ldb;
         CB_CHECK(ea * 2 < lim && eb * 2 < lim, CB_ERR_SHAPE, "gemm_bf16: an operand slice exceeds 2 GiB");
     }
-    if (gvariant().glds) autotune<bf16_t>(L, a, bf16_bk(), plan_knobs().bf16_speed);
+    autotune<bf16_t>(L, a, bf16_bk(), plan_knobs().bf16_speed);
     KArgs ka;
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
@@ -861,7 +690,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_HIP(hipGetLastError());
     if (prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_%skernel<%s%d,%d,%s>", pl.BM == 256 ? "glds256_" : (gvariant().glds ? "glds_" : "bf16_"), gvariant().glds ? "bf16," : "", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        snprintf(nm, sizeof nm, "gemm_%skernel<bf16,%d,%d,%s>", pl.BM == 256 ? "glds256_" : "glds_", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }

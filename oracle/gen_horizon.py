@@ -22,6 +22,9 @@ from oracle import cb_oracle as O                      # noqa: E402
 from oracle.replay import make_batch                   # noqa: E402
 
 RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt", grad_steps=(1, 2, 5, 10, 25, 50, 100)),
+            # the SAME oracle run on a different number of host threads, i.e. with another fp32 summation order inside torch's CPU GEMMs /
+            # convolutions: how far two correct fp32 evaluations of the reference's arithmetic drift apart under AdamW (slim: no gradients)
+            fp32alt=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1_alt.pt", grad_steps=(), threads=3, slim=True),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 
@@ -30,6 +33,8 @@ def main(which, steps=None):
     r = dict(RUNS[which])
     if steps:
         r["steps"] = int(steps)
+    if r.get("threads"):
+        torch.set_num_threads(r["threads"])
     m = dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
              placeholder=O.PLACEHOLDER_SKS)
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
@@ -57,6 +62,8 @@ def main(which, steps=None):
             out = dict(rec, steps=s + 1, loss=torch.tensor(rec["loss"], dtype=torch.float64), coef=torch.stack(rec["coef"]),
                        id_coef=torch.stack(rec["id_coef"]), id_emb_norm=torch.stack(rec["id_emb_norm"]),
                        Wm_rows=st.Wm[::ROW_STRIDE].clone(), W0_rows=W0[::ROW_STRIDE].clone(), bm=st.bm.clone())
+            if r.get("slim"):
+                out = dict(cfg=out["cfg"], steps=out["steps"], loss=out["loss"], coef=out["coef"], id_coef=out["id_coef"])
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", r["out"])
             torch.save(out, path + ".tmp")
             os.replace(path + ".tmp", path)

@@ -299,6 +299,12 @@ def test_geglu_bf16(cbf):
     (1, 200, 136, 256, 2, 0, 0),     # d=128 (KS=4), ragged both ways
     (2, 100, 100, 64, 4, 1, 1),      # d=16 causal (mini configs)
     (4, 1024, 1024, 640, 8, 0, 1),   # UNet level-1 self-attention at bs=4
+    # second-generation kernels (cb_flash_bf16_v2.hip: LDS-DMA ring, 16*QB rows per wave, pre-transposed second operands), 32 < d <= 64:
+    (1, 4096, 4096, 320, 8, 0, 1),   # the shape that carries the attention FLOPs: 64x64 level, d = 40 (QB = 1 at 8 heads)
+    (4, 1024, 1024, 320, 8, 0, 1),   # d = 40, 32 heads: QB = 2 forward / dQ
+    (8, 2048, 2048, 320, 8, 0, 1),   # d = 40, 64 heads: QB = 4 forward / dQ, QB = 2 dK/dV
+    (1, 1000, 520, 512, 8, 0, 0),    # d = 64 (four output tiles), ragged query / key counts, separate q and kv buffers
+    (2, 264, 1288, 384, 8, 0, 0),    # d = 48, key tail of 8
 ])
 def test_attention_bf16(cbf, B, Nq, Nk, Cc, heads, causal, fused):
     lib, ctx = cbf

@@ -408,7 +408,8 @@ def test_feeder_augmentations_vs_oracle(cb):
     ctx.sync()
     assert tuple(b["image"].shape) == (3, 64, 64, 3) and tuple(b["image_ori"]["faces"].shape) == (3, 64, 64, 6)
     assert b["image_ori"]["ids"].dtype == torch.int64 and b["image_ori"]["ids"].tolist() == [[0, 0], [1, 1], [0, 0]]
-    assert float(b["image"].min()) >= -1.0 and float(b["image"].max()) <= 1.0 and torch.isfinite(b["image_ori"]["faces"]).all()
+    # (bilinear weights sum to 1 only to fp32 round-off: 1 + 2.4e-7 has been seen)
+    assert float(b["image"].min()) >= -1.0 - 1e-6 and float(b["image"].max()) <= 1.0 + 1e-6 and torch.isfinite(b["image_ori"]["faces"]).all()
     assert all("sks" in c for c in b["caption"])
 
 
