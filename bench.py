@@ -409,6 +409,23 @@ def main():
             tr3.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], lr3)
         el3 = timed_loop(run3, args.steps, args.warmup, 1, dist, dev, False)
         rf3, ph3, st3 = profile_step(ctx3, run3, PEAK_BF16_MFMA_TFLOPS, bf16=True)
+        # the same K steps with the gradient-free first stage of batch i+1 (VAE encode + FR backbone) enqueued on the prefetch stream
+        # under the UNet of batch i (cb_trainer_prefetch, what `celebbasis_amd.main` does by default): every iteration still runs one
+        # VAE encode, one FR pass, one CLIP forward and one full UNet step; results are bitwise identical. Secondary, like `pipelined`.
+        pipe3 = None
+        if not args.no_pipelined:
+            nb3 = lambda i: b3[i % len(b3)]
+            tr3.prefetch(nb3(0)["image"], nb3(0)["faces"], nb3(0)["post_noise"])
+            for i in range(2):
+                n = nb3(i + 1); tr3.prefetch(n["image"], n["faces"], n["post_noise"]); run3(i)
+            torch.cuda.synchronize()
+            tp = time.perf_counter()
+            for i in range(2, 2 + args.steps):
+                n = nb3(i + 1); tr3.prefetch(n["image"], n["faces"], n["post_noise"]); run3(i)
+            torch.cuda.synchronize()
+            elp = time.perf_counter() - tp
+            pipe3 = dict(samples_per_s=round(B3 * args.steps / elp, 3), ms_per_step=round(elp / args.steps * 1e3, 3),
+                         note="first stage of batch i+1 overlapped with step i (cb_trainer_prefetch); secondary figure")
         rf3["traffic"], rf3["traffic_detail"] = pmc_traffic(rf3["kernel"], bf16=True)
         rf3["frac_range_boxes"] = frac_range(rf3["frac"], bf16=True)
         ms3 = el3 / args.steps * 1e3
@@ -417,7 +434,8 @@ def main():
                           "steps_per_s": round(args.steps / el3, 4), "samples_per_s": round(B3 * args.steps / el3, 3), "ms_per_step": round(ms3, 3),
                           "vs_config2_samples_per_s": None if only3 else round(B3 * args.steps / el3 / out["value"], 3),
                           "step_tflop": round(st3["gemm_flops"] / 1e12, 4), "step_tflops_per_gpu": round(st3["gemm_flops"] / 1e12 / (ms3 * 1e-3), 2),
-                          "kernel_launches_per_step": st3["launches"], "loss": float(tr3.get_state("loss")[0]), "phase_ms": ph3, "roofline": rf3}
+                          "kernel_launches_per_step": st3["launches"], "loss": float(tr3.get_state("loss")[0]), "phase_ms": ph3, "pipelined": pipe3,
+                          "roofline": rf3}
         tr3.close(); ctx3.close()
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:

@@ -570,7 +570,15 @@ class Trainer(_Handle):
             if getattr(self, "_pf_stream", None) is None:
                 # the prefetch stream is TORCH's (never destroyed): the one call whose reads of caller memory are not ordered on
                 # the context stream when it returns (celebbasis_hip.h), so the caching allocator is told about the second reader
-                self._pf_stream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device))
+                # HIGH priority (-1): measured on MI355X (profiles/README.md, round 3) — the bf16 bs=4 step runs 34.2 ms pipelined with
+                # the prefetch stream at priority -1 against 37.8 / 38.0 ms at +1 / 0 (and 35.5 ms unpipelined): the big first-stage
+                # convolutions have to get onto the CUs AHEAD of the step's many small kernels to overlap with them at all; the fp32
+                # bs=1 step is indifferent (38.3 - 38.7 ms). CB_PF_PRIORITY overrides the value.
+                lo = int(os.environ.get("CB_PF_PRIORITY", "-1"))
+                try:
+                    self._pf_stream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device), priority=lo)
+                except Exception:
+                    self._pf_stream = torch.cuda.Stream(device=torch.device("cuda", self.ctx.device))
                 check(load().cb_trainer_set_prefetch_stream(self.h, C.c_void_p(self._pf_stream.cuda_stream)))
         check(load().cb_trainer_prefetch(self.h, C.byref(b)))
         if not self.ctx.dry:

@@ -4,6 +4,9 @@ instead of on the CPU oracle:
 
     python oracle/gen_horizon.py fp32   -> tests/golden/horizon_sd14_b1.pt   BASELINE config 2: bs=1, 100 optimiser steps
     python oracle/gen_horizon.py bf16   -> tests/golden/horizon_sd14_b4.pt   BASELINE config 3: bs=4, 20 optimiser steps (fp32 oracle)
+    python oracle/gen_horizon.py fp32alt  -> horizon_sd14_b1_alt.pt   20 steps of `fp32` on 3 instead of 8 host threads (torch-CPU's convolutions
+                                            do not change their summation order with the thread count: the two runs agree to 1.5e-6)
+    python oracle/gen_horizon.py fp32pert -> horizon_sd14_b1_pert.pt  `fp32` with every step's MLP gradient perturbed by 4e-5 relative noise
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
@@ -24,7 +27,12 @@ from oracle.replay import make_batch                   # noqa: E402
 RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt", grad_steps=(1, 2, 5, 10, 25, 50, 100)),
             # the SAME oracle run on a different number of host threads, i.e. with another fp32 summation order inside torch's CPU GEMMs /
             # convolutions: how far two correct fp32 evaluations of the reference's arithmetic drift apart under AdamW (slim: no gradients)
-            fp32alt=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1_alt.pt", grad_steps=(), threads=3, slim=True),
+            fp32alt=dict(B=1, steps=20, lr=5e-3, seed=8, out="horizon_sd14_b1_alt.pt", grad_steps=(), threads=3, slim=True),
+            # SENSITIVITY of the reference's own arithmetic to gradient round-off: the same oracle run with the MLP gradient of every step
+            # perturbed by seeded noise of relative L2 size 4e-5 — what the HIP path's dW measures against the oracle at SD size
+            # (summation order inside 1.7 TFLOP of fp32 convolutions). AdamW turns that into weight differences of order lr on the
+            # elements whose gradient is round-off sized; this trajectory shows how fast ANY fp32 evaluation with such an error separates.
+            fp32pert=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1_pert.pt", grad_steps=(), slim=True, grad_noise=4e-5),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 
@@ -35,6 +43,13 @@ def main(which, steps=None):
         r["steps"] = int(steps)
     if r.get("threads"):
         torch.set_num_threads(r["threads"])
+    if r.get("grad_noise"):
+        eps, gen, real = float(r["grad_noise"]), torch.Generator().manual_seed(77), O.adamw_step
+
+        def noisy_adamw(p, g, m, v, step, lr, **kw):
+            g = g + eps * g.norm() / (g.numel() ** 0.5) * torch.randn(g.shape, generator=gen)
+            return real(p, g, m, v, step, lr, **kw)
+        O.adamw_step = noisy_adamw
     m = dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
              placeholder=O.PLACEHOLDER_SKS)
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])

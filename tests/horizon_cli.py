@@ -24,7 +24,8 @@ def main(which, steps, tag):
     fx = load(os.path.join(HERE, "golden"), "horizon_sd14_b4.pt" if bf else "horizon_sd14_b1.pt")
     rep = {}
     name = ("horizon_sd14_b4_bf16_" if bf else "horizon_sd14_b1_") + tag
-    s = run_horizon(lib, ctx, fx, int(steps), name, rep, {})
+    os.makedirs("gpurun_out", exist_ok=True)
+    s = run_horizon(lib, ctx, fx, int(steps), name, rep, {}, save_traj=f"gpurun_out/{name}_traj.pt")
     s["env"] = {k: v for k, v in os.environ.items() if k.startswith("CB_")}
     print(json.dumps(s), flush=True)
     ctx.sync()
