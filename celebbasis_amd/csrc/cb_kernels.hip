@@ -472,32 +472,56 @@ __device__ __forceinline__ void gn_stq(bf16_t* p, const float4 (&v)[2]) {
     u.x = pack_bf16x2(v[0].x, v[0].y); u.y = pack_bf16x2(v[0].z, v[0].w); u.z = pack_bf16x2(v[1].x, v[1].y); u.w = pack_bf16x2(v[1].z, v[1].w);
     *reinterpret_cast<uint4*>(p) = u;
 }
+// Apply pass. The grid's total thread count is a multiple of the units per row (host: gn_apply_grid), so a thread visits the SAME
+// channels in every iteration of its grid-stride loop: the per-channel constants (mean, rstd * gamma, beta) live in registers and are
+// re-read only when the walk crosses into the next image. (Round 2's form fetched a 16-byte constant record per ELEMENT — eight
+// table loads per 16-byte payload load in bf16 — and topped out at 2.1 TB/s on the VAE's 268 MB tensors.)
 template <typename T, int VQ>
 __global__ __launch_bounds__(256) void gn_apply_kernel(T* __restrict__ y, const T* __restrict__ x,
                                                         const float* __restrict__ chn, long nquads, int HW, int C, int silu) {
-    const int Q = C >> 2;
-    const long nunits = nquads / VQ;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < nunits; u += (long)gridDim.x * 256) {
-        const long i = u * VQ;
-        const int q = (int)(i % Q);
-        const long n = i / ((long)HW * Q);
+    const int Q = C >> 2, UPR = Q / VQ;
+    const long nunits = nquads / VQ, per_img = (long)HW * UPR, stride = (long)gridDim.x * 256;
+    const long u0 = blockIdx.x * 256L + threadIdx.x;
+    if (u0 >= nunits) return;
+    const int c0 = (int)(u0 % UPR) * 4 * VQ;
+    long n = u0 / per_img, rem = u0 - n * per_img;
+    float mean[4 * VQ], sc[4 * VQ], sh[4 * VQ];
+    bool fresh = true;
+    for (long u = u0; u < nunits; u += stride) {
+        if (fresh) {
+            fresh = false;
+#pragma unroll
+            for (int j = 0; j < 4 * VQ; ++j) {
+                const float4 kk = *reinterpret_cast<const float4*>(chn + (n * C + c0 + j) * 4);
+                mean[j] = kk.x; sc[j] = kk.y * kk.z; sh[j] = kk.w;
+            }
+        }
         float4 v[VQ], r[VQ];
-        gn_ldq(x + i * 4, v);
+        gn_ldq(x + u * VQ * 4, v);
 #pragma unroll
         for (int w = 0; w < VQ; ++w) {
-            const float4* k = reinterpret_cast<const float4*>(chn + (n * C + (q + w) * 4) * 4);
             const float in[4] = {v[w].x, v[w].y, v[w].z, v[w].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 kk = k[j];
-                const float t = (in[j] - kk.x) * kk.y * kk.z + kk.w;
+                const float t = (in[j] - mean[4 * w + j]) * sc[4 * w + j] + sh[4 * w + j];
                 o[j] = silu ? t * sigmoidf_(t) : t;
             }
             r[w] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        gn_stq(y + i * 4, r);
+        gn_stq(y + u * VQ * 4, r);
+        rem += stride;
+        while (rem >= per_img) { rem -= per_img; ++n; fresh = true; }
     }
+}
+// grid for the apply kernels: as many blocks as grid1d would give, rounded down to a multiple of UPR / gcd(UPR, 256)
+static dim3 gn_apply_grid(long nunits, int UPR) {
+    long g = std::min<long>((nunits + 255) / 256, 4096);
+    int a = UPR, b2 = 256;
+    while (b2) { int t = a % b2; a = b2; b2 = t; }
+    const long m = UPR / a;
+    g = std::max<long>(m, g / m * m);
+    return dim3((unsigned)g);
 }
 
 // backward: t = x_hat*gamma+beta ; dt = dy * silu'(t) (or dy) ; s1 = mean(dt*gamma) ; s2 = mean(dt*gamma*x_hat) (per n,g)
@@ -642,9 +666,9 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
         hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
         hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
         if (GnVec<T>::VQ == 2 && C % 8 == 0)
-            hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), grid1d(nquads / 2, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+            hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
         else
-            hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
+            hipLaunchKernelGGL((gn_apply_kernel<T, 1>), gn_apply_grid(nquads, C / 4), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
     });
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
@@ -711,25 +735,36 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(T* __restrict__ dx, c
                                                             const T* __restrict__ dy, const float* __restrict__ chn,
                                                             const float* __restrict__ gs, long nquads, int HW, int C, int silu,
                                                             float acc_beta) {
-    const int Q = C >> 2;
-    const long nunits = nquads / VQ;
-    for (long u = blockIdx.x * 256L + threadIdx.x; u < nunits; u += (long)gridDim.x * 256) {
+    // same walk as gn_apply_kernel: the six per-channel constants (mean, rstd, gamma, beta, s1, s2) stay in registers
+    const int Q = C >> 2, UPR = Q / VQ;
+    const long nunits = nquads / VQ, per_img = (long)HW * UPR, stride = (long)gridDim.x * 256;
+    const long u0 = blockIdx.x * 256L + threadIdx.x;
+    if (u0 >= nunits) return;
+    const int c0 = (int)(u0 % UPR) * 4 * VQ;
+    long n = u0 / per_img, rem = u0 - n * per_img;
+    float4 kc[4 * VQ]; float2 sc[4 * VQ];
+    bool fresh = true;
+    for (long u = u0; u < nunits; u += stride) {
+        if (fresh) {
+            fresh = false;
+#pragma unroll
+            for (int j = 0; j < 4 * VQ; ++j) {
+                kc[j] = *reinterpret_cast<const float4*>(chn + (n * C + c0 + j) * 4);
+                sc[j] = *reinterpret_cast<const float2*>(gs + (n * C + c0 + j) * 2);
+            }
+        }
         const long i = u * VQ;
-        const int q = (int)(i % Q);
-        const long n = i / ((long)HW * Q);
         float4 xv[VQ], dv[VQ], old[VQ], r[VQ];
         gn_ldq(x + i * 4, xv);
         gn_ldq(dy + i * 4, dv);
         if (acc_beta != 0.f) gn_ldq(dx + i * 4, old);
 #pragma unroll
         for (int w = 0; w < VQ; ++w) {
-            const float4* k = reinterpret_cast<const float4*>(chn + (n * C + (q + w) * 4) * 4);
-            const float2* sg = reinterpret_cast<const float2*>(gs + (n * C + (q + w) * 4) * 2);
             const float xi[4] = {xv[w].x, xv[w].y, xv[w].z, xv[w].w}, di[4] = {dv[w].x, dv[w].y, dv[w].z, dv[w].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float4 kk = k[j]; const float2 ss = sg[j];
+                const float4 kk = kc[4 * w + j]; const float2 ss = sc[4 * w + j];
                 const float xh = (xi[j] - kk.x) * kk.y;
                 const float dt = gn_dt(xh, kk.z, kk.w, di[j], silu) * kk.z;
                 o[j] = kk.y * (dt - ss.x - xh * ss.y);
@@ -738,6 +773,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(T* __restrict__ dx, c
             r[w] = make_float4(o[0], o[1], o[2], o[3]);
         }
         gn_stq(dx + i * 4, r);
+        rem += stride;
+        while (rem >= per_img) { rem -= per_img; ++n; fresh = true; }
     }
 }
 void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const void* dy, const float* gamma, const float* beta,
@@ -772,10 +809,10 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
                            chn, HW, C, G, nchunk, rpb, silu);
         hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
         if (GnVec<T>::VQ == 2 && C % 8 == 0)
-            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, GnVec<T>::VQ>), grid1d(nquads / 2, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x,
+            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, (T*)dx, (const T*)x,
                                (const T*)dy, chn, gs, nquads, HW, C, silu, acc_beta);
         else
-            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 1>), grid1d(nquads, 256, 4096), dim3(256), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, chn,
+            hipLaunchKernelGGL((gn_bwd_apply_kernel<T, 1>), gn_apply_grid(nquads, C / 4), dim3(256), 0, L.stream, (T*)dx, (const T*)x, (const T*)dy, chn,
                                gs, nquads, HW, C, silu, acc_beta);
     });
     if (prof) L.prof->end(&rec, L.stream);
@@ -1119,12 +1156,44 @@ __global__ __launch_bounds__(256) void mse_loss_kernel(float* __restrict__ loss,
     acc = block_sum256(acc, sh);
     if (threadIdx.x == 0) atomicAdd(loss, acc * inv);
 }
+// the step's latent (<= 256K elements): ONE block of 1024 threads, a pixel per thread and iteration (32-bit index math, the C channels
+// of the NHWC prediction contiguous), fixed shuffle / LDS reduction tree -> the scalar is bitwise reproducible and is written directly
+// (no zero-fill launch, no atomic). Round 2's 256-thread grid-stride form with 64-bit div / mod per element took 44 us (170 us at bs=4).
+template <typename T>
+__global__ __launch_bounds__(1024) void mse_loss_block_kernel(float* __restrict__ loss, T* __restrict__ dpred, const T* __restrict__ pred,
+                                                              const float* __restrict__ target, int B, int C, int HW) {
+    __shared__ float sh[16];
+    const int npix = B * HW;
+    const float inv = 1.f / ((float)npix * (float)C);
+    float acc = 0.f;
+    for (int p = threadIdx.x; p < npix; p += 1024) {
+        const int b = p / HW, hw = p - b * HW;
+        for (int c = 0; c < C; ++c) {
+            const float d = ld1(pred + (long)p * C + c) - target[((long)b * C + c) * HW + hw];
+            acc += d * d;
+            if (dpred) st1(dpred + (long)p * C + c, 2.f * d * inv);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        *loss = t * inv;
+    }
+}
 void k_mse_loss(const Launch& L, DType dt, float* loss, void* dpred, const void* pred, const float* target_nchw, int B, int C, int HW) {
-    LAUNCH((fill_kernel<float>), dim3(1), dim3(64), L, loss, 1L, 0.f);
-    // one block up to 256K elements (the latent of bs <= 16): the scalar is then summed in a fixed order — with several blocks
-    // the float atomicAdd order, and with it the last bits of the reported loss, would vary from run to run
     const long total = (long)B * C * HW;
-    CB_DT_SWITCH(dt, T, LAUNCH((mse_loss_kernel<T>), total <= (1L << 18) ? dim3(1) : grid1d(total, 256, 64), dim3(256), L, loss, (T*)dpred,
+    if (total <= (1L << 18)) {
+        CB_DT_SWITCH(dt, T, LAUNCH((mse_loss_block_kernel<T>), dim3(1), dim3(1024), L, loss, (T*)dpred, (const T*)pred, target_nchw, B, C, HW));
+        return;
+    }
+    LAUNCH((fill_kernel<float>), dim3(1), dim3(64), L, loss, 1L, 0.f);
+    // larger tensors (op-level callers): several blocks + float atomicAdd — the last bits of the scalar then depend on the arrival order
+    CB_DT_SWITCH(dt, T, LAUNCH((mse_loss_kernel<T>), grid1d(total, 256, 64), dim3(256), L, loss, (T*)dpred,
                                (const T*)pred, target_nchw, B, C, HW));
 }
 
