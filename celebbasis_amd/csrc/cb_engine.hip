@@ -365,7 +365,10 @@ Ten* Graph::linear(Ten* x, const Lin& l, Ten* residual) {
     long rows = x->rows();
     const int inp = l.in_p ? l.in_p : l.in;
     if (residual) CB_CHECK(residual->numel() == y->numel() && residual->dt == y->dt, CB_ERR_SHAPE, "linear: residual shape");
-    if (rows <= 8 && !residual && inp == l.in) {
+    // few rows: a one-wave-per-output-column GEMV streams the weight once — but it re-reads all `rows` input rows per weight chunk, so it
+    // only pays while those stay cache-resident (time embedding, emb_layers, the MLP head: <= 1280 inputs per row). The FR backbone's
+    // 25088 -> 512 fc at 8 faces ran 220 us that way (233 GB/s of weight traffic); the split-K GEMM takes it instead.
+    if (rows <= 8 && !residual && inp == l.in && l.in <= 8192) {
         k_gemv(L, x->dt, y->p, x->p, l.w, l.b, (int)rows, l.out, l.in);
     } else {
         GemmArgs a;
