@@ -183,15 +183,29 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
     ach = dom["flops"] / (dom["ms"] * 1e-3) / 1e12
     src, stale, per_sym, sym_ms = rocprof_trace(bf16)
 
+    # fused-attention profiler rows span several kernel symbols (weights: the share of a symbol that belongs to the row — the v2 transposes
+    # run once per forward and three times per backward launch)
+    n_f2f = sum(q["launches"] for q in prof if q["kernel"] == "flash_bf16_v2_fwd_kernel")
+    n_f2b = sum(q["launches"] for q in prof if q["kernel"] == "flash_bf16_v2_bwd_kernels")
+    tshare = n_f2f / max(n_f2f + 3 * n_f2b, 1)
+    FLASH_SYMS = {
+        "flash_fwd_kernel": [("flash_fwd_kernel", 1.0), ("flash_fwd_combine_kernel", 1.0)],
+        "flash_bwd_kernels": [("flash_bwd_dq_kernel", 1.0), ("flash_bwd_dkv_kernel", 1.0), ("flash_dkv_reduce_kernel", 1.0), ("flash_dq_combine_kernel", 1.0),
+                              ("flash_dvec_kernel", 1.0)],
+        "flash_bf16_fwd_kernel": [("flash_bf16_fwd_kernel", 1.0)],
+        "flash_bf16_bwd_kernels": [("flash_bf16_dq_kernel", 1.0), ("flash_bf16_dkv_kernel", 1.0), ("flash_bf16_dkv_reduce_kernel", 1.0), ("flash_bf16_dvec_kernel", 1.0)],
+        "flash_bf16_v2_fwd_kernel": [("f2_fwd_kernel", 1.0), ("f2_transpose_kernel", tshare)],
+        "flash_bf16_v2_bwd_kernels": [("f2_dq_kernel", 1.0), ("f2_dkv_kernel", 1.0), ("f2_transpose_kernel", 1.0 - tshare)],
+    }
+
     def trace_ms(p):
         """(ms per step, launches per step) of a profiler row in the matching trace, or (None, None)"""
         sym = trace_symbol(p["kernel"])
         if sym in per_sym:
             return per_sym[sym][1], per_sym[sym][0]
-        base = p["kernel"].split("<")[0].split("[")[0]
-        same = [q for q in prof if q["kernel"].split("<")[0].split("[")[0] == base]
-        if base.startswith("flash") and len(same) == 1 and base + "_kernel" in sym_ms:
-            return sym_ms[base + "_kernel"], None
+        grp = FLASH_SYMS.get(p["kernel"])
+        if grp and any(b_ in sym_ms for b_, _ in grp):
+            return sum(sym_ms.get(b_, 0.0) * w for b_, w in grp), None
         return None, None
 
     hb = []
