@@ -489,7 +489,7 @@ void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     }
 }
 
-constexpr int kMaxBatch = 8;
+constexpr int kMaxBatch = 16;
 static const float kTheta[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f,     // meta_net.py:131-142 trans_matrix
                                 0.03625215f, 1.07695457f, -5.32134629f / 512.f};
 

@@ -453,7 +453,8 @@ def test_argument_errors_on_a_dry_context(built_lib):
     shapes = dict(synthetic.trainer_shapes()); shapes.update(synthetic.decoder_shapes())
     wt = lib.WeightTable(shapes)
     tr = lib.Trainer(ctx, wt)
-    for bad in (0, 9):
+    tr.step(16, None, None, None, None, None, None, 5e-3)          # the largest supported batch plans on a dry context
+    for bad in (0, 17):
         with pytest.raises(lib.CBError) as e:
             tr.step(bad, None, None, None, None, None, None, 5e-3)
         assert "batch" in str(e.value)
