@@ -65,15 +65,9 @@ int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
         CB_CHECK(std::string(prop.gcnArchName).rfind("gfx950", 0) == 0, CB_ERR_HIP,
                  "libcelebbasis_hip is built for gfx950 (MI355X) only; device %d is %s", device, prop.gcnArchName);
         c.stream = static_cast<hipStream_t>(hip_stream);
-        {   // The identity branch (FR backbone, head, CLIP text forward: ~400 launches of 5 - 50 us) shares the chip with the VAE encode's
-            // 500 us convolutions and is the longer of the two: its small kernels must not queue behind the big ones for CU slots, so its
-            // stream gets the device's highest priority. CB_AUX_PRIORITY overrides (0 = same as the context stream).
-            int lo = 0, hi = 0;
-            CB_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            static const int want = [] { const char* e = getenv("CB_AUX_PRIORITY"); return e ? atoi(e) : -1; }();
-            const int prio = want < hi ? hi : (want > lo ? lo : want);
-            CB_HIP(hipStreamCreateWithPriority(&c.aux, hipStreamNonBlocking, prio));
-        }
+        // (a high-priority side stream was measured: 39.23 / 39.09 ms against 39.24 / 39.26 ms per fp32 step, 34.64 / 34.41 against 34.55 / 34.56 ms
+        //  per bf16 step — no effect, plain stream kept; profiles/README.md round 3)
+        CB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
         CB_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         CB_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
     }

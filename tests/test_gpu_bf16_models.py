@@ -165,6 +165,33 @@ def test_train_20_steps_sd14_bf16_bs4_horizon(cbf, golden_dir):
     assert g1 <= 3e-2, f"first-step dW relative L2 {g1:.3e} (bf16 UNet backward) — measured 7e-3 .. 8e-3"
 
 
+def test_trainer_step_b16_largest_batch_is_finite_and_deterministic(cbf):
+    """the largest batch the trainer accepts (kMaxBatch = 16: 32 faces, a 16384-row head GEMM instead of the GEMV, 48 GiB of step arena in
+    bf16) at SD size: two steps from the same state give the same loss bit for bit and finite gradients (no oracle at this size)"""
+    from celebbasis_amd import synthetic
+    lib, ctx = cbf
+    state = synthetic.synthetic_state(synthetic.trainer_shapes(), seed=0)
+    tr = lib.Trainer(ctx, lib.WeightTable(state))
+    b = synthetic.synthetic_batch(16, step=0, device=DEV, identity=1)
+    losses = []
+    for _ in range(2):
+        tr.set_state("mlp.weight", state["embedding_manager.meta_id_net.stylegan_mlp.net.0.weight"])
+        tr.set_state("mlp.bias", state["embedding_manager.meta_id_net.stylegan_mlp.net.0.bias"])
+        tr.set_state("step", torch.zeros(1))
+        for n_, k in (("adam.m_weight", 1024 * 512), ("adam.v_weight", 1024 * 512), ("adam.m_bias", 1024), ("adam.v_bias", 1024)):
+            tr.set_state(n_, torch.zeros(k))
+        tr.step(b["image"], b["faces"], b["ids"], b["tokens"], b["t"], b["noise"], b["post_noise"], 5e-3 * 16)
+        ctx.sync()
+        losses.append(float(tr.get_state("loss")[0]))
+        assert torch.isfinite(tr.get_state("mlp.weight")).all() and torch.isfinite(tr.get_state("mlp.grad_weight")).all()
+    REPORT["bf16.step[512px,B16].loss"] = losses
+    assert losses[0] == losses[1] and 0.5 < losses[0] < 3.0
+    with pytest.raises(lib.CBError):
+        b17 = synthetic.synthetic_batch(17, step=0, device=DEV, identity=1)
+        tr.step(b17["image"], b17["faces"], b17["ids"], b17["tokens"], b17["t"], b17["noise"], b17["post_noise"], 5e-3)
+    tr.close()
+
+
 def test_sampler_mini_bf16_vs_oracle(cbf):
     """DDIM with guidance on a bf16 context (the reference samples under fp16 autocast, stable_txt2img.py:320-322): the sampler
     state stays fp32, the UNet runs in bf16; 4 steps against the fp32 oracle"""

@@ -390,6 +390,63 @@ def test_run_config5_launches_its_own_ranks_and_checks_the_merge():
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
 
 
+def test_build_guard_flags_scratch_in_counted_wait_kernels():
+    """celebbasis_amd/build.py parses -Rpass-analysis=kernel-resource-usage remarks and fails the build when a kernel whose software
+    pipeline counts its VMEM instructions (cb_gemm_glds.hip, cb_flash_bf16_v2.hip) has scratch, spills or a dynamic stack"""
+    from celebbasis_amd import build
+    ok = """x.hip:5:1: remark: Function Name: _ZN2cb16gemm_glds_kernelIfLi64ELi64ELi0ELi128ELi2EEEvNS_5KArgsE [-Rpass-analysis=kernel-resource-usage]
+x.hip:5:1: remark:     VGPRs: 47 [-Rpass-analysis=kernel-resource-usage]
+x.hip:5:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:5:1: remark:     Dynamic Stack: False [-Rpass-analysis=kernel-resource-usage]
+x.hip:5:1: remark:     SGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:5:1: remark:     VGPRs Spill: 0 [-Rpass-analysis=kernel-resource-usage]
+x.hip:9:1: remark: Function Name: _ZN2cb20splitk_reduce_kernelIfEEvNS_5KArgsE [-Rpass-analysis=kernel-resource-usage]
+x.hip:9:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-resource-usage]
+"""
+    bad, seen = build.check_no_scratch(ok, "gemm_glds")
+    assert bad == [] and seen == 1                       # the spilling kernel is not one of the guarded ones
+    spill = ok.replace("ScratchSize [bytes/lane]: 0", "ScratchSize [bytes/lane]: 104").replace("VGPRs Spill: 0", "VGPRs Spill: 25")
+    bad, seen = build.check_no_scratch(spill, "gemm_glds")
+    assert seen == 1 and {b[1] for b in bad} == {"ScratchSize [bytes/lane]", "VGPRs Spill"} and bad[0][0].startswith("_ZN2cb16gemm_glds")
+    assert build.check_no_scratch("", "gemm_glds") == ([], 0)          # no remarks at all is an error for the caller (seen == 0)
+    d = build.source_digest()
+    assert set(d) == {"src_sha", "plan_table_sha"} and len(d["src_sha"]) == 16 and d == build.source_digest()
+    assert set(build.NO_SCRATCH) == {"cb_gemm_glds.hip", "cb_flash_bf16_v2.hip"}
+
+
+def test_bench_uses_committed_profiles_only_when_their_stamp_is_this_tree(tmp_path, monkeypatch):
+    """bench.py quotes rocprofv3 / PMC numbers from profiles/ only if they were measured on the running tree (stamp = sha of the kernel
+    sources + plan table); anything else is `profile_stale` and contributes nothing to the line"""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    monkeypatch.setattr(sys, "argv", ["bench.py"])
+    spec.loader.exec_module(bench)
+    st = bench.tree_stamp()
+    (tmp_path / "profiles").mkdir()
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    body = "name,calls,total_ms,ms_per_step,avg_us,min_us,max_us,pct\n" \
+           '"gemm_glds_kernel<float, 128, 128, 2, 128, 2>",378,79.8,8.867,211.1,72.2,736.1,20.8\n"splitk_reduce_kernel<float>",3924,22.5,2.509,5.75,2.8,14.6,5.9\n'
+    good = f"# stamp src_sha={st['src_sha']} plan_table_sha={st['plan_table_sha']} nsteps=9\n# rocprofv3\n" + body
+    (tmp_path / "profiles" / "r03z_bench_kernel_stats.csv").write_text(good)
+    src, stale, per, base = bench.rocprof_trace(False)
+    assert src == "r03z_bench_kernel_stats.csv" and stale is False and abs(base["splitk_reduce_kernel"] - 2.509) < 1e-9
+    assert per["gemm_glds_kernel<float, 128, 128, 2, 128, 2>"][0] == 42.0           # launches per step from calls / nsteps
+    assert bench.trace_symbol("gemm_glds_kernel<float,128,128,CONVF>") == "gemm_glds_kernel<float, 128, 128, 2, 128, 2>"
+    (tmp_path / "profiles" / "r03z_bench_kernel_stats.csv").write_text(good.replace(st["src_sha"], "0" * 16))
+    src, stale, per, base = bench.rocprof_trace(False)
+    assert stale is True and per == {} and base == {}
+    pmc = {"stamp": st, "per_symbol": {"gemm_glds_kernel<float, 128, 128, 2, 128, 2>": {"launches": 210, "fetch_bytes_per_launch": 90e6, "write_bytes_per_launch": 24e6}}}
+    (tmp_path / "profiles" / "r03z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
+    assert t == 204000000 and det["stale"] is False and det["fetch_size_bytes_per_launch_raw"] == 90000000      # 2 x FETCH_SIZE + WRITE_SIZE
+    pmc["stamp"] = {"src_sha": "x", "plan_table_sha": "y"}
+    (tmp_path / "profiles" / "r03z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
+    assert t is None and det["stale"] is True
+
+
 def test_bench_line_contract_of_committed_profile():
     """the bench.py JSON line committed under profiles/ carries every field of the driver's contract (keys and types), the
     roofline and cpu_baseline objects, and internally consistent numbers"""
