@@ -26,10 +26,21 @@ typedef unsigned u32x4b __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int F2_TK = 64;             // rows of a streamed tile
-constexpr int F2_IMG = 64 * 8 * 16;   // one tile image: 64 rows x 8 chunks of 16 bytes. Row-major image: rows = keys / queries, chunk c =
-                                      // head-dim elements 8c .. 8c+7 (d <= 64); transposed image: rows = head-dim index, chunk c = permuted
-                                      // positions 8c .. 8c+7 of the 64-row tile
 constexpr int F2_OOB = -16;           // 0xFFFFFFF0 >= num_records: the DMA writes zeros
+// Tile images (all in 16-byte chunks, filled by LDS-DMA in 4 KiB slots = 256 threads x 16 bytes):
+//   row-major image  : 64 rows (keys / queries) x 4 KS chunks — chunk c = head-dim elements 8c .. 8c+7; KS = 32-wide k groups of the head
+//                      dim: 2 (d <= 64: 128-byte rows) or 3 (d <= 96: 192-byte rows)
+//   transposed image : 16 DT rows (head-dim index) x 8 chunks — chunk c = permuted positions 8c .. 8c+7 of the 64-row tile
+template <int KS> struct F2R { static constexpr int CPR = 4 * KS, NS = CPR * 64 / 256, BYTES = NS * 4096; };
+template <int DT> struct F2T { static constexpr int NS = (16 * DT * 8 + 255) / 256, BYTES = NS * 4096; };
+// bank swizzle of a row-major image, applied to the LOGICAL chunk index c of row r (an involution within aligned groups of 8 / 4 chunks):
+// 128-byte rows (8 chunks): c ^ ((r >> 1) & 7), the scheme of cb_gemm_glds.hip; 192-byte rows (12 chunks): consecutive rows already start
+// 12 bank quads apart, so only the low two chunk bits are permuted, by {0,3,2,1}[(r >> 2) & 3] — with either, the 16-lane groups of the
+// MFMA operand read (ds_read_b128: rows {0-3,12-15} at chunk 4ks+g and rows {4-11} at chunk 4ks+g+1, ...) hit 16 distinct bank quads.
+template <int KS> __device__ __forceinline__ int f2_swz(int c, int r) {
+    if constexpr (KS == 2) return c ^ ((r >> 1) & 7);
+    else return c ^ ((0x6C >> (2 * ((r >> 2) & 3))) & 3);          // 0x6C = 01 10 11 00b : {0, 3, 2, 1}
+}
 
 __device__ __forceinline__ float f2_quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float f2_quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
@@ -40,10 +51,11 @@ __device__ __forceinline__ bf16x8_t f2_pack8(const f32x4& a, const f32x4& b) {
     bf16x8_t r = {(bf16_t)a[0], (bf16_t)a[1], (bf16_t)a[2], (bf16_t)a[3], (bf16_t)b[0], (bf16_t)b[1], (bf16_t)b[2], (bf16_t)b[3]};
     return r;
 }
-// a row of the head as MFMA B operand: reg[s] = src[row][32s + 8g .. +7], zero beyond d / limit  (two 32-wide k groups: d <= 64)
-__device__ __forceinline__ void f2_rowregs(bf16x8_t (&reg)[2], const bf16_t* __restrict__ src, long ld, int row, int limit, int d, int g) {
+// a row of the head as MFMA B operand: reg[s] = src[row][32s + 8g .. +7], zero beyond d / limit
+template <int KS>
+__device__ __forceinline__ void f2_rowregs(bf16x8_t (&reg)[KS], const bf16_t* __restrict__ src, long ld, int row, int limit, int d, int g) {
 #pragma unroll
-    for (int s = 0; s < 2; ++s) {
+    for (int s = 0; s < KS; ++s) {
         const int c = 32 * s + 8 * g;
         u32x4b v = {0u, 0u, 0u, 0u};
         if (row < limit && c < d) v = *reinterpret_cast<const u32x4b*>(src + (long)row * ld + c);
@@ -56,49 +68,62 @@ __device__ __forceinline__ void f2_store4(bf16_t* p, const f32x4& v, float beta)
     st4(p, o);
 }
 
-// ---- LDS-DMA of one 64-row tile image: thread slot idx = tid + 256 i (i = 0, 1) owns LDS chunk idx = (row = idx >> 3, physical chunk
-// idx & 7) and fetches LOGICAL chunk (idx & 7) ^ ((row >> 1) & 7) of that row.
-struct F2Slots {
-    int off[2];                        // byte offset of (row, logical chunk) relative to the tile's first row, or F2_OOB
-    int row[2];
+// ---- LDS-DMA of one tile image: thread slot idx = tid + 256 i owns LDS chunk idx (lane-linear image) = (row, physical chunk) and fetches
+// the LOGICAL chunk the swizzle maps there.
+template <int NS> struct F2Slots {
+    int off[NS];                       // byte offset of (row, logical chunk) relative to the tile's first row, or F2_OOB
+    int row[NS];
     // row-major source: element (r, 8c) of a [rows][ld] matrix; chunks at or beyond the head dim d are never fetched (zeros)
-    __device__ __forceinline__ void init_rows(long ld, int d, int tid) {
+    template <int KS> __device__ __forceinline__ void init_rows(long ld, int d, int tid) {
+        constexpr int CPR = F2R<KS>::CPR;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) ^ ((r >> 1) & 7);
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + 256 * i, r = idx / CPR, c = f2_swz<KS>(idx - r * CPR, r);
             row[i] = r;
             off[i] = (8 * c < d) ? (int)(((long)r * ld + 8 * c) * 2) : F2_OOB;
         }
     }
-    // transposed source: row = head-dim index (< DR) of a [DR][Np] image, chunk = 8 positions
+    // transposed source: row = head-dim index (< DR) of a [DR][Np] image, 8 chunks of 8 positions per row (128-byte rows)
     __device__ __forceinline__ void init_tr(int Np, int DR, int tid) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) ^ ((r >> 1) & 7);
+        for (int i = 0; i < NS; ++i) {
+            const int idx = tid + 256 * i, r = idx >> 3, c = f2_swz<2>(idx & 7, r);
             row[i] = r;
             off[i] = (r < DR) ? (r * Np + 8 * c) * 2 : F2_OOB;
         }
     }
 };
 // dst = this wave's 1 KiB piece of the image (wave-uniform): image + 1024 * wave; slot i lands 4 KiB further
-__device__ __forceinline__ void f2_dma_rows(__amdgpu_buffer_rsrc_t srd, char* dst, const F2Slots& s, int r0, int limit, long ld) {
+template <int NS>
+__device__ __forceinline__ void f2_dma_rows(__amdgpu_buffer_rsrc_t srd, char* dst, const F2Slots<NS>& s, int r0, int limit, long ld) {
     const int base = (int)((long)r0 * ld * 2);
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const int o = (s.off[i] != F2_OOB && r0 + s.row[i] < limit) ? s.off[i] + base : F2_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(dst + i * 4096), 16, o, 0, 0, 0);
     }
 }
-__device__ __forceinline__ void f2_dma_tr(__amdgpu_buffer_rsrc_t srd, char* dst, const F2Slots& s, int p0) {
+template <int NS>
+__device__ __forceinline__ void f2_dma_tr(__amdgpu_buffer_rsrc_t srd, char* dst, const F2Slots<NS>& s, int p0) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < NS; ++i) {
         const int o = (s.off[i] != F2_OOB) ? s.off[i] + p0 * 2 : F2_OOB;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(dst + i * 4096), 16, o, 0, 0, 0);
     }
 }
-// MFMA A-operand read of a tile image: 16-row block `blk`, 32-wide k group `kg` (lane (l15, g) holds k-slots 8g .. 8g+7 of the group)
-__device__ __forceinline__ bf16x8_t f2_frag(const char* img, int blk, const int (&lo)[2], int kg) {
-    return *reinterpret_cast<const bf16x8_t*>(img + blk * 2048 + lo[kg]);
+// MFMA A-operand reads: 16-row block `blk` of an image, 32-wide k group `kg` (lane (l15, g) holds k-slots 8g .. 8g+7 of the group).
+// lor[kg] / lot[kg] = this lane's byte offset inside a block of the row-major / transposed image (f2_lane_offsets)
+template <int KS> __device__ __forceinline__ bf16x8_t f2_frag_r(const char* img, int blk, const int (&lor)[KS], int kg) {
+    return *reinterpret_cast<const bf16x8_t*>(img + blk * (16 * F2R<KS>::CPR * 16) + lor[kg]);
+}
+__device__ __forceinline__ bf16x8_t f2_frag_t(const char* img, int blk, const int (&lot)[2], int kg) {
+    return *reinterpret_cast<const bf16x8_t*>(img + blk * 2048 + lot[kg]);
+}
+template <int KS> __device__ __forceinline__ void f2_lane_offsets(int (&lor)[KS], int (&lot)[2], int l15, int g) {
+#pragma unroll
+    for (int x = 0; x < KS; ++x) lor[x] = (l15 * F2R<KS>::CPR + f2_swz<KS>(4 * x + g, l15)) * 16;
+#pragma unroll
+    for (int x = 0; x < 2; ++x) lot[x] = (l15 * 8 + f2_swz<2>(4 * x + g, l15)) * 16;
 }
 
 // ---------------------------------------------------------------------------------------------- prepass: transpose + permute
@@ -142,9 +167,9 @@ __global__ __launch_bounds__(256) void f2_transpose_kernel(const bf16_t* __restr
 // half a v_cvt_pk per score: the maximum is taken on the raw scores (scale > 0), the scale and the running maximum enter the exponent as
 // one FMA, and with ONES the row sum comes out of the P.V MFMA (row d of the V^T image is all ones) instead of 16 v_add per lane and tile;
 // the accumulator rescale is skipped while no lane's running maximum moves.
-template <int DT, int QB, bool ONES, bool RG>
+template <int KS, int DT, int QB, bool ONES, bool RG>
 __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const bf16_t* __restrict__ VTg, int Np) {
-    constexpr int STAGE = 2 * F2_IMG;
+    constexpr int RIMG = F2R<KS>::BYTES, STAGE = RIMG + F2T<DT>::BYTES;
     __shared__ __attribute__((aligned(16))) char ring[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
@@ -153,9 +178,9 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
     const bf16_t* K = static_cast<const bf16_t*>(a.k) + b * a.skb + h * a.skh;
     constexpr int DR = 16 * DT;
 
-    bf16x8_t qreg[QB][2];
+    bf16x8_t qreg[QB][KS];
 #pragma unroll
-    for (int qb = 0; qb < QB; ++qb) f2_rowregs(qreg[qb], Q, a.ldq, q0 + 16 * qb + l15, a.Nq, a.d, g);
+    for (int qb = 0; qb < QB; ++qb) f2_rowregs<KS>(qreg[qb], Q, a.ldq, q0 + 16 * qb + l15, a.Nq, a.d, g);
     const float scale2 = a.scale * 1.4426950408889634f;          // scores are kept in the log2 domain
     f32x4 o[QB][DT];
     float m[QB], l[QB];
@@ -166,17 +191,17 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
         for (int t = 0; t < DT; ++t) o[qb][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     const __amdgpu_buffer_rsrc_t srdK = f2_srd(K), srdT = f2_srd(VTg + (long)bh * DR * Np);
-    F2Slots sk, st;
-    sk.init_rows(a.ldk, a.d, tid);
+    F2Slots<F2R<KS>::NS> sk;
+    F2Slots<F2T<DT>::NS> st;
+    sk.template init_rows<KS>(a.ldk, a.d, tid);
     st.init_tr(Np, DR, tid);
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 1024);
-    int lo[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) lo[x] = (l15 * 8 + ((4 * x + g) ^ (l15 >> 1))) * 16;
+    int lor[KS], lot[2];
+    f2_lane_offsets<KS>(lor, lot, l15, g);
 
     const int ntiles = (a.Nk + F2_TK - 1) / F2_TK;
     f2_dma_rows(srdK, ring + wbase, sk, 0, a.Nk, a.ldk);
-    f2_dma_tr(srdT, ring + F2_IMG + wbase, st, 0);
+    f2_dma_tr(srdT, ring + RIMG + wbase, st, 0);
     for (int t = 0; t < ntiles; ++t) {
         // tile t has landed for this wave (nothing else is in flight) ... and, after the barrier, for every wave; the barrier also says
         // that everybody has finished reading the other slot, which is refilled next
@@ -185,14 +210,14 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
         if (t + 1 < ntiles) {
             char* nx = ring + ((t + 1) & 1) * STAGE + wbase;
             f2_dma_rows(srdK, nx, sk, (t + 1) * F2_TK, a.Nk, a.ldk);
-            f2_dma_tr(srdT, nx + F2_IMG, st, (t + 1) * F2_TK);
+            f2_dma_tr(srdT, nx + RIMG, st, (t + 1) * F2_TK);
         }
         // the key mask exists only in the last tile of a ragged key count: two instantiations of the tile body behind a wave-uniform branch
         // (left to the compiler, the masking turns into 64 v_cndmask per row block in EVERY tile)
         auto tile_body = [&](auto mask_tag) {
             constexpr bool MK = decltype(mask_tag)::value;
             const char* Ks = ring + (t & 1) * STAGE;
-            const char* Vt = Ks + F2_IMG;
+            const char* Vt = Ks + RIMG;
             const int k0 = t * F2_TK;
             f32x4 s[QB][4];
 #pragma unroll
@@ -200,10 +225,10 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) s[qb][kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 2; ++ks)
+            for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int kt = 0; kt < 4; ++kt) {
-                    const bf16x8_t av = f2_frag(Ks, kt, lo, ks);
+                    const bf16x8_t av = f2_frag_r<KS>(Ks, kt, lor, ks);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) s[qb][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, qreg[qb][ks], s[qb][kt], 0, 0, 0);
                 }
@@ -246,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
                 for (int qb = 0; qb < QB; ++qb) pb[qb] = f2_pack8(s[qb][2 * G], s[qb][2 * G + 1]);
 #pragma unroll
                 for (int t2 = 0; t2 < DT; ++t2) {
-                    const bf16x8_t av = f2_frag(Vt, t2, lo, G);
+                    const bf16x8_t av = f2_frag_t(Vt, t2, lot, G);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) o[qb][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pb[qb], o[qb][t2], 0, 0, 0);
                 }
@@ -279,10 +304,12 @@ __global__ __launch_bounds__(256, 2) void f2_fwd_kernel(const FlashArgs a, const
 
 // ---------------------------------------------------------------------------------------------- backward: dQ
 // block: 4 waves x (16 QB) queries; stage = {K (row-major), V (row-major), K^T (transposed)}; also publishes D = rowsum(dO * O)
-template <int DT, int QB, bool RG>
+template <int KS, int DT> constexpr int f2_dq_stage() { return 2 * F2R<KS>::BYTES + F2T<DT>::BYTES; }
+template <int KS, int DT, int QB, bool RG>
 __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const bf16_t* __restrict__ KTg, int Np) {
-    constexpr int STAGE = 3 * F2_IMG;
-    __shared__ __attribute__((aligned(16))) char ring[2 * STAGE];
+    constexpr int RIMG = F2R<KS>::BYTES, STAGE = f2_dq_stage<KS, DT>();
+    extern __shared__ __attribute__((aligned(16))) char ring_dq[];          // 2 x STAGE (48 KB at d <= 64, 72 KB at d <= 96: dynamic)
+    char* ring = ring_dq;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = blockIdx.x * (64 * QB) + wave * (16 * QB);
@@ -293,20 +320,20 @@ __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const 
     const bf16_t* Oo = static_cast<const bf16_t*>(a.o) + b * a.sob + h * a.soh;
     constexpr int DR = 16 * DT;
 
-    bf16x8_t qreg[QB][2], dreg[QB][2];
+    bf16x8_t qreg[QB][KS], dreg[QB][KS];
     float lse[QB], Dq[QB];
     f32x4 gq[QB][DT];
 #pragma unroll
     for (int qb = 0; qb < QB; ++qb) {
         const int qrow = q0 + 16 * qb + l15;
-        f2_rowregs(qreg[qb], Q, a.ldq, qrow, a.Nq, a.d, g);
-        f2_rowregs(dreg[qb], dO, a.ldo, qrow, a.Nq, a.d, g);
+        f2_rowregs<KS>(qreg[qb], Q, a.ldq, qrow, a.Nq, a.d, g);
+        f2_rowregs<KS>(dreg[qb], dO, a.ldo, qrow, a.Nq, a.d, g);
         lse[qb] = qrow < a.Nq ? a.lse[(long)bh * a.Nq + qrow] : 0.f;
-        bf16x8_t oreg[2];
-        f2_rowregs(oreg, Oo, a.ldo, qrow, a.Nq, a.d, g);
+        bf16x8_t oreg[KS];
+        f2_rowregs<KS>(oreg, Oo, a.ldo, qrow, a.Nq, a.d, g);
         float dsum = 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < 2; ++s_)
+        for (int s_ = 0; s_ < KS; ++s_)
 #pragma unroll
             for (int e = 0; e < 8; ++e) dsum += (float)oreg[s_][e] * (float)dreg[qb][s_][e];
         dsum = f2_quad_sum(dsum);
@@ -317,32 +344,32 @@ __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const 
     }
     const float scale2 = a.scale * 1.4426950408889634f;
     const __amdgpu_buffer_rsrc_t srdK = f2_srd(K), srdV = f2_srd(V), srdT = f2_srd(KTg + (long)bh * DR * Np);
-    F2Slots sr, st;
-    sr.init_rows(a.ldk, a.d, tid);
+    F2Slots<F2R<KS>::NS> sr;
+    F2Slots<F2T<DT>::NS> st;
+    sr.template init_rows<KS>(a.ldk, a.d, tid);
     st.init_tr(Np, DR, tid);
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 1024);
-    int lo[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) lo[x] = (l15 * 8 + ((4 * x + g) ^ (l15 >> 1))) * 16;
+    int lor[KS], lot[2];
+    f2_lane_offsets<KS>(lor, lot, l15, g);
 
     const int ntiles = (a.Nk + F2_TK - 1) / F2_TK;
     f2_dma_rows(srdK, ring + wbase, sr, 0, a.Nk, a.ldk);
-    f2_dma_rows(srdV, ring + F2_IMG + wbase, sr, 0, a.Nk, a.ldk);
-    f2_dma_tr(srdT, ring + 2 * F2_IMG + wbase, st, 0);
+    f2_dma_rows(srdV, ring + RIMG + wbase, sr, 0, a.Nk, a.ldk);
+    f2_dma_tr(srdT, ring + 2 * RIMG + wbase, st, 0);
     for (int t = 0; t < ntiles; ++t) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         if (t + 1 < ntiles) {
             char* nx = ring + ((t + 1) & 1) * STAGE + wbase;
             f2_dma_rows(srdK, nx, sr, (t + 1) * F2_TK, a.Nk, a.ldk);
-            f2_dma_rows(srdV, nx + F2_IMG, sr, (t + 1) * F2_TK, a.Nk, a.ldk);
-            f2_dma_tr(srdT, nx + 2 * F2_IMG, st, (t + 1) * F2_TK);
+            f2_dma_rows(srdV, nx + RIMG, sr, (t + 1) * F2_TK, a.Nk, a.ldk);
+            f2_dma_tr(srdT, nx + 2 * RIMG, st, (t + 1) * F2_TK);
         }
         auto tile_body = [&](auto mask_tag) {              // ragged last key tile only: see f2_fwd_kernel
             constexpr bool MK = decltype(mask_tag)::value;
             const char* Ks = ring + (t & 1) * STAGE;
-            const char* Vs = Ks + F2_IMG;
-            const char* Kt = Ks + 2 * F2_IMG;
+            const char* Vs = Ks + RIMG;
+            const char* Kt = Ks + 2 * RIMG;
             const int k0 = t * F2_TK;
 #pragma unroll
             for (int G = 0; G < 2; ++G) {                               // one 32-key group at a time keeps S / dP at 2 sub-tiles per row block
@@ -352,11 +379,11 @@ __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const 
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) { s[qb][sub] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qb][sub] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) {
-                        const bf16x8_t ak = f2_frag(Ks, 2 * G + sub, lo, ks);
-                        const bf16x8_t av = f2_frag(Vs, 2 * G + sub, lo, ks);
+                        const bf16x8_t ak = f2_frag_r<KS>(Ks, 2 * G + sub, lor, ks);
+                        const bf16x8_t av = f2_frag_r<KS>(Vs, 2 * G + sub, lor, ks);
 #pragma unroll
                         for (int qb = 0; qb < QB; ++qb) {
                             s[qb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, qreg[qb][ks], s[qb][sub], 0, 0, 0);      // S^T  = K Q^T
@@ -379,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const 
                 // dQ^T += K^T dS^T
 #pragma unroll
                 for (int t2 = 0; t2 < DT; ++t2) {
-                    const bf16x8_t ak = f2_frag(Kt, t2, lo, G);
+                    const bf16x8_t ak = f2_frag_t(Kt, t2, lot, G);
 #pragma unroll
                     for (int qb = 0; qb < QB; ++qb) gq[qb][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ak, sb[qb], gq[qb][t2], 0, 0, 0);
                 }
@@ -409,10 +436,10 @@ __global__ __launch_bounds__(256, 2) void f2_dq_kernel(const FlashArgs a, const 
 //   dP[q][key]   = dO V^T        A = dO tile, B = V regs
 //   dV^T[d][key] += dO^T P       A = dO^T tile, B = P regs
 //   dK^T[d][key] += Q^T dS       A = Q^T tile,  B = dS regs
-constexpr int F2_DKV_STAGE = 4 * F2_IMG + 1024;
-template <int DT, int QB, bool RG>
+template <int KS, int DT> constexpr int f2_dkv_stage() { return 2 * F2R<KS>::BYTES + 2 * F2T<DT>::BYTES + 1024; }
+template <int KS, int DT, int QB, bool RG>
 __global__ __launch_bounds__(256, 2) void f2_dkv_kernel(const FlashArgs a, const bf16_t* __restrict__ QTg, const bf16_t* __restrict__ DTg, int Np) {
-    constexpr int STAGE = F2_DKV_STAGE;
+    constexpr int RIMG = F2R<KS>::BYTES, TIMG = F2T<DT>::BYTES, STAGE = f2_dkv_stage<KS, DT>();
     extern __shared__ __attribute__((aligned(16))) char ring2[];
     char* ring = ring2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g = lane >> 4;
@@ -424,39 +451,39 @@ __global__ __launch_bounds__(256, 2) void f2_dkv_kernel(const FlashArgs a, const
     const bf16_t* dO = static_cast<const bf16_t*>(a.dout) + b * a.sob + h * a.soh;
     constexpr int DR = 16 * DT;
 
-    bf16x8_t kreg[QB][2], vreg[QB][2];
+    bf16x8_t kreg[QB][KS], vreg[QB][KS];
     f32x4 gk[QB][DT], gv[QB][DT];
 #pragma unroll
     for (int kb = 0; kb < QB; ++kb) {
-        f2_rowregs(kreg[kb], K, a.ldk, k0 + 16 * kb + l15, a.Nk, a.d, g);
-        f2_rowregs(vreg[kb], V, a.ldk, k0 + 16 * kb + l15, a.Nk, a.d, g);
+        f2_rowregs<KS>(kreg[kb], K, a.ldk, k0 + 16 * kb + l15, a.Nk, a.d, g);
+        f2_rowregs<KS>(vreg[kb], V, a.ldk, k0 + 16 * kb + l15, a.Nk, a.d, g);
 #pragma unroll
         for (int t = 0; t < DT; ++t) { gk[kb][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; gv[kb][t] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
     }
     const float scale2 = a.scale * 1.4426950408889634f;
     const __amdgpu_buffer_rsrc_t srdQ = f2_srd(Q), srdD = f2_srd(dO), srdQT = f2_srd(QTg + (long)bh * DR * Np), srdDT = f2_srd(DTg + (long)bh * DR * Np);
     const __amdgpu_buffer_rsrc_t srdL = f2_srd(a.lse + (long)bh * a.Nq), srdS = f2_srd(a.dvec + (long)bh * a.Nq);
-    F2Slots sq, so, st;
-    sq.init_rows(a.ldq, a.d, tid);
-    so.init_rows(a.ldo, a.d, tid);
+    F2Slots<F2R<KS>::NS> sq, so;
+    F2Slots<F2T<DT>::NS> st;
+    sq.template init_rows<KS>(a.ldq, a.d, tid);
+    so.template init_rows<KS>(a.ldo, a.d, tid);
     st.init_tr(Np, DR, tid);
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 1024);
-    int lo[2];
-#pragma unroll
-    for (int x = 0; x < 2; ++x) lo[x] = (l15 * 8 + ((4 * x + g) ^ (l15 >> 1))) * 16;
+    int lor[KS], lot[2];
+    f2_lane_offsets<KS>(lor, lot, l15, g);
 
     // lse / D of a query tile: 64 + 64 floats = 32 chunks, fetched by wave 0 (lanes 0-15: lse, 16-31: D, the rest zero-fill their slots)
     auto issue = [&](int q0t, int slot) {
         char* nx = ring + slot * STAGE + wbase;
         f2_dma_rows(srdQ, nx, sq, q0t, a.Nq, a.ldq);
-        f2_dma_rows(srdD, nx + F2_IMG, so, q0t, a.Nq, a.ldo);
-        f2_dma_tr(srdQT, nx + 2 * F2_IMG, st, q0t);
-        f2_dma_tr(srdDT, nx + 3 * F2_IMG, st, q0t);
+        f2_dma_rows(srdD, nx + RIMG, so, q0t, a.Nq, a.ldo);
+        f2_dma_tr(srdQT, nx + 2 * RIMG, st, q0t);
+        f2_dma_tr(srdDT, nx + 2 * RIMG + TIMG, st, q0t);
         if (wave == 0) {
             const int c = lane & 15;
             const int o = (lane < 32 && q0t + 4 * c < a.Nq) ? (q0t + 4 * c) * 4 : F2_OOB;
-            if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdL, (lds_ptr_t)(ring + slot * STAGE + 4 * F2_IMG), 16, o, 0, 0, 0);
-            else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdS, (lds_ptr_t)(ring + slot * STAGE + 4 * F2_IMG), 16, o, 0, 0, 0);
+            if (lane < 16) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdL, (lds_ptr_t)(ring + slot * STAGE + 2 * RIMG + 2 * TIMG), 16, o, 0, 0, 0);
+            else __builtin_amdgcn_raw_ptr_buffer_load_lds(srdS, (lds_ptr_t)(ring + slot * STAGE + 2 * RIMG + 2 * TIMG), 16, o, 0, 0, 0);
         }
     };
     const int ntiles = (a.Nq + F2_TK - 1) / F2_TK;
@@ -468,10 +495,10 @@ __global__ __launch_bounds__(256, 2) void f2_dkv_kernel(const FlashArgs a, const
         auto tile_body = [&](auto mask_tag) {              // ragged query tile / ragged key block only: see f2_fwd_kernel
             constexpr bool MK = decltype(mask_tag)::value;
             const char* Qs = ring + (t & 1) * STAGE;
-            const char* Ds = Qs + F2_IMG;
-            const char* Qt = Qs + 2 * F2_IMG;
-            const char* Dt = Qs + 3 * F2_IMG;
-            const float* Ls = reinterpret_cast<const float*>(Qs + 4 * F2_IMG);          // lse[64], D[64]
+            const char* Ds = Qs + RIMG;
+            const char* Qt = Qs + 2 * RIMG;
+            const char* Dt = Qs + 2 * RIMG + TIMG;
+            const float* Ls = reinterpret_cast<const float*>(Qs + 2 * RIMG + 2 * TIMG);          // lse[64], D[64]
             const int q0t = t * F2_TK;
 #pragma unroll
             for (int G = 0; G < 2; ++G) {
@@ -481,11 +508,11 @@ __global__ __launch_bounds__(256, 2) void f2_dkv_kernel(const FlashArgs a, const
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) { s[kb][sub] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kb][sub] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks)
+                for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                     for (int sub = 0; sub < 2; ++sub) {
-                        const bf16x8_t aq = f2_frag(Qs, 2 * G + sub, lo, ks);
-                        const bf16x8_t ad = f2_frag(Ds, 2 * G + sub, lo, ks);
+                        const bf16x8_t aq = f2_frag_r<KS>(Qs, 2 * G + sub, lor, ks);
+                        const bf16x8_t ad = f2_frag_r<KS>(Ds, 2 * G + sub, lor, ks);
 #pragma unroll
                         for (int kb = 0; kb < QB; ++kb) {
                             s[kb][sub] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(aq, kreg[kb][ks], s[kb][sub], 0, 0, 0);
@@ -513,8 +540,8 @@ __global__ __launch_bounds__(256, 2) void f2_dkv_kernel(const FlashArgs a, const
                 }
 #pragma unroll
                 for (int t2 = 0; t2 < DT; ++t2) {
-                    const bf16x8_t ad = f2_frag(Dt, t2, lo, G);
-                    const bf16x8_t aq = f2_frag(Qt, t2, lo, G);
+                    const bf16x8_t ad = f2_frag_t(Dt, t2, lot, G);
+                    const bf16x8_t aq = f2_frag_t(Qt, t2, lot, G);
 #pragma unroll
                     for (int kb = 0; kb < QB; ++kb) {
                         gv[kb][t2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ad, pb[kb], gv[kb][t2], 0, 0, 0);
@@ -550,9 +577,11 @@ static bool f2_enabled() {
 static int f2_np(int n) { return (n + F2_TK - 1) / F2_TK * F2_TK; }
 static int f2_dt(int d) { return (d + 15) / 16; }
 
+// Shapes v2 takes: 32 < d <= 64 (two 32-wide k groups: the 64x64-level self-attention, d = 40) and 64 < d <= 80 (three k groups, five
+// output tiles: the 32x32 level, d = 80); no mask; at least 256 rows on both sides; row counts multiples of 8 (16-byte lse / D chunks).
 bool flash_bf16_v2_ok(const FlashArgs& a) {
     if (!f2_enabled() || a.dt != DT_BF16 || a.causal) return false;
-    if (a.d <= 32 || a.d > 64 || a.d % 8) return false;
+    if (a.d <= 32 || a.d > 80 || a.d % 8) return false;
     if (a.Nq < 256 || a.Nk < 256 || a.Nq % 8 || a.Nk % 8) return false;
     return true;       // strides / alignment: flash_bf16_supported (checked by the caller first)
 }
@@ -569,8 +598,6 @@ static void f2_transpose(const Launch& L, const void* X, long ld, long sb, long 
                        ones_row);
 }
 
-
-
 // rows per block = 64 QB: take the widest row block that still gives every CU two blocks (experiments: CB_F2_QB="fwd,dq,dkv" caps them)
 static int f2_pick_qb(int rows, int BH, int qbmax, int which) {
     static int envcap[3] = {0, 0, 0};
@@ -581,45 +608,58 @@ static int f2_pick_qb(int rows, int BH, int qbmax, int which) {
     while (qb > 1 && (long)cdiv(rows, 64 * qb) * BH < 512) qb >>= 1;
     return qb;
 }
-// Instantiations: QB = 4 exists for three output tiles (d <= 48) and whole tiles only — four row blocks x four output tiles, or a second
-// (masked) copy of the tile body, would spill, and celebbasis_amd/build.py fails the build on any scratch in this file.
-template <int DT, bool ONES>
+// Instantiations: (KS, DT) = (2, 3) d <= 48, (2, 4) d <= 64, (3, 5) d <= 80. QB = 4 exists for (2, 3) and whole tiles only — four row
+// blocks x four / five output tiles, or a second (masked) copy of the tile body, would spill, and celebbasis_amd/build.py fails the build
+// on any scratch in this file.
+template <int KS, int DT, int QB, bool ONES, bool RG>
+static void f2_go_fwd(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* VT, int Np) {
+    hipLaunchKernelGGL((f2_fwd_kernel<KS, DT, QB, ONES, RG>), grid, dim3(256), 0, st, a, VT, Np);
+}
+template <int KS, int DT, bool ONES>
 static void f2_launch_fwd(int qb, bool rg, dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* VT, int Np) {
-    if (rg) {
-        if (qb == 2) hipLaunchKernelGGL((f2_fwd_kernel<DT, 2, ONES, true>), grid, dim3(256), 0, st, a, VT, Np);
-        else hipLaunchKernelGGL((f2_fwd_kernel<DT, 1, ONES, true>), grid, dim3(256), 0, st, a, VT, Np);
-        return;
-    }
-    if constexpr (DT == 3) { if (qb == 4) { hipLaunchKernelGGL((f2_fwd_kernel<3, 4, ONES, false>), grid, dim3(256), 0, st, a, VT, Np); return; } }
-    if (qb == 2) hipLaunchKernelGGL((f2_fwd_kernel<DT, 2, ONES, false>), grid, dim3(256), 0, st, a, VT, Np);
-    else hipLaunchKernelGGL((f2_fwd_kernel<DT, 1, ONES, false>), grid, dim3(256), 0, st, a, VT, Np);
+    if (rg) { if (qb == 2) f2_go_fwd<KS, DT, 2, ONES, true>(grid, st, a, VT, Np); else f2_go_fwd<KS, DT, 1, ONES, true>(grid, st, a, VT, Np); return; }
+    if constexpr (KS == 2 && DT == 3) { if (qb == 4) { f2_go_fwd<2, 3, 4, ONES, false>(grid, st, a, VT, Np); return; } }
+    if (qb == 2) f2_go_fwd<KS, DT, 2, ONES, false>(grid, st, a, VT, Np); else f2_go_fwd<KS, DT, 1, ONES, false>(grid, st, a, VT, Np);
 }
-template <int DT>
-static void f2_launch_dq(int qb, bool rg, dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* KT, int Np) {
-    if (rg) {
-        if (qb == 2) hipLaunchKernelGGL((f2_dq_kernel<DT, 2, true>), grid, dim3(256), 0, st, a, KT, Np);
-        else hipLaunchKernelGGL((f2_dq_kernel<DT, 1, true>), grid, dim3(256), 0, st, a, KT, Np);
-        return;
-    }
-    if constexpr (DT == 3) { if (qb == 4) { hipLaunchKernelGGL((f2_dq_kernel<3, 4, false>), grid, dim3(256), 0, st, a, KT, Np); return; } }
-    if (qb == 2) hipLaunchKernelGGL((f2_dq_kernel<DT, 2, false>), grid, dim3(256), 0, st, a, KT, Np);
-    else hipLaunchKernelGGL((f2_dq_kernel<DT, 1, false>), grid, dim3(256), 0, st, a, KT, Np);
-}
-template <int DT, int QB, bool RG>
-static void f2_launch_dkv1(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* QT, const bf16_t* DTp, int Np) {
+template <int KS, int DT, int QB, bool RG>
+static void f2_go_dq(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* KT, int Np) {
+    constexpr int LDS = 2 * f2_dq_stage<KS, DT>();
     static const bool once = [] {
-        CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&f2_dkv_kernel<DT, QB, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * F2_DKV_STAGE));
+        CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&f2_dq_kernel<KS, DT, QB, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         return true;
     }();
     (void)once;
-    hipLaunchKernelGGL((f2_dkv_kernel<DT, QB, RG>), grid, dim3(256), 2 * F2_DKV_STAGE, st, a, QT, DTp, Np);
+    hipLaunchKernelGGL((f2_dq_kernel<KS, DT, QB, RG>), grid, dim3(256), LDS, st, a, KT, Np);
 }
-template <int DT>
+template <int KS, int DT>
+static void f2_launch_dq(int qb, bool rg, dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* KT, int Np) {
+    if (rg) { if (qb == 2) f2_go_dq<KS, DT, 2, true>(grid, st, a, KT, Np); else f2_go_dq<KS, DT, 1, true>(grid, st, a, KT, Np); return; }
+    if constexpr (KS == 2 && DT == 3) { if (qb == 4) { f2_go_dq<2, 3, 4, false>(grid, st, a, KT, Np); return; } }
+    if (qb == 2) f2_go_dq<KS, DT, 2, false>(grid, st, a, KT, Np); else f2_go_dq<KS, DT, 1, false>(grid, st, a, KT, Np);
+}
+template <int KS, int DT, int QB, bool RG>
+static void f2_go_dkv(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* QT, const bf16_t* DTp, int Np) {
+    constexpr int LDS = 2 * f2_dkv_stage<KS, DT>();
+    static const bool once = [] {
+        CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&f2_dkv_kernel<KS, DT, QB, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        return true;
+    }();
+    (void)once;
+    hipLaunchKernelGGL((f2_dkv_kernel<KS, DT, QB, RG>), grid, dim3(256), LDS, st, a, QT, DTp, Np);
+}
+template <int KS, int DT>
 static void f2_launch_dkv(int qb, bool rg, dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* QT, const bf16_t* DTp, int Np) {
     if (rg) {
-        if constexpr (DT == 3) { if (qb == 2) { f2_launch_dkv1<3, 2, true>(grid, st, a, QT, DTp, Np); return; } }
-        f2_launch_dkv1<DT, 1, true>(grid, st, a, QT, DTp, Np);       // (four output tiles x two key blocks x two tile bodies would spill)
-    } else { if (qb == 2) f2_launch_dkv1<DT, 2, false>(grid, st, a, QT, DTp, Np); else f2_launch_dkv1<DT, 1, false>(grid, st, a, QT, DTp, Np); }
+        if constexpr (DT == 3) { if (qb == 2) { f2_go_dkv<KS, 3, 2, true>(grid, st, a, QT, DTp, Np); return; } }
+        f2_go_dkv<KS, DT, 1, true>(grid, st, a, QT, DTp, Np);
+    } else {
+        if constexpr (DT <= 4) { if (qb == 2) { f2_go_dkv<KS, DT, 2, false>(grid, st, a, QT, DTp, Np); return; } }
+        f2_go_dkv<KS, DT, 1, false>(grid, st, a, QT, DTp, Np);
+    }
+}
+static int f2_qbmax(int dt, bool rg, int which) {      // which: 0 forward, 1 dQ, 2 dK/dV — must mirror the instantiations above
+    if (which == 2) return (dt == 3 || (dt == 4 && !rg)) ? 2 : 1;
+    return (dt == 3 && !rg) ? 4 : 2;
 }
 
 void flash_bf16_v2_forward(const Launch& L, const FlashArgs& a, int B, void* tws) {
@@ -629,10 +669,11 @@ void flash_bf16_v2_forward(const Launch& L, const FlashArgs& a, int B, void* tws
     const bool ones = (a.d & 15) != 0;       // a spare row in the last 16-row block of the V^T image: the softmax denominator rides on the P.V MFMA
     const bool rg = (a.Nk % F2_TK) != 0;
     f2_transpose(L, a.v, a.ldk, a.skb, a.skh, a.H, a.Nk, a.d, BH, VT, ones ? 1 : 0);
-    const int qb = f2_pick_qb(a.Nq, BH, (dt == 3 && !rg) ? 4 : 2, 0);
+    const int qb = f2_pick_qb(a.Nq, BH, f2_qbmax(dt, rg, 0), 0);
     dim3 grid(cdiv(a.Nq, 64 * qb), BH);
-    if (dt == 3) { if (ones) f2_launch_fwd<3, true>(qb, rg, grid, L.stream, a, VT, Np); else f2_launch_fwd<3, false>(qb, rg, grid, L.stream, a, VT, Np); }
-    else { if (ones) f2_launch_fwd<4, true>(qb, rg, grid, L.stream, a, VT, Np); else f2_launch_fwd<4, false>(qb, rg, grid, L.stream, a, VT, Np); }
+    if (dt == 3) { if (ones) f2_launch_fwd<2, 3, true>(qb, rg, grid, L.stream, a, VT, Np); else f2_launch_fwd<2, 3, false>(qb, rg, grid, L.stream, a, VT, Np); }
+    else if (dt == 4) { if (ones) f2_launch_fwd<2, 4, true>(qb, rg, grid, L.stream, a, VT, Np); else f2_launch_fwd<2, 4, false>(qb, rg, grid, L.stream, a, VT, Np); }
+    else { if (ones) f2_launch_fwd<3, 5, true>(qb, rg, grid, L.stream, a, VT, Np); else f2_launch_fwd<3, 5, false>(qb, rg, grid, L.stream, a, VT, Np); }
 }
 
 void flash_bf16_v2_backward(const Launch& L, const FlashArgs& a, int B, bool need_dq, bool need_dkv, void* tws) {
@@ -645,18 +686,23 @@ void flash_bf16_v2_backward(const Launch& L, const FlashArgs& a, int B, bool nee
     f2_transpose(L, a.k, a.ldk, a.skb, a.skh, a.H, a.Nk, a.d, BH, KT);
     {
         const bool rg = (a.Nk % F2_TK) != 0;
-        const int qb = f2_pick_qb(a.Nq, BH, (dt == 3 && !rg) ? 4 : 2, 1);
+        const int qb = f2_pick_qb(a.Nq, BH, f2_qbmax(dt, rg, 1), 1);
         dim3 grid(cdiv(a.Nq, 64 * qb), BH);
-        if (dt == 3) f2_launch_dq<3>(qb, rg, grid, L.stream, a, KT, Npk); else f2_launch_dq<4>(qb, rg, grid, L.stream, a, KT, Npk);
+        if (dt == 3) f2_launch_dq<2, 3>(qb, rg, grid, L.stream, a, KT, Npk);
+        else if (dt == 4) f2_launch_dq<2, 4>(qb, rg, grid, L.stream, a, KT, Npk);
+        else f2_launch_dq<3, 5>(qb, rg, grid, L.stream, a, KT, Npk);
     }
     if (need_dkv) {
         f2_transpose(L, a.q, a.ldq, a.sqb, a.sqh, a.H, a.Nq, a.d, BH, QT);
         f2_transpose(L, a.dout, a.ldo, a.sob, a.soh, a.H, a.Nq, a.d, BH, DT);
-        int qb = f2_pick_qb(a.Nk, BH, 2, 2);
+        // ragged = a partial query tile or a partial key block somewhere in the launch; the widest key block depends on it and vice versa
+        int qb = f2_pick_qb(a.Nk, BH, f2_qbmax(dt, false, 2), 2);
         bool rg = (a.Nq % F2_TK) != 0 || (a.Nk % (64 * qb)) != 0;
-        if (rg && dt == 4 && qb == 2) { qb = 1; rg = (a.Nq % F2_TK) != 0 || (a.Nk % F2_TK) != 0; }
+        if (rg && qb > f2_qbmax(dt, true, 2)) { qb = f2_qbmax(dt, true, 2); rg = (a.Nq % F2_TK) != 0 || (a.Nk % (64 * qb)) != 0; }
         dim3 grid(cdiv(a.Nk, 64 * qb), BH);
-        if (dt == 3) f2_launch_dkv<3>(qb, rg, grid, L.stream, a, QT, DT, Npq); else f2_launch_dkv<4>(qb, rg, grid, L.stream, a, QT, DT, Npq);
+        if (dt == 3) f2_launch_dkv<2, 3>(qb, rg, grid, L.stream, a, QT, DT, Npq);
+        else if (dt == 4) f2_launch_dkv<2, 4>(qb, rg, grid, L.stream, a, QT, DT, Npq);
+        else f2_launch_dkv<3, 5>(qb, rg, grid, L.stream, a, QT, DT, Npq);
     }
 }
 

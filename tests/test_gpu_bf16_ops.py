@@ -299,12 +299,15 @@ def test_geglu_bf16(cbf):
     (1, 200, 136, 256, 2, 0, 0),     # d=128 (KS=4), ragged both ways
     (2, 100, 100, 64, 4, 1, 1),      # d=16 causal (mini configs)
     (4, 1024, 1024, 640, 8, 0, 1),   # UNet level-1 self-attention at bs=4
-    # second-generation kernels (cb_flash_bf16_v2.hip: LDS-DMA ring, 16*QB rows per wave, pre-transposed second operands), 32 < d <= 64:
+    # second-generation kernels (cb_flash_bf16_v2.hip: LDS-DMA ring, 16*QB rows per wave, pre-transposed second operands), 32 < d <= 80
+    # (the (4, 1024, 1024, 640, 8) case above is the UNet's 32x32 level on them too):
     (1, 4096, 4096, 320, 8, 0, 1),   # the shape that carries the attention FLOPs: 64x64 level, d = 40 (QB = 1 at 8 heads)
     (4, 1024, 1024, 320, 8, 0, 1),   # d = 40, 32 heads: QB = 2 forward / dQ
     (8, 2048, 2048, 320, 8, 0, 1),   # d = 40, 64 heads: QB = 4 forward / dQ, QB = 2 dK/dV
     (1, 1000, 520, 512, 8, 0, 0),    # d = 64 (four output tiles), ragged query / key counts, separate q and kv buffers
     (2, 264, 1288, 384, 8, 0, 0),    # d = 48, key tail of 8
+    (1, 520, 1000, 576, 8, 0, 0),    # d = 72: three 32-wide k groups (192-byte tile rows), ones row, ragged both ways
+    (2, 1032, 264, 640, 8, 0, 0),    # d = 80 (five output tiles, no spare row), ragged query tile, separate q / kv buffers
 ])
 def test_attention_bf16(cbf, B, Nq, Nk, Cc, heads, causal, fused):
     lib, ctx = cbf
