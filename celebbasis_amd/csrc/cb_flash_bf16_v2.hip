@@ -133,7 +133,7 @@ template <int KS> __device__ __forceinline__ void f2_lane_offsets(int (&lor)[KS]
 // produces the softmax denominator sum_k P in its accumulator row d, for free (f2_fwd_kernel<.., ONES = true>).
 __global__ __launch_bounds__(256) void f2_transpose_kernel(const bf16_t* __restrict__ X, long ld, long sb, long sh, int H, int N, int d,
                                                            int DR, int Np, bf16_t* __restrict__ XT, int ones_row) {
-    __shared__ __attribute__((aligned(16))) unsigned short tile[64][66];
+    __shared__ __attribute__((aligned(16))) unsigned short tile[64][98];      // 64 rows x DR <= 96 head-dim values (+2: the row pitch stays a multiple of 4 bytes and off the banks' period)
     const int bh = blockIdx.y, b = bh / H, h = bh - b * H, n0 = blockIdx.x * 64;
     const bf16_t* src = X + b * sb + h * sh;
     const int cpr = DR >> 3;
