@@ -1,6 +1,6 @@
-// cb_flash_bf16_v2.hip — second-generation fused attention for the bf16 step (BASELINE config 3), head dims 40 .. 64, the shape
+// cb_flash_bf16_v2.hip — second-generation fused attention for the bf16 step (BASELINE config 3), head dims 40 .. 80: the shape
 // that carries 85 % of the UNet's attention FLOPs (the five 64x64-level self-attention layers: N = 4096, d = 40, 8 heads;
-// ldm/modules/attention.py:170-193). Same arithmetic as cb_flash_bf16.hip (S^T = K Q^T in 16x16x32 bf16 MFMA tiles, log2-domain
+// ldm/modules/attention.py:170-193) and the 32x32 level (N = 1024, d = 80). Same arithmetic as cb_flash_bf16.hip (S^T = K Q^T in 16x16x32 bf16 MFMA tiles, log2-domain
 // online softmax in fp32, P consumed from the accumulators as the next MFMA's B operand), re-built around what bounded it:
 //
 //   * LDS traffic, not MFMA, set the pace: a block of 4 waves x 16 rows re-staged every 64-row K / V tile through VGPRs
@@ -9,13 +9,16 @@
 //     registers) and every LDS fragment it reads feeds QB MFMAs.
 //   * No register staging: every streamed tile is fetched by `buffer_load_dwordx4 ... lds` (LDS-DMA) into a two-stage ring —
 //     one counted wait + ONE barrier per tile, no ds_write, no v_perm, no staging VGPRs. The DMA image is lane-linear, so the
-//     bank swizzle (chunk ^ (row >> 1) & 7 on 128-byte rows, the scheme of cb_gemm_glds.hip) is applied to the SOURCE address.
+//     bank swizzle (f2_swz: chunk ^ (row >> 1) & 7 on 128-byte rows, the scheme of cb_gemm_glds.hip; a 2-bit permutation on the
+//     192-byte rows of d <= 96) is applied to the SOURCE address.
 //   * LDS-DMA cannot transpose, and the second MFMA of each phase (P.V, dS.K, dS^T.Q, P^T.dO) wants its streamed operand
 //     transposed ([head dim][row], with the rows of a 32-row group permuted to the k-slot order in which the probabilities lie
 //     in the accumulators). Those operands are therefore transposed ONCE per layer by a small prepass kernel into a
 //     [B*H][16*DT][N] scratch image (10 MB at N = 4096: ~5 us) and streamed from there like any other tile.
-// Not taken by v2 (falls back to cb_flash_bf16.hip): causal masks, head dims outside (32, 64], fewer than 256 rows on either
-// side (cross-attention, the small levels), the query-split dK/dV path.
+// Not taken by v2 (falls back to cb_flash_bf16.hip): causal masks, head dims outside (32, 80], fewer than 256 rows on either
+// side (cross-attention, the small levels), the query-split dK/dV path. Measured (tools/bench_flash.py, bs = 4, forward / backward):
+// d = 40, N = 4096: 165.6 / 433.6 us against 290.7 / 874.9 us for the round-2 kernels; d = 80, N = 1024: 33.6 / 107.4 us against
+// 43.0 / 113.5 us (one block per CU there: 8 row blocks x 32 heads, and 98 KB of LDS per dK/dV block).
 #include "cb_device.h"
 #include <type_traits>
 
