@@ -717,6 +717,10 @@ def main():
     with open(os.path.join(OUT, "state_dict_digests.json"), "w") as f:
         json.dump(digests, f, indent=1, sort_keys=True)
     manifest["state_dict_digests.json"] = "sha256 over sorted 'key:shape' lines of the reference modules' float state_dict at SD v1-4 sizes"
+    # fixtures written by oracle/gen_horizon.py (minutes of CPU each, not regenerated here): ORACLE trajectories, not reference outputs
+    manifest["horizon_sd14_b1.pt"] = ("oracle/gen_horizon.py fp32: 100 optimiser steps of oracle.cb_oracle.train_step (the restatement step_mini.pt pins) "
+                                      "at SD v1-4 size, bs=1, replay stream oracle/replay.py — losses, step coefficients, EMA dictionary rows, sampled MLP gradient rows")
+    manifest["horizon_sd14_b4.pt"] = "oracle/gen_horizon.py bf16: the same for 20 steps at bs=4, lr 2e-2 (fp32 oracle; checks the bf16 step)"
     with open(os.path.join(OUT, "MANIFEST.json"), "w") as f:
         json.dump(manifest, f, indent=1, sort_keys=True)
     for k in sorted(os.listdir(OUT)):
