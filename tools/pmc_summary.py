@@ -15,7 +15,7 @@ for d in sys.argv[1:]:
     for p in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(p)):
             n = clean(r["Kernel_Name"])
-            if "gemm" not in n and "flash" not in n:
+            if "gemm" not in n and "flash" not in n and not n.startswith("f2_"):
                 continue
             key = (n, int(r["Grid_Size"]))
             a = acc[key][r["Counter_Name"]]
