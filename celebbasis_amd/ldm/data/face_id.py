@@ -4,8 +4,9 @@ num_ids}, caption, id_idx, img_idx — with the same 81-template caption list an
 Augmentations (flip, colour jitter, `_add_bg` rescale-paste): the random draws are made on the host like the reference's
 transforms; the pixel work runs either per sample on the CPU (`__getitem__`, DataLoader workers, as in the reference) or for a
 whole batch on the device (`DeviceAugmenter`: cb_face_augment + cb_paste_on_canvas), which is what keeps the feeder ahead of a
-21 steps/s training loop. Bit-exact torchvision/PIL parity is not a goal: parity of the training step is defined
-on a replay stream. Without a dataset on disk the feeder synthesises seeded faces so the rest of the pipeline can run offline."""
+21 steps/s training loop. ColorJitter's four ops run in a per-call random order, as torchvision's do. The formulas are PIL's
+(the backend the reference's PIL inputs select) in float, i.e. without PIL's uint8 rounding after every op; bit-exact parity with
+that rounding is not a goal: parity of the training step is defined on a replay stream. Without a dataset on disk the feeder synthesises seeded faces so the rest of the pipeline can run offline."""
 import pickle
 import random
 
@@ -132,24 +133,28 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
 
     def _aug(self, img):
         """flip + colour jitter on the CPU worker (face_id.py:526-532), same parameter draws and formulas as the device path"""
-        flip, b, c, sat, hue = self._jitter_params()
+        (flip, b, c, sat, hue), order = self._jitter_params()
         x = (img.flip(1) if flip else img + 0) * 0.5 + 0.5
         gray = lambda t: 0.2989 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]
-        x = (x * b).clamp(0, 1)
-        x = (c * x + (1 - c) * gray(x).mean()).clamp(0, 1)
-        x = (sat * x + (1 - sat) * gray(x).unsqueeze(-1)).clamp(0, 1)
-        if hue != 0.0:
-            mx, mn = x.max(-1).values, x.min(-1).values
-            d = mx - mn
-            s_ = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
-            dd = torch.where(d > 0, d, torch.ones_like(d))
-            r, g, bl = x[..., 0], x[..., 1], x[..., 2]
-            h = torch.where(mx == r, (g - bl) / dd, torch.where(mx == g, 2 + (bl - r) / dd, 4 + (r - g) / dd))
-            h = (torch.where(d > 0, (h / 6) % 1.0, torch.zeros_like(h)) + hue) % 1.0
-            fi = torch.floor(h * 6); f = h * 6 - fi; i = fi.long() % 6
-            p_, q, t = (mx * (1 - s_)).clamp(0, 1), (mx * (1 - f * s_)).clamp(0, 1), (mx * (1 - (1 - f) * s_)).clamp(0, 1)
-            pick = lambda *a: torch.stack(a, -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
-            x = torch.stack([pick(mx, q, p_, p_, t, mx), pick(t, mx, mx, q, p_, p_), pick(p_, p_, t, mx, mx, q)], -1)
+        for op in order:                                        # ColorJitter.forward: fn_idx = randperm(4)
+            if op == 0:
+                x = (x * b).clamp(0, 1)
+            elif op == 1:
+                x = (c * x + (1 - c) * gray(x).mean()).clamp(0, 1)
+            elif op == 2:
+                x = (sat * x + (1 - sat) * gray(x).unsqueeze(-1)).clamp(0, 1)
+            elif hue != 0.0:
+                mx, mn = x.max(-1).values, x.min(-1).values
+                d = mx - mn
+                s_ = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
+                dd = torch.where(d > 0, d, torch.ones_like(d))
+                r, g, bl = x[..., 0], x[..., 1], x[..., 2]
+                h = torch.where(mx == r, (g - bl) / dd, torch.where(mx == g, 2 + (bl - r) / dd, 4 + (r - g) / dd))
+                h = (torch.where(d > 0, (h / 6) % 1.0, torch.zeros_like(h)) + hue) % 1.0
+                fi = torch.floor(h * 6); f = h * 6 - fi; i = fi.long() % 6
+                p_, q, t = (mx * (1 - s_)).clamp(0, 1), (mx * (1 - f * s_)).clamp(0, 1), (mx * (1 - (1 - f) * s_)).clamp(0, 1)
+                pick = lambda *a: torch.stack(a, -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
+                x = torch.stack([pick(mx, q, p_, p_, t, mx), pick(t, mx, mx, q, p_, p_), pick(p_, p_, t, mx, mx, q)], -1)
         return x * 2 - 1
 
     def _bg_geometry(self):
@@ -170,9 +175,13 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         return canvas
 
     def _jitter_params(self):
-        """flip, brightness, contrast, saturation, hue of ColorJitter((0.8,1.2),(0.8,1.2),(0.8,1.2),0.01) + RandomHorizontalFlip"""
+        """([flip, brightness, contrast, saturation, hue], order) of RandomHorizontalFlip + ColorJitter((0.8,1.2),(0.8,1.2),(0.8,1.2),0.01):
+        the flip coin, then ColorJitter.get_params' draws in its order — the permutation of the four ops (fn_idx) first, then
+        the four factors"""
         r = self.rng
-        return [1.0 if r.random() < self.flip_p else 0.0, r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(-0.01, 0.01)]
+        flip = 1.0 if r.random() < self.flip_p else 0.0
+        order = r.sample(range(4), 4)
+        return [flip, r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(-0.01, 0.01)], order
 
     def __getitem__(self, i):
         self._worker_rng()
@@ -195,8 +204,12 @@ class FaceIdDatasetOneShot(FaceIdDatasetStyleGAN3):
 class DeviceAugmenter:
     """Batch-level counterpart of `__getitem__` with the pixel work on the GPU: the base faces stay resident in HBM, the host
     draws the per-sample parameters — from the dataset's generator, in `__getitem__`'s order (augmentation 1, augmentation 2,
-    `_add_bg` geometry, caption), so the same generator state yields the same batch on either path — and two native launches per
-    augmentation produce `image` (B,S,S,3), `image_ori.faces` (B,S,S,6) and the ids/captions of face_id.py:598-644."""
+    `_add_bg` geometry, caption), so the same generator state yields the same batch on either path — and native launches
+    produce `image` (B,S,S,3), `image_ori.faces` (B,S,S,6) and the ids/captions of face_id.py:598-644. ColorJitter's per-sample op
+    order: cb_face_augment applies brightness -> contrast -> saturation -> hue, and every op is the identity at its neutral
+    factor (1, 1, 1, 0), so pass k of four runs the k-th op of EACH sample's own permutation with the other three neutral."""
+
+    SLOTS = 4                                                   # pinned staging buffers in flight (one H2D copy per batch)
 
     def __init__(self, dataset, device="cuda"):
         from ... import lib as _lib
@@ -205,6 +218,8 @@ class DeviceAugmenter:
         self.ctx = context_for(self.dev)
         self.idents = list(dataset.ids)
         self.base = torch.stack([dataset.faces[i] for i in self.idents]).to(self.dev).float().contiguous()     # (n_ids,S,S,3)
+        self.idents_dev = torch.tensor(self.idents, dtype=torch.int64, device=self.dev)
+        self._stage, self._turn = [None] * self.SLOTS, 0
 
     def draws(self, indices):
         """host half of a batch: per sample the draws of `__getitem__`, in its order"""
@@ -217,22 +232,57 @@ class DeviceAugmenter:
             caps.append(ds.rng.choice(imagenet_templates_small).format(f"face of {ds.placeholder} person"))
         return p1, p3, geom, caps
 
+    @staticmethod
+    def passes(params, order):
+        """[flip, b, c, s, h] + op order -> the 4 x 5 parameters of the four single-op passes (the flip rides on the first)"""
+        rows = []
+        for k, op in enumerate(order):
+            row = [params[0] if k == 0 else 0.0, 1.0, 1.0, 1.0, 0.0]
+            row[1 + op] = params[1 + op]
+            rows += row
+        return rows
+
+    def _to_device(self, values):
+        """ONE asynchronous H2D copy per batch, from a pinned staging buffer: a pageable source would make the copy wait for the
+        stream to drain, i.e. put the host's feeder work in series with every training step. A slot is reused SLOTS batches later,
+        after its copy event"""
+        n = len(values)
+        slot = self._turn % self.SLOTS
+        self._turn += 1
+        entry = self._stage[slot]
+        if entry is None or entry[0].numel() < n:
+            entry = [torch.empty(max(n, 256), dtype=torch.float32).pin_memory(), None]
+            self._stage[slot] = entry
+        if entry[1] is not None:
+            entry[1].synchronize()
+        entry[0][:n] = torch.tensor(values, dtype=torch.float32)
+        devp = entry[0][:n].to(self.dev, non_blocking=True)
+        entry[1] = torch.cuda.Event()
+        entry[1].record(torch.cuda.current_stream(self.dev))
+        return devp
+
     def batch(self, indices):
         L = self._lib
         B = len(indices)
         which = [i % len(self.idents) for i in indices]
         p1, p3, geom, caps = self.draws(indices)
-        # ONE H2D copy carries every per-sample scalar of the batch: 5 + 5 jitter parameters, 4 paste integers, the face index
-        host = torch.tensor([a + b + [float(v) for v in (g or (0, 0, 0, 0))] + [float(w)]
-                             for a, b, g, w in zip(p1, p3, geom or [None] * B, which)], dtype=torch.float32)
-        devp = host.to(self.dev, non_blocking=True)
-        src = self.base[devp[:, 14].to(torch.int64)].contiguous()
-        img = L.face_augment(self.ctx, src, devp[:, 0:5].contiguous())
-        img3 = L.face_augment(self.ctx, src, devp[:, 5:10].contiguous())
-        image = L.paste_on_canvas(self.ctx, img, devp[:, 10:14].to(torch.int32).contiguous()) if geom else img
-        ids = torch.tensor([[self.idents[w]] * 2 for w in which], dtype=torch.int64)
-        return dict(image=image, caption=caps, id_idx=ids[:, 0].clone(), img_idx=torch.tensor(list(indices)),
-                    image_ori=dict(faces=torch.cat([img, img3], dim=-1).contiguous(), ids=ids.to(self.dev, non_blocking=True),
+        # staging layout: pass k of four, the batch's first augmentations then its second ones [4][2B][5] | paste integers [B][4] | face index [2B]
+        rows1, rows3 = [self.passes(*a) for a in p1], [self.passes(*b) for b in p3]
+        flat = [v for k in range(4) for rows in (rows1, rows3) for r in rows for v in r[5 * k:5 * k + 5]]
+        flat += [float(v) for g in geom for v in g] + [float(w) for w in which] * 2
+        devp = self._to_device(flat)
+        o_geom = 40 * B
+        o_which = o_geom + 4 * len(geom)
+        idx = devp[o_which:o_which + 2 * B].to(torch.int64)
+        both = self.base[idx]                                   # (2B,S,S,3): rows 0..B-1 become `img`, rows B..2B-1 `img3`
+        for k in range(4):
+            both = L.face_augment(self.ctx, both, devp[10 * B * k:10 * B * (k + 1)].view(2 * B, 5))
+        img, img3 = both[:B], both[B:]
+        image = L.paste_on_canvas(self.ctx, img, devp[o_geom:o_which].view(B, 4).to(torch.int32)) if geom else img
+        ident = self.idents_dev[idx[:B]]
+        return dict(image=image, caption=caps, id_idx=torch.tensor([self.idents[w] for w in which], dtype=torch.int64),
+                    img_idx=torch.tensor(list(indices)),
+                    image_ori=dict(faces=torch.cat([img, img3], dim=-1), ids=torch.stack([ident, ident], dim=1),
                                    num_ids=torch.ones(B, dtype=torch.int64)))
 
 
@@ -254,10 +304,10 @@ class DeviceFeeder:
     def _tokens(self, caps):
         rows = []
         for c in caps:
-            if c not in self._tok:
-                self._tok[c] = self.tokenize([c])[0].to(torch.int64).cpu()
+            if c not in self._tok:                              # cached ON the device: a steady-state batch needs no H2D copy for its tokens
+                self._tok[c] = self.tokenize([c])[0].to(torch.int64).to(self.aug.dev)
             rows.append(self._tok[c])
-        return torch.stack(rows).to(self.aug.dev, non_blocking=True)
+        return torch.stack(rows)
 
     def __iter__(self):
         n = len(self.ds)

@@ -14,6 +14,9 @@ The CLIP text layers live in the third-party dependency transformers==4.18.0 (en
 vendored and whose installed version (5.x) is API-incompatible with the reference's monkey-patch; they are
 restated from the published 4.18 `modeling_clip` algorithm and cross-checked against the installed
 `transformers.CLIPTextModel` arithmetic (same weights) in gen_golden.py.
+The feeder's colour jitter lives in torchvision==0.11.3 (environment.yaml:57, absent here) on top of PIL (installed): the
+restatement is pinned against PIL's ImageEnhance / HSV results to uint8 quantisation (tests/test_host_cpu.py::
+test_oracle_jitter_vs_pil); no reference-produced fixture exists for it.
 
 Weights are plain {state-dict key: tensor} dicts using the reference's key names.
 """
@@ -566,32 +569,46 @@ def face_warp_resize(faces_hwc, out_size=112):
 
 
 # ----------------------------------------------------------------------------- CelebBasis head + manager hook
-def color_jitter_flip(img_hwc, flip, brightness, contrast, saturation, hue):
-    """face_id.py:526-532 `trans` after the resize on one HWC image in [-1,1]: RandomHorizontalFlip + ColorJitter + Normalize with
-    torchvision's tensor formulas (functional_tensor.adjust_brightness/contrast/saturation/hue) in the order b, c, s, h"""
+def color_jitter_flip(img_hwc, flip, brightness, contrast, saturation, hue, order=(0, 1, 2, 3)):
+    """face_id.py:526-532 `trans` after the resize on one HWC image in [-1,1]: RandomHorizontalFlip + ColorJitter + Normalize.
+    `order` is ColorJitter's `fn_idx` (torchvision 0.11.3 transforms.ColorJitter.forward applies 0 = brightness, 1 = contrast,
+    2 = saturation, 3 = hue in a random permutation drawn per call). The reference hands the transform a PIL image, so the
+    arithmetic it executes is PIL's (ImageEnhance.Brightness / Contrast / Color = blend against black / the mean-gray image /
+    the gray image; hue = a shift of the H plane of the 8-bit HSV image), quantised to uint8 after every op. This restatement
+    keeps the same formulas in float (torchvision's functional_tensor forms) without the intermediate quantisation:
+    tests/test_host_cpu.py::test_oracle_jitter_vs_pil pins it against PIL to that quantisation."""
     x = (img_hwc + 1.0) * 0.5
     if flip:
         x = x.flip(1)
     gray = lambda t: 0.2989 * t[..., 0] + 0.587 * t[..., 1] + 0.114 * t[..., 2]
-    x = (x * brightness).clamp(0, 1)
-    x = (contrast * x + (1.0 - contrast) * gray(x).mean()).clamp(0, 1)
-    x = (saturation * x + (1.0 - saturation) * gray(x).unsqueeze(-1)).clamp(0, 1)
-    if hue != 0.0:
-        r, g, b = x[..., 0], x[..., 1], x[..., 2]
-        mx, mn = x.max(dim=-1).values, x.min(dim=-1).values
-        d = mx - mn
-        sat = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
-        dd = torch.where(d > 0, d, torch.ones_like(d))
-        h = torch.where(mx == r, (g - b) / dd, torch.where(mx == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd))
-        h = torch.where(d > 0, (h / 6.0) % 1.0, torch.zeros_like(h))
-        h = (h + hue) % 1.0
-        h6 = h * 6.0
-        fi = torch.floor(h6); f = h6 - fi; i = fi.to(torch.int64) % 6
-        v = mx
-        p_ = (v * (1.0 - sat)).clamp(0, 1); q = (v * (1.0 - f * sat)).clamp(0, 1); t = (v * (1.0 - (1.0 - f) * sat)).clamp(0, 1)
-        sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5], -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
-        x = torch.stack([sel(v, q, p_, p_, t, v), sel(t, v, v, q, p_, p_), sel(p_, p_, t, v, v, q)], dim=-1)
+    for op in order:
+        if op == 0:
+            x = (x * brightness).clamp(0, 1)
+        elif op == 1:
+            x = (contrast * x + (1.0 - contrast) * gray(x).mean()).clamp(0, 1)
+        elif op == 2:
+            x = (saturation * x + (1.0 - saturation) * gray(x).unsqueeze(-1)).clamp(0, 1)
+        elif hue != 0.0:
+            x = _hue_shift(x, hue)
     return x * 2.0 - 1.0
+
+
+def _hue_shift(x, hue):
+    """rgb -> hsv, h += hue (mod 1), hsv -> rgb on an HWC image in [0,1]"""
+    r, g, b = x[..., 0], x[..., 1], x[..., 2]
+    mx, mn = x.max(dim=-1).values, x.min(dim=-1).values
+    d = mx - mn
+    sat = torch.where(mx > 0, d / mx.clamp_min(1e-30), torch.zeros_like(mx))
+    dd = torch.where(d > 0, d, torch.ones_like(d))
+    h = torch.where(mx == r, (g - b) / dd, torch.where(mx == g, 2.0 + (b - r) / dd, 4.0 + (r - g) / dd))
+    h = torch.where(d > 0, (h / 6.0) % 1.0, torch.zeros_like(h))
+    h = (h + hue) % 1.0
+    h6 = h * 6.0
+    fi = torch.floor(h6); f = h6 - fi; i = fi.to(torch.int64) % 6
+    v = mx
+    p_ = (v * (1.0 - sat)).clamp(0, 1); q = (v * (1.0 - f * sat)).clamp(0, 1); t = (v * (1.0 - (1.0 - f) * sat)).clamp(0, 1)
+    sel = lambda a0, a1, a2, a3, a4, a5: torch.stack([a0, a1, a2, a3, a4, a5], -1).gather(-1, i.unsqueeze(-1)).squeeze(-1)
+    return torch.stack([sel(v, q, p_, p_, t, v), sel(t, v, v, q, p_, p_), sel(p_, p_, t, v, v, q)], dim=-1)
 
 
 def add_bg(img_hwc, rh, rw, pos_h, pos_w):

@@ -396,6 +396,17 @@ def test_feeder_augmentations_vs_oracle(cb):
     ref = torch.stack([O.color_jitter_flip(faces[b], bool(params[b, 0]), *[float(v) for v in params[b, 1:]]) for b in range(B)])
     close("feeder.jitter", out, ref, 2e-5)
     assert torch.equal(out[2].cpu(), faces[2].flip(1)) or (out[2].cpu() - faces[2].flip(1)).abs().max() < 1e-6   # identity jitter = flip only
+    # ColorJitter's per-call op order (fn_idx): the feeder runs four single-op passes, pass k = the k-th op of each sample's own permutation
+    from celebbasis_amd.ldm.data.face_id import DeviceAugmenter
+    orders = [[3, 1, 0, 2], [1, 2, 3, 0], [0, 1, 2, 3]]
+    rows = torch.tensor([DeviceAugmenter.passes([float(v) for v in params[b]], orders[b]) for b in range(B)])
+    chain = dv(faces)
+    for k in range(4):
+        chain = lib.face_augment(ctx, chain, dv(rows[:, 5 * k:5 * k + 5].contiguous()))
+    ctx.sync()
+    refo = torch.stack([O.color_jitter_flip(faces[b], bool(params[b, 0]), *[float(v) for v in params[b, 1:]], order=orders[b]) for b in range(B)])
+    close("feeder.jitter.order", chain, refo, 2e-5)
+    assert float((refo[0] - ref[0]).abs().max()) > 1e-2         # the permutation is not a no-op on this image
     geom = torch.tensor([[40, 43, 10, 7], [96, 96, 0, 0], [1, 1, 95, 95]], dtype=torch.int32)
     pasted = lib.paste_on_canvas(ctx, out, geom.to(_dev()))
     ctx.sync()

@@ -485,8 +485,9 @@ def test_feeder_draws_and_lookahead():
     ds = FaceIdDatasetOneShot(pickle_path=None, num_ids=1, size=64, seed=1, diff_cnt=0, synthetic=True)
     ds.rng = random.Random(0)
     for _ in range(200):
-        flip, b, c, s, h = ds._jitter_params()
+        (flip, b, c, s, h), order = ds._jitter_params()
         assert flip in (0.0, 1.0) and all(0.8 <= v <= 1.2 for v in (b, c, s)) and -0.01 <= h <= 0.01
+        assert sorted(order) == [0, 1, 2, 3]                     # ColorJitter's fn_idx: a permutation of the four ops
         rh, rw, ph, pw = ds._bg_geometry()
         assert 1 <= rh <= 64 and 1 <= rw <= 64 and 0 <= ph <= 64 - rh and 0 <= pw <= 64 - rw
         assert rh >= int(64 * 0.1) and abs(rw - rh) <= int(0.1 * rh) + 1
@@ -496,6 +497,72 @@ def test_feeder_draws_and_lookahead():
     exec("def make():\n" + src[start:end] + "    return lookahead\n", ns)
     pairs = list(ns["make"]()([10, 11, 12]))
     assert pairs == [(10, 11), (11, 12), (12, None)] and list(ns["make"]()([])) == []
+
+
+def test_oracle_jitter_vs_pil():
+    """A0 pin. The reference's `trans` (face_id.py:526-532) receives PIL images, so torchvision 0.11.3's ColorJitter runs PIL's
+    arithmetic: ImageEnhance.Brightness / Contrast / Color (a blend of the image against black / its mean gray / its gray
+    version) and, for hue, a shift of the H plane of the 8-bit HSV image — each quantised to uint8. torchvision itself is not
+    installed; PIL is, so the oracle's float restatement (and with it the device kernel, which the GPU suite checks against the
+    oracle) is pinned against PIL's results to that quantisation: <= 1.5 LSB per brightness / contrast / saturation op
+    (PIL truncates), hue within the 8-bit HSV round trip (mean <= 1.5 LSB, max <= 16 LSB — a wrong sign is tens of LSB),
+    and a whole permuted chain of ops (the matching order is the closest one). Also: the feeder's four single-op passes compose to the
+    oracle's permuted chain (DeviceAugmenter.passes, host logic only)."""
+    np = pytest.importorskip("numpy")
+    Image = pytest.importorskip("PIL.Image")
+    ImageEnhance = pytest.importorskip("PIL.ImageEnhance")
+    from celebbasis_amd.ldm.data.face_id import DeviceAugmenter
+    from oracle import cb_oracle as O
+    g = torch.Generator().manual_seed(0)
+    S = 96
+    low = torch.rand(1, 3, 8, 8, generator=g)
+    u8 = (torch.nn.functional.interpolate(low, size=S, mode="bicubic", align_corners=True)[0].permute(1, 2, 0).clamp(0, 1) * 255).round().to(torch.uint8)
+    pil = Image.fromarray(u8.numpy(), "RGB")
+    x = u8.float() / 255 * 2 - 1                               # ToTensor + Normalize(0.5, 0.5) of the same image, HWC
+    lsb = lambda a, b: (a - b).abs() * 127.5
+    to_t = lambda im: torch.from_numpy(np.asarray(im).copy()).float() / 255 * 2 - 1
+
+    def pil_hue(im, hf):                                       # torchvision functional_pil.adjust_hue
+        h, s_, v = im.convert("HSV").split()
+        nh = np.array(h, dtype=np.uint8)
+        with np.errstate(over="ignore"):
+            nh = nh + np.uint8(int(hf * 255) % 256)
+        return Image.merge("HSV", (Image.fromarray(nh, "L"), s_, v)).convert("RGB")
+
+    ops = {0: lambda im, f: ImageEnhance.Brightness(im).enhance(f), 1: lambda im, f: ImageEnhance.Contrast(im).enhance(f),
+           2: lambda im, f: ImageEnhance.Color(im).enhance(f), 3: pil_hue}
+    for f in (0.8, 0.93, 1.0, 1.13, 1.2):
+        for op in (0, 1, 2):
+            args = [1.0, 1.0, 1.0, 0.0]; args[op] = f
+            d = lsb(to_t(ops[op](pil, f)), O.color_jitter_flip(x, False, *args))
+            assert float(d.max()) <= 1.5, (op, f, float(d.max()))
+    for hf in (-0.01, 0.004, 0.01, 0.1, -0.25, 0.4):
+        d = lsb(to_t(pil_hue(pil, hf)), O.color_jitter_flip(x, False, 1.0, 1.0, 1.0, hf))
+        wrong = lsb(to_t(pil_hue(pil, hf)), O.color_jitter_flip(x, False, 1.0, 1.0, 1.0, -hf))
+        assert float(d.mean()) <= 1.5 and float(d.max()) <= 16.0, (hf, float(d.mean()), float(d.max()))
+        if abs(hf) >= 0.1:
+            assert float(wrong.mean()) > 10 * float(d.mean())    # the check has teeth: the opposite shift is far outside the bar
+    # a permuted chain, flip included (PIL: FLIP_LEFT_RIGHT, then the ops in fn_idx order, uint8 after each)
+    params, order = [1.0, 1.17, 0.84, 1.12, 0.0], [2, 0, 3, 1]
+    im = pil.transpose(Image.FLIP_LEFT_RIGHT)
+    for op in order:
+        if op != 3:
+            im = ops[op](im, params[1 + op])
+    d = lsb(to_t(im), O.color_jitter_flip(x, True, *params[1:], order=order))
+    # (PIL's blend truncates, so each op adds up to -1 LSB of bias: three ops = mean 1.5, max 3)
+    assert float(d.max()) <= 4.5 and float(d.mean()) <= 2.0, (float(d.max()), float(d.mean()))
+    for wrong_order in ([0, 1, 2, 3], [1, 0, 2, 3]):             # contrast's pivot depends on what ran before it: the order is visible
+        other = lsb(to_t(im), O.color_jitter_flip(x, True, *params[1:], order=wrong_order))
+        assert float(other.mean()) > 1.5 * float(d.mean()), (wrong_order, float(other.mean()), float(d.mean()))
+    # the device feeder's decomposition: four passes of the fixed-order op with three neutral factors each == the permuted chain
+    params[4] = 0.008
+    rows = DeviceAugmenter.passes(params, order)
+    y = x
+    for k in range(4):
+        r = rows[5 * k:5 * k + 5]
+        y = O.color_jitter_flip(y, bool(r[0]), *r[1:])
+    assert float((y - O.color_jitter_flip(x, True, *params[1:], order=order)).abs().max()) <= 2e-6
+    assert [r for r in rows[0::5]] == [1.0, 0.0, 0.0, 0.0]
 
 
 def test_argument_errors_on_a_dry_context(built_lib):
