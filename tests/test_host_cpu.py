@@ -348,6 +348,27 @@ if r == 0:
     subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                     "--master-port", "29533", str(script)], check=True, env=env, timeout=300)
     assert (tmp_path / "ok").read_text() == "ok"
+    # fewer identities than ranks: the rank that owns none contributes an EMPTY block list (what main.py hands over: zeros(0, D))
+    # and still takes part in both collectives; everybody ends up with the same merged table
+    script2 = tmp_path / "w3.py"
+    script2.write_text(f"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, {ROOT!r})
+from celebbasis_amd import sharding
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+mine = sharding.identities_for_rank(2, r, w)
+assert (mine == []) == (r == 2)
+blocks = torch.stack([torch.full((12,), float(10 * (i + 1))) for i in mine]) if mine else torch.zeros(0, 12)
+out = sharding.gather_identity_blocks(mine, blocks, 4)
+assert out.shape == (4, 12) and torch.all(out[0] == 10) and torch.all(out[1] == 20) and torch.all(out[2:] == 0), (r, out[:, 0])
+dist.barrier()
+if r == 2:
+    open({str(tmp_path / 'ok3')!r}, "w").write("ok")
+""")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "3", "--master-addr", "127.0.0.1",
+                    "--master-port", "29534", str(script2)], check=True, env=env, timeout=300)
+    assert (tmp_path / "ok3").read_text() == "ok"
 
 
 def test_bench_launches_its_own_ranks_and_checks_the_merge():
