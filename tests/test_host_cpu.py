@@ -24,6 +24,33 @@ def test_abi_exports_every_declared_symbol(built_lib):
     assert built_lib.cb_version() == 300          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
 
 
+def test_integration_stub_matches_the_library(built_lib):
+    """INTEGRATION.md §2 shows the reference-side ctypes stub a maintainer would add. Its code block is executed here against
+    the built library (no GPU: definitions only + the calls that need no device): the version it asserts is the library's, every
+    entry point it names is exported, its `cb_batch` has the layout of the typed binding, its opaque 512-byte `cb_trainer_cfg`
+    buffer is large enough and `cb_trainer_cfg_default` writes the struct_size the library will check."""
+    import ctypes as C
+    import re
+    from celebbasis_amd import lib
+    text = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = re.search(r"```python\n(# ldm/models/diffusion/native_step.py.*?)```", text, re.S).group(1)
+    block = block.replace('C.CDLL("libcelebbasis_hip.so")', f"C.CDLL({built_lib._name!r})")
+    ns = {}
+    exec(compile(block, "INTEGRATION.md:native_step", "exec"), ns)          # runs the stub's own `assert lib.cb_version() == 300`
+    so = ns["lib"]
+    for name in set(re.findall(r"lib\.(cb_[a-z0-9_]+)", block)):
+        assert hasattr(so, name), name
+    stub_batch = ns["cb_batch"]
+    assert [(n, t) for n, t in stub_batch._fields_] == [(n, t) for n, t in lib.Batch._fields_]
+    assert C.sizeof(stub_batch) == C.sizeof(lib.Batch)
+    assert C.sizeof(lib.TrainerCfg) <= 512
+    cfg = (C.c_byte * 512)()
+    ns["check"](so.cb_trainer_cfg_default(cfg))
+    assert C.cast(cfg, C.POINTER(C.c_int))[0] == C.sizeof(lib.TrainerCfg)
+    with pytest.raises(RuntimeError):                              # the stub's error path: status -> cb_last_error() text
+        ns["check"](so.cb_trainer_create(None, None, None, None))
+
+
 def test_errors_do_not_cross_the_boundary(built_lib):
     from celebbasis_amd import lib
     ctx = lib.Context(device=-1)
