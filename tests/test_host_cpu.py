@@ -51,6 +51,38 @@ def test_integration_stub_matches_the_library(built_lib):
         ns["check"](so.cb_trainer_create(None, None, None, None))
 
 
+def test_header_structs_and_ctypes_binding_agree(tmp_path):
+    """the C header is what a C / cgo / JNI caller compiles against, celebbasis_amd/lib.py is what the tests call through: a plain-C
+    translation unit (gcc, no HIP) prints sizeof and every field offset of the header's structs, which must equal the ctypes
+    classes' — field for field, by name. Also proves the header is self-contained C (no torch / HIP types in the signatures)."""
+    import ctypes as C
+    import shutil
+    from celebbasis_amd import lib
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc")
+    pairs = [("cb_gemm_desc", lib.GemmDesc), ("cb_attention_desc", lib.AttentionDesc), ("cb_unet_cfg", lib.UNetCfg), ("cb_vae_cfg", lib.VaeCfg),
+             ("cb_clip_cfg", lib.ClipCfg), ("cb_trainer_cfg", lib.TrainerCfg), ("cb_batch", lib.Batch)]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "celebbasis_hip.h"', "int main(void) {"]
+    for cname, cls in pairs:
+        lines.append(f'  printf("{cname} %zu", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            lines.append(f'  printf(" {fname}=%zu", offsetof({cname}, {fname}));')
+        lines.append('  printf("\\n");')
+    lines += ['  printf("version %d\\n", CB_ABI_VERSION);', "  return 0;", "}"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines) + "\n")
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.strip().splitlines()
+    assert out[-1] == f"version {lib.ABI_VERSION}"
+    for (cname, cls), line in zip(pairs, out):
+        toks = line.split()
+        assert toks[0] == cname and int(toks[1]) == C.sizeof(cls), (cname, toks[1], C.sizeof(cls))
+        got = dict(t.split("=") for t in toks[2:])
+        for fname, _ in cls._fields_:
+            assert int(got[fname]) == getattr(cls, fname).offset, (cname, fname, got[fname], getattr(cls, fname).offset)
+
+
 def test_errors_do_not_cross_the_boundary(built_lib):
     from celebbasis_amd import lib
     ctx = lib.Context(device=-1)
