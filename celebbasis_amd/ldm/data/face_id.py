@@ -64,7 +64,7 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
             lo, hi = [int(x) for x in specific_ids.split("-")]
             specific_ids = list(range(lo, hi))
         self.size = int(size if size is not None else image_size)
-        self.flip_p, self.split, self.repeats = (flip_p if split == "train" else 0.0), split, repeats
+        self.flip_p, self.split, self.repeats = flip_p, split, repeats      # 'dev' is the reference's only special split (face_id.py:533-539, 627)
         self.num_ids, self.specific_ids, self.images_per_id = int(num_ids), (list(specific_ids) if specific_ids is not None else None), 1
         self.placeholder, self.seed, self.synthetic = placeholder, seed, bool(synthetic)
         self.rng = random.Random(seed)
@@ -129,7 +129,7 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         return self.rng
 
     def __len__(self):
-        return len(self.ids) * (self.repeats if self.split == "train" else 1)
+        return len(self.ids) * self.repeats                     # face_id.py:516-522: every split repeats its list
 
     def _aug(self, img):
         """flip + colour jitter on the CPU worker (face_id.py:526-532), same parameter draws and formulas as the device path"""
@@ -180,6 +180,8 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         the four factors"""
         r = self.rng
         flip = 1.0 if r.random() < self.flip_p else 0.0
+        if self.split == "dev":                                 # face_id.py:533-539: the 'dev' transform flips but has no ColorJitter
+            return [flip, 1.0, 1.0, 1.0, 0.0], [0, 1, 2, 3]
         order = r.sample(range(4), 4)
         return [flip, r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(0.8, 1.2), r.uniform(-0.01, 0.01)], order
 
@@ -188,7 +190,7 @@ class FaceIdDatasetStyleGAN3(torch.utils.data.Dataset):
         ident = self.ids[i % len(self.ids)]                   # dense slot = id_idx of face_id.py:650-653
         face = self.faces[ident]
         img, img3 = self._aug(face), self._aug(face)
-        train_img = self._add_bg(img) if self.split == "train" else img
+        train_img = self._add_bg(img) if self.split != "dev" else img       # face_id.py:627
         caption = self.rng.choice(imagenet_templates_small).format(f"face of {self.placeholder} person")
         return dict(image=train_img, image_ori=dict(faces=torch.cat([img, img3], -1), ids=torch.tensor([ident, ident]), num_ids=1),
                     caption=caption, id_idx=ident, img_idx=i)
@@ -227,7 +229,7 @@ class DeviceAugmenter:
         p1, p3, geom, caps = [], [], [], []
         for _ in indices:
             p1.append(ds._jitter_params()); p3.append(ds._jitter_params())
-            if ds.split == "train":
+            if ds.split != "dev":
                 geom.append(ds._bg_geometry())
             caps.append(ds.rng.choice(imagenet_templates_small).format(f"face of {ds.placeholder} person"))
         return p1, p3, geom, caps

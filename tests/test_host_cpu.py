@@ -571,6 +571,24 @@ def test_feeder_draws_and_lookahead():
         rh, rw, ph, pw = ds._bg_geometry()
         assert 1 <= rh <= 64 and 1 <= rw <= 64 and 0 <= ph <= 64 - rh and 0 <= pw <= 64 - rw
         assert rh >= int(64 * 0.1) and abs(rw - rh) <= int(0.1 * rh) + 1
+    # splits (face_id.py:516-539, 627): only 'dev' is special — it keeps the flip but has no ColorJitter and no `_add_bg`; 'val' (the
+    # shipped validation block, aigc_id.yaml:110-119) is augmented like 'train'; every split repeats its list
+    mk = lambda split: FaceIdDatasetOneShot(pickle_path=None, num_ids=2, size=32, seed=1, diff_cnt=0, synthetic=True, split=split, repeats=3)
+    tr_, val, dev = mk("train"), mk("val"), mk("dev")
+    assert len(tr_) == len(val) == len(dev) == 6
+    a, b = tr_[1], val[1]
+    assert torch.equal(a["image"], b["image"]) and torch.equal(a["image_ori"]["faces"], b["image_ori"]["faces"]) and a["caption"] == b["caption"]
+    flips = 0
+    for i in range(20):
+        d = dev[i]
+        face = dev.faces[i % 2]
+        img1, img3 = d["image_ori"]["faces"][..., :3], d["image_ori"]["faces"][..., 3:]
+        for im in (img1, img3):
+            same, flipped = float((im - face).abs().max()), float((im - face.flip(1)).abs().max())
+            assert min(same, flipped) < 1e-6                    # flip or not, nothing else
+            flips += flipped < same
+        assert torch.equal(d["image"], img1)                    # no rescale-paste on 'dev'
+    assert 5 <= flips <= 35                                     # RandomHorizontalFlip(p=0.5) stays on
     src = open(os.path.join(ROOT, "celebbasis_amd", "main.py")).read()
     ns = {}
     start = src.index("    def lookahead(loader):"); end = src.index("    while step < max_steps:")
