@@ -7,7 +7,6 @@ process per GPU (torchrun), identities sharded across ranks, coefficients merged
 import argparse
 import os
 import random
-import sys
 
 import torch
 import yaml

@@ -5,8 +5,6 @@ kernel: fp32 accumulation of bf16 operands + one bf16 rounding of the output). T
 max|hip - ref| <= tol * max|ref| with tol = 1e-2, i.e. ~2.5 bf16 ulps (2^-8 = 3.9e-3) of the output's largest magnitude —
 one rounding of the result plus the roundings of bf16 intermediates (probabilities, dS) inside the fused kernels."""
 import ctypes as C
-import json
-import os
 
 import pytest
 import torch

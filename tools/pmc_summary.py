@@ -7,8 +7,6 @@ from _names import clean  # noqa: E402
 import collections
 import csv
 import glob
-import re
-import sys
 
 acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0, 0.0]))
 for d in sys.argv[1:]:

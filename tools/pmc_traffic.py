@@ -16,8 +16,6 @@ import collections
 import csv
 import glob
 import json
-import re
-import sys
 
 
 def load(d, counter):

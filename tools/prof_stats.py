@@ -4,9 +4,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _names import clean  # noqa: E402
-import re
 import sqlite3
-import sys
 
 db, out, nsteps = sys.argv[1], sys.argv[2], int(sys.argv[3])
 c = sqlite3.connect(db).cursor()

@@ -5,9 +5,7 @@ import os
 import sys
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from _names import clean  # noqa: E402
-import re
 import sqlite3
-import sys
 
 db, nsteps = sys.argv[1], int(sys.argv[2])
 sub = sys.argv[3] if len(sys.argv) > 3 else ""
