@@ -14,8 +14,8 @@
 #   pmcsq <tag> <script.py>   three --pmc passes (SQ busy / waits, instruction mix, L2 hit + TA busy) of a fixed workload
 #   py <script> [args]        python <script> …                       -> gpurun_out/<script name>.log
 # Box time measured in round 3 (what a call is charged, + ~20 s per call): full `tests` ~7 min (the CPU oracle at SD size is most of it); one
-# bench.py process ~25 - 30 s; `trace` + `trace3` + `pmc` + `pmc3` (six rocprofv3 runs of bench.py) ~4 min — i.e. re-stamping profiles/ after a
-# kernel change costs ~5 min, a pmcsq of a micro-workload < 1 min, the CLI with --report (220 steps) ~25 s.
+# bench.py process ~25 - 30 s; `trace` + `trace3` + `pmc` + `pmc3` (six rocprofv3 runs of bench.py) ~2 min (the call that ran suite + smoke + bench + all four was
+# charged 550 s) — i.e. re-stamping profiles/ after a kernel change costs ~3 min with a bench run, a pmcsq of a micro-workload < 1 min, the CLI with --report (220 steps) ~25 s.
 set -u
 mkdir -p gpurun_out
 export TMPDIR=/tmp
