@@ -2,6 +2,7 @@
 # tools/gpurun.sh <what> [args…] — the one script that runs on the GPU box (invoked as: gpurun -- 'bash tools/gpurun.sh <what> …').
 # Everything it writes goes to gpurun_out/ (merged back by gpurun); summaries worth keeping are copied to profiles/ by hand.
 #   tests [pytest args]       pytest -m gpu (default: the whole GPU suite)
+#   fast                      pytest -m 'gpu and not slow' (everything but the SD-size oracle / subprocess tests: 119 tests in 47 s)
 #   smoke                     __graft_entry__.smoke()
 #   bench [bench.py args]     python bench.py …                       -> gpurun_out/bench.json
 #   trace <tag> [bench args]  rocprofv3 --kernel-trace of bench.py + per-symbol CSV (tools/prof_stats.py)
@@ -26,6 +27,9 @@ case "$what" in
     if [ $# -eq 0 ]; then set -- tests -m gpu; fi
     ( time python -m pytest "$@" -q -p no:cacheprovider --no-header ) > gpurun_out/pytest.log 2>&1
     tail -25 gpurun_out/pytest.log ;;
+  fast)
+    ( time python -m pytest tests -m "gpu and not slow" -q -p no:cacheprovider --no-header --durations=10 "$@" ) > gpurun_out/pytest_fast.log 2>&1
+    tail -25 gpurun_out/pytest_fast.log ;;
   smoke)
     python -c "import __graft_entry__ as g; g.smoke()" > gpurun_out/smoke.log 2>&1; tail -2 gpurun_out/smoke.log ;;
   bench)
