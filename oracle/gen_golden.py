@@ -357,7 +357,7 @@ def gen_basis(manifest):
         ids = [49406] + tab[name] + [49407] * (77 - 1 - len(tab[name]))
         return {"input_ids": torch.tensor([ids])}
 
-    out = dict(table_seed=61, width=width, n_components=K, names=names, token_table={n: tab[n] for n in set(names)})
+    out = dict(table_seed=61, width=width, n_components=K, names=names, token_table={n: tab[n] for n in sorted(set(names))})
     with tempfile.TemporaryDirectory() as td:
         txt = os.path.join(td, "names.txt")
         open(txt, "w").write("\n".join(names))
