@@ -26,7 +26,8 @@ EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_V
 # Kernels whose software pipeline COUNTS its outstanding VMEM instructions (`s_waitcnt vmcnt(N)` + raw `s_barrier`,
 # cb_gemm_glds.hip): a register spill would add scratch loads / stores to that count and let a tile be read before it has landed.
 # The build therefore fails if any kernel of these files has scratch, spills or a dynamic stack (-Rpass-analysis remarks).
-NO_SCRATCH = {"cb_gemm_glds.hip": "gemm_glds", "cb_flash_bf16_v2.hip": "f2_"}
+# (The f2_* attention kernels drain with vmcnt(0) and do not depend on the count: scratch there is reported, not fatal.)
+NO_SCRATCH = {"cb_gemm_glds.hip": ("gemm_glds", True), "cb_flash_bf16_v2.hip": ("f2_", False)}
 
 
 def source_digest():
@@ -90,16 +91,31 @@ def check_no_scratch(remarks, needle):
             continue
         if cur is None:
             continue
-        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|SGPRs Spill|VGPRs Spill|Dynamic Stack): (\S+)", line)
+        # SGPR -> VGPR spills add no memory instructions and are harmless to the count
+        m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill|Dynamic Stack): (\S+)", line)
         if m and m.group(2) not in ("0", "False"):
             bad.append((cur, m.group(1), m.group(2)))
     return bad, seen
 
 
 def build(verbose=True, force=False):
+    """Serialised across processes: N ranks importing `lib` against a stale or missing library all arrive here; an exclusive flock on
+    _build/.lock lets the first one compile while the others wait and then find everything up to date (tests/test_host_cpu.py)."""
+    import fcntl
     os.makedirs(BUILD, exist_ok=True)
+    with open(os.path.join(BUILD, ".lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            return _build_locked(verbose, force)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose, force):
     hdrs = [os.path.join(CSRC, h) for h in HEADERS]
     hipcc = _hipcc()
+    for flags in {tuple(v) for v in EXTRA.values() if v}:          # probe once, before the worker threads share the cache
+        _flag_supported(hipcc, flags)
 
     def compile_one(src):
         import hashlib
@@ -109,7 +125,7 @@ def build(verbose=True, force=False):
             print(f"[celebbasis_amd.build] WARNING: {hipcc} rejects {' '.join(extra)}; building {src} without it "
                   "(attention accumulators in AGPR form: correct, a few percent slower)", flush=True)
             extra = []
-        guard = NO_SCRATCH.get(src)
+        guard, fatal = NO_SCRATCH.get(src, (None, False))
         if guard:
             extra += ["-Rpass-analysis=kernel-resource-usage"]
         # the RESOLVED flag set is part of the object's cache key
@@ -124,8 +140,21 @@ def build(verbose=True, force=False):
                 if r.returncode != 0:
                     sys.stderr.write(r.stderr)
                     raise subprocess.CalledProcessError(r.returncode, cmd)
+                show = False                                        # ordinary warnings of these files are not swallowed
+                for l in r.stderr.splitlines():
+                    if "remark:" in l:
+                        show = False
+                    elif "warning:" in l or "error:" in l:
+                        show = True
+                    if show:
+                        sys.stderr.write(l + "\n")
                 bad, seen = check_no_scratch(r.stderr, guard)
-                if bad or not seen:
+                if not seen and os.environ.get("CB_REQUIRE_REMARKS", "0") != "1":
+                    print(f"[celebbasis_amd.build] WARNING: {hipcc} printed no kernel-resource-usage remarks for {src}; the spill "
+                          "guard of the counted-vmcnt kernels could not run (CB_REQUIRE_REMARKS=1 makes this fatal)", flush=True)
+                elif bad and not fatal:
+                    print(f"[celebbasis_amd.build] WARNING: {src}: scratch / spills in {bad[:4]} (slower, still correct)", flush=True)
+                elif bad or not seen:
                     if os.path.exists(o):
                         os.remove(o)
                     raise RuntimeError(f"{src}: the counted-vmcnt pipeline requires spill-free kernels; "

@@ -78,6 +78,10 @@ struct Launch {
     void count(long n = 1) const { if (stats) stats->launches += n; }
 };
 
+// Kernels with more than 64 KB of dynamic LDS need hipFuncAttributeMaxDynamicSharedMemorySize, and the attribute belongs to the
+// CURRENT device: remembered per (kernel, device), so a second context on another GPU of the same process sets it again.
+void set_dyn_lds(const void* kernel, int bytes);
+
 inline unsigned cdiv(long a, long b) { return (unsigned)((a + b - 1) / b); }
 inline long rup(long a, long b) { return (a + b - 1) / b * b; }
 

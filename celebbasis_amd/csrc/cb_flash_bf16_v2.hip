@@ -627,11 +627,7 @@ static void f2_launch_fwd(int qb, bool rg, dim3 grid, hipStream_t st, const Flas
 template <int KS, int DT, int QB, bool RG>
 static void f2_go_dq(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* KT, int Np) {
     constexpr int LDS = 2 * f2_dq_stage<KS, DT>();
-    static const bool once = [] {
-        CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&f2_dq_kernel<KS, DT, QB, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        return true;
-    }();
-    (void)once;
+    set_dyn_lds(reinterpret_cast<const void*>(&f2_dq_kernel<KS, DT, QB, RG>), LDS);
     hipLaunchKernelGGL((f2_dq_kernel<KS, DT, QB, RG>), grid, dim3(256), LDS, st, a, KT, Np);
 }
 template <int KS, int DT>
@@ -643,11 +639,7 @@ static void f2_launch_dq(int qb, bool rg, dim3 grid, hipStream_t st, const Flash
 template <int KS, int DT, int QB, bool RG>
 static void f2_go_dkv(dim3 grid, hipStream_t st, const FlashArgs& a, const bf16_t* QT, const bf16_t* DTp, int Np) {
     constexpr int LDS = 2 * f2_dkv_stage<KS, DT>();
-    static const bool once = [] {
-        CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&f2_dkv_kernel<KS, DT, QB, RG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        return true;
-    }();
-    (void)once;
+    set_dyn_lds(reinterpret_cast<const void*>(&f2_dkv_kernel<KS, DT, QB, RG>), LDS);
     hipLaunchKernelGGL((f2_dkv_kernel<KS, DT, QB, RG>), grid, dim3(256), LDS, st, a, QT, DTp, Np);
 }
 template <int KS, int DT>

@@ -23,6 +23,7 @@
 // profiles/r01_pmc_conv.md (PMC) and profiles/README.md (per-step history, rejected experiments).
 #include "cb_gemm_tiles.h"
 #include <cstdarg>
+#include <mutex>
 
 namespace cb {
 
@@ -390,6 +391,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 }
 
 // ---------------------------------------------------------------- host side (planner: cb_gemm_tiles.h)
+void set_dyn_lds(const void* kernel, int bytes) {
+    static std::mutex mu;
+    static std::unordered_map<const void*, uint64_t> done;       // kernel -> bit per device ordinal
+    int dev = 0;
+    CB_HIP(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> g(mu);
+    uint64_t& m = done[kernel];
+    if (dev < 64 && ((m >> dev) & 1ull)) return;
+    CB_HIP(hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    if (dev < 64) m |= 1ull << dev;
+}
+
 size_t gemm_ws_bytes(const GemmArgs& a) {
     Plan pl = make_plan(a, BK, 1.0);
     size_t own = pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);

@@ -151,6 +151,39 @@ __device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
     *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
 }
+// one 8-column piece of an output row: v = alpha*acc + bias, + rowbias / residual / beta*C, rounded once to T. `vec`: the piece lies
+// inside N; the 16-byte path needs aligned C / rowbias / R pieces, everything else goes element by element.
+template <typename T>
+__device__ __forceinline__ void glds_finish_piece(const GemmArgs& a, float (&v)[8], const float (&bcol)[8], T* __restrict__ Cp, const T* __restrict__ Rp,
+                                                  const T* __restrict__ rowbias, long ldrb, int row, int col, bool vec) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a.alpha * v[e] + bcol[e];
+    T* c = Cp + (long)row * a.ldc + col;
+    const T* rb = rowbias ? rowbias + (long)(row / a.rows_per_img) * ldrb + col : nullptr;
+    const T* rr = Rp ? Rp + (long)row * a.ldr + col : nullptr;
+    if (vec && al16(c) && (!rb || al16(rb)) && (!rr || al16(rr))) {
+        float t[8];
+        if (rb) { ld8(rb, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+        if (rr) { ld8(rr, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+        if (a.beta != 0.f) { ld8(c, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
+        st8(c, v);
+    } else {
+        for (int e = 0; e < 8 && col + e < a.N; ++e) {
+            float x = v[e];
+            if (rb) x += (float)rb[e];
+            if (rr) x += (float)rr[e];
+            if (a.beta != 0.f) x += a.beta * (float)c[e];
+            c[e] = (T)x;
+        }
+    }
+}
 template <typename T, int BM, int BN, int WM = 2>
 __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)[BM / WM / 32][BN / 64], char* lds, int m0, int n0, int wm,
                                                    int wn, int lane, int wave, int split, int z, int zb, int zh) {
@@ -194,39 +227,13 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
     }
     T* __restrict__ Cp = static_cast<T*>(a.C) + zb * a.sCb + zh * a.sCh;
     const T* __restrict__ Rp = a.R ? static_cast<const T*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
 #pragma unroll
     for (int ps = 0; ps < WR / RPP; ++ps) {
         const int rl = ps * RPP + rsub, row = m0 + wm * WR + rl;
         if (row >= a.M || col >= a.N) continue;
         const float4 v0 = *reinterpret_cast<const float4*>(S + rl * WC + cc), v1 = *reinterpret_cast<const float4*>(S + rl * WC + cc + 4);
         float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = a.alpha * v[e] + bcol[e];
-        T* c = Cp + (long)row * a.ldc + col;
-        const T* rb = rowbias ? rowbias + (long)(row / a.rows_per_img) * ldrb + col : nullptr;
-        const T* rr = Rp ? Rp + (long)row * a.ldr + col : nullptr;
-        if (vec && al16(c) && (!rb || al16(rb)) && (!rr || al16(rr))) {
-            float t[8];
-            if (rb) { ld8(rb, t);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += t[e]; }
-            if (rr) { ld8(rr, t);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += t[e]; }
-            if (a.beta != 0.f) { ld8(c, t);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
-            st8(c, v);
-        } else {
-            for (int e = 0; e < 8 && col + e < a.N; ++e) {
-                float x = v[e];
-                if (rb) x += (float)rb[e];
-                if (rr) x += (float)rr[e];
-                if (a.beta != 0.f) x += a.beta * (float)c[e];
-                c[e] = (T)x;
-            }
-        }
+        glds_finish_piece<T>(a, v, bcol, Cp, Rp, rowbias, ldrb, row, col, vec);
     }
 }
 
@@ -376,6 +383,208 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const KArgs p) {
     gemm_glds_body<T, BM, BN, AK, RB, STAGES>(p, lds);
 }
 
+
+// ================================================================= the 80-column tile (fp32): SD v1-4's widths are 320 * 2^j
+// Every Linear / conv output of the UNet is 320, 640, 1280 (or a small multiple) columns wide and, at bs = 1, 4096 / 1024 / 256 / 64
+// rows tall. In 64-wide tiles that is 5 * 2^j column tiles: 320 blocks at 64x64 on 256 CUs put two tiles on 64 of them (the critical
+// CU runs 2.0 tile-times for 1.25 tiles of work), and the 32x32 ... 8x8 levels need a split-K with its reduce launch to fill the
+// chip at all. An 80-column tile makes the column count 4 * 2^j, and the block's four waves trade rows for k-groups as M shrinks:
+//      BM = 64: 4 waves x 16 rows, one k-group      4096 x 320 -> 64 x 4 = 256 blocks
+//      BM = 32: 2 x 16 rows, 2 k-groups             1024 x 640 -> 32 x 8 = 256 blocks
+//      BM = 16: 1 x 16 rows, 4 k-groups              256 x 1280 -> 16 x 16 = 256 blocks
+// i.e. one block per CU, one wave per SIMD, at every level, with the k-split INSIDE the block: the KW partial strips meet in LDS (fixed
+// order: deterministic), no partials in HBM, no reduce launch. A wave owns a 16 x 80 strip = five 16x16 accumulators of
+// v_mfma_f32_16x16x4_f32 (same FLOP rate as 32x32x2; one A fragment feeds five MFMAs), k-group g walks its own contiguous slice of K.
+// Staging is the LDS-DMA ring of the kernel above (128-byte rows, source-side XOR swizzle, counted vmcnt): the A image is 64 rows
+// (KW groups x BM rows), the B image KW x 80 rows padded to whole 256-chunk slots. A 16-lane group of the ds_read_b128 fragment read
+// covers rows {0-3, 12-15} at logical chunk c and rows {4-11} at chunk c ^ 1: with the (row >> 1) & 7 swizzle 16 distinct bank quads.
+typedef float f32x4a __attribute__((ext_vector_type(4)));
+template <int BM, int STAGES> struct G80 {
+    static constexpr int KW = 64 / BM, WMV = BM / 16, NA = 2, BROWS = KW * 80, NB = (BROWS * 8 + 255) / 256;
+    static constexpr int A_BUF = 64 * 128, B_BUF = NB * 256 * 16, STAGE = A_BUF + B_BUF, LDS = STAGES * STAGE, SLD = 84;
+    static_assert(64 * SLD * 4 <= LDS, "the epilogue parks KW x BM x 80 fp32 partials in the ring");
+};
+
+template <int BM, int AK, int STAGES>
+__device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
+    using Q = G80<BM, STAGES>;
+    using G = GGeo<128, 4>;
+    constexpr int KW = Q::KW, WMV = Q::WMV, NA = Q::NA, NB = Q::NB, BKT = 32;
+    const GemmArgs& a = p.a;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    const int t = xcd_remap(blockIdx.x, ntiles);
+    const int tm = t / p.tiles_n, tn = t - tm * p.tiles_n;
+    const int m0 = tm * BM, n0 = tn * 80;
+    const int split = blockIdx.y;
+    const float* __restrict__ Ap = static_cast<const float*>(a.A);
+    const float* __restrict__ Bp = static_cast<const float*>(a.B);
+    const int kbeg = split * p.k_per_split;
+    const int kend = min(a.K, kbeg + p.k_per_split);
+    const int ktiles = (kend - kbeg + BKT - 1) / BKT;
+    const int ktg = (ktiles + KW - 1) / KW;                 // k-tiles per group (the last group may get fewer: zero tiles past its end)
+
+    // ---- per-slot source state. Slot i of a thread is chunk idx = tid + i * 256 of the stage image (lane-linear LDS-DMA destination).
+    int a_off[NA], a_klim[NA], b_off[NB], b_klim[NB];
+    unsigned a_vmask[NA]; int a_tap[NA], a_ci[NA];
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+        const int idx = tid + i * 256, irow = idx >> 3;
+        const int g = __builtin_amdgcn_readfirstlane(((wave * 64 + i * 256) >> 3) / BM);      // wave-uniform: 64 lanes = 8 image rows
+        const int r = irow - g * BM, lc = G::chunk(idx) * 4;
+        const int kg0 = kbeg + g * ktg * BKT, kge = min(kend, kg0 + ktg * BKT);
+        a_klim[i] = kge - kg0 - lc;
+        a_vmask[i] = 0; a_tap[i] = 0; a_ci[i] = 0;
+        const int row = m0 + r;
+        if constexpr (AK == AK_ROW) {
+            a_off[i] = (row < a.M) ? (int)(((long)row * a.lda + kg0 + lc) * 4) : OOB;
+        } else {
+            const ConvGeom& cg = a.g;
+            unsigned m = 0; int b = 0;
+            if (row < a.M) {
+                const int HWo = cg.Ho * cg.Wo;
+                const int n = row / HWo, rem = row - n * HWo, oy = rem / cg.Wo, ox = rem - oy * cg.Wo;
+                const int vy0 = oy * cg.stride - cg.pad, vx0 = ox * cg.stride - cg.pad;
+                unsigned xb = 0, yb = 0;
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (k < cg.ks) {
+                        xb |= ((unsigned)(vx0 + k) < (unsigned)cg.W) ? (1u << k) : 0u;
+                        yb |= ((unsigned)(vy0 + k) < (unsigned)cg.H) ? (1u << k) : 0u;
+                    }
+#pragma unroll
+                for (int ky = 0; ky < 4; ++ky)
+                    if (ky < cg.ks && ((yb >> ky) & 1u)) m |= xb << (cg.ks * ky);
+                b = (((n * cg.H + vy0) * cg.W + vx0) * cg.C + lc) * 4;
+            }
+            a_vmask[i] = m; a_off[i] = b;
+            a_tap[i] = kg0 / cg.C; a_ci[i] = kg0 - a_tap[i] * cg.C;          // scalar (g is wave-uniform): the group's tap walk
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+        const int idx = tid + i * 256, irow = idx >> 3;
+        const int g = irow / 80, r = irow - g * 80, lc = G::chunk(idx) * 4;
+        const int kg0 = kbeg + g * ktg * BKT, kge = min(kend, kg0 + ktg * BKT);
+        const bool ok = irow < Q::BROWS && n0 + r < a.N;
+        b_klim[i] = ok ? kge - kg0 - lc : 0;
+        b_off[i] = ok ? (int)(((long)(n0 + r) * a.ldb + kg0 + lc) * 4) : OOB;
+    }
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    const int wbase = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
+
+    // one LDS-DMA piece (slot `pc`: A slots first, then B) of k-tile kt -> ring slot `stage`
+    auto piece = [&](int pc, int kt, char* stage) {
+        const int ko = kt * BKT;
+        if (pc < NA) {
+            const int i = pc;
+            int oa;
+            if constexpr (AK == AK_ROW) oa = (a_off[i] != OOB && ko < a_klim[i]) ? a_off[i] + ko * 4 : OOB;
+            else {
+                const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
+                const int delta = ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;
+                oa = (ko < a_klim[i] && ((a_vmask[i] >> (a_tap[i] & 31)) & 1u)) ? a_off[i] + delta : OOB;
+                a_ci[i] += BKT;
+                if (a_ci[i] >= a.g.C) { a_ci[i] -= a.g.C; ++a_tap[i]; }
+            }
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, oa, 0, 0, 0);
+        } else {
+            const int i = pc - NA;
+            const int ob = (ko < b_klim[i]) ? b_off[i] + ko * 4 : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(stage + Q::A_BUF + wbase + i * 4096), 16, ob, 0, 0, 0);
+        }
+    };
+
+    f32x4a acc[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) acc[j] = f32x4a{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < STAGES - 1; ++s)
+#pragma unroll
+        for (int pc = 0; pc < NA + NB; ++pc) piece(pc, s, lds80 + s * Q::STAGE);
+
+    const int g = wave / WMV, wm = wave - g * WMV;
+    const int lg = lane >> 4, lr = lane & 15, sw = lr >> 1;
+    const int arow_off = (g * BM + wm * 16 + lr) * 128, brow_off = Q::A_BUF + (g * 80 + lr) * 128;
+    int cur = 0, nxt = STAGES - 1;
+    for (int kt = 0; kt < ktg; ++kt) {
+        if (p.safe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
+        else { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory"); __builtin_amdgcn_s_barrier(); }
+        const char* st = lds80 + cur * Q::STAGE;
+        // the next tile's pieces go out in one clump: spreading them between the MFMAs was measured and changes nothing (profiles/README.md, round 4)
+#pragma unroll
+        for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + STAGES - 1, lds80 + nxt * Q::STAGE);
+        // all twelve fragment reads of the k-tile first (chunk 4s + lg is the lane's k-slot quadruple of half tile s), then the 40 MFMAs:
+        // with one wave per SIMD nobody else covers the LDS latency, so it is paid once per k-tile instead of once per half tile
+        f32x4a av[2], bv[2][5];
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const int co = ((4 * s + lg) ^ sw) * 16;
+            av[s] = *reinterpret_cast<const f32x4a*>(st + arow_off + co);
+#pragma unroll
+            for (int j = 0; j < 5; ++j) bv[s][j] = *reinterpret_cast<const f32x4a*>(st + brow_off + j * 2048 + co);
+        }
+        __builtin_amdgcn_sched_barrier(0);                    // keep the reads ahead of the MFMAs (the scheduler sinks half of them otherwise)
+#pragma unroll
+        for (int q = 0; q < 40; ++q) {
+            const int s = q / 20, e = (q / 5) & 3, j = q % 5;
+            acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][e], bv[s][j][e], acc[j], 0, 0, 0);
+        }
+        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
+        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    // ---- the KW partial strips meet in LDS; D layout of 16x16x4: lane holds column lr, rows 4 * lg + r
+    float* S = reinterpret_cast<float*>(lds80);
+#pragma unroll
+    for (int j = 0; j < 5; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) S[(g * BM + wm * 16 + 4 * lg + r) * Q::SLD + j * 16 + lr] = acc[j][r];
+    __syncthreads();
+    float* __restrict__ Cp = static_cast<float*>(a.C);
+    const float* __restrict__ Rp = static_cast<const float*>(a.R);
+    const float* __restrict__ rowbias = static_cast<const float*>(a.rowbias);
+    const long ldrb = a.ld_rowbias ? a.ld_rowbias : a.N;
+    for (int q = tid; q < BM * 10; q += 256) {
+        const int rl = q / 10, cc = (q - rl * 10) * 8;
+        const int row = m0 + rl, col = n0 + cc;
+        if (row >= a.M || col >= a.N) continue;
+        float v[8];
+        {
+            const float4 v0 = *reinterpret_cast<const float4*>(S + rl * Q::SLD + cc), v1 = *reinterpret_cast<const float4*>(S + rl * Q::SLD + cc + 4);
+            v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+        }
+#pragma unroll
+        for (int gg = 1; gg < KW; ++gg) {
+            const float* sp = S + (gg * BM + rl) * Q::SLD + cc;
+            const float4 v0 = *reinterpret_cast<const float4*>(sp), v1 = *reinterpret_cast<const float4*>(sp + 4);
+            v[0] += v0.x; v[1] += v0.y; v[2] += v0.z; v[3] += v0.w; v[4] += v1.x; v[5] += v1.y; v[6] += v1.z; v[7] += v1.w;
+        }
+        const bool vec = (col + 8 <= a.N);
+        if (p.splitk > 1) {
+            float* w = p.ws + (long)split * a.M * a.N + (long)row * a.N + col;
+            if (vec && (a.N % 4 == 0)) {
+                *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else
+                for (int e = 0; e < 8 && col + e < a.N; ++e) w[e] = v[e];
+            continue;
+        }
+        float bcol[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bcol[e] = (a.bias && col + e < a.N) ? a.bias[col + e] : 0.f;
+        glds_finish_piece<float>(a, v, bcol, Cp, Rp, rowbias, ldrb, row, col, vec);
+    }
+}
+// (the body lives in a __device__ function: target builtins used directly inside a __global__ template make the HOST pass drop the stub)
+template <int BM, int AK, int STAGES>
+__global__ __launch_bounds__(256) void gemm_glds80_kernel(const KArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char lds80_dyn[];
+    gemm_glds80_body<BM, AK, STAGES>(p, lds80_dyn);
+}
+
 // ---------------------------------------------------------------- host side
 // Variant selection (experiments): CB_BF16_GEMM = 128x2 | 128x3 | 64x2 | 64x3  (row bytes x ring stages; default 128x2)
 struct GVariant { bool glds; int rb, stages; };
@@ -404,11 +613,7 @@ static void launch_tiles_bf16(const Plan& pl, dim3 grid, hipStream_t s, const KA
     const GVariant& v = gvariant();
     if (pl.BM == 256) {
         CB_CHECK(v.glds && v.rb == 128 && pl.BN == 128, CB_ERR_STATE, "gemm_bf16: the 256x128 tile exists for the default LDS-DMA variant only");
-        static const bool once = [] {
-            CB_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_glds256_kernel<bf16_t, AK>), hipFuncAttributeMaxDynamicSharedMemorySize, GLDS256_LDS));
-            return true;
-        }();
-        (void)once;
+        set_dyn_lds(reinterpret_cast<const void*>(&gemm_glds256_kernel<bf16_t, AK>), GLDS256_LDS);
         hipLaunchKernelGGL((gemm_glds256_kernel<bf16_t, AK>), grid, dim3(512), GLDS256_LDS, s, ka);
         return;
     }
@@ -451,13 +656,36 @@ static double f32_glds_speed() {
     static const double s = [] { const char* e = getenv("CB_PLAN_F32G_SPEED"); return e && atof(e) > 0 ? atof(e) : 1.25; }();
     return s;
 }
+// the 80-column tiles take what the fp32 LDS-DMA kernel takes, minus batches and the general gather (upsample / transposed holes / C % 32)
+static bool n80_ok(const GemmArgs& a) {
+    static const bool on = [] { const char* e = getenv("CB_N80"); return !(e && e[0] == '0'); }();
+    if (!on || f32_glds_mode() != 1 || a.batch != 1 || a.N < 40) return false;
+    if (a.a_kind == LD_CONV) return !a.g.up && !a.g.tr && a.g.C % 32 == 0;
+    return a.a_kind == LD_ROW;
+}
 size_t gemm_f32_glds_ws_bytes(const GemmArgs& a) {
-    Plan pl = make_plan(a, f32_glds_bk(), f32_glds_speed());
+    Plan pl = make_plan(a, f32_glds_bk(), f32_glds_speed(), n80_ok(a));
     return pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
+}
+// the 80-column tiles: dynamic LDS (40 / 56 / 96 KB for BM = 64 / 32 / 16), two ring stages (three were measured slower: fewer blocks per CU)
+template <int BM, int AK>
+static void launch_n80_one(dim3 grid, hipStream_t s, const KArgs& ka) {
+    constexpr int LDS = G80<BM, 2>::LDS;
+    set_dyn_lds(reinterpret_cast<const void*>(&gemm_glds80_kernel<BM, AK, 2>), LDS);
+    hipLaunchKernelGGL((gemm_glds80_kernel<BM, AK, 2>), grid, dim3(256), LDS, s, ka);
+}
+template <int AK>
+static void launch_n80(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    CB_CHECK(AK != AK_CONV, CB_ERR_STATE, "gemm: the 80-column tile takes ROW and plain-conv (C %% 32 == 0) operands only");
+    constexpr int AKK = AK == AK_CONV ? AK_CONVF : AK;
+    if (pl.BM == 64) launch_n80_one<64, AKK>(grid, s, ka);
+    else if (pl.BM == 32) launch_n80_one<32, AKK>(grid, s, ka);
+    else launch_n80_one<16, AKK>(grid, s, ka);
 }
 template <int AK>
 static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     CB_CHECK(pl.BM != 256, CB_ERR_STATE, "gemm: the 256x128 tile is a bf16 variant");
+    if (pl.BN == 80) { launch_n80<AK>(pl, grid, s, ka); return; }
     if (f32_glds_mode() == 2) launch_glds<float, AK, 64, 3>(pl, grid, s, ka);
     else launch_glds<float, AK, 128, 2>(pl, grid, s, ka);
 }
@@ -486,9 +714,10 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     const std::string key = plan_key(a, bk);
     if (t->seen.count(key)) return;
     t->seen[key] = 1;
-    static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
+    static const int tiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
-    const int ntile = (sizeof(T) == 2 && bk == 64) ? 5 : 4;           // the 8-wave 256x128 tile: bf16, default ring only
+    const bool n80 = sizeof(T) == 4 && n80_ok(a);
+    const int ntile = n80 ? 8 : ((sizeof(T) == 2 && bk == 64) ? 5 : 4);           // the 8-wave 256x128 tile: bf16, default ring only
     const int ksteps = cdiv(a.K, bk);
     const size_t out_elems = (size_t)a.M * (size_t)std::max<long>(a.ldc, a.N);
     size_t ws_max = 0;
@@ -511,11 +740,12 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
         float ms = 0.f; CB_HIP(hipEventElapsedTime(&ms, e0, e1));
         return (double)ms * 1e3 / 5.0;
     };
-    const Plan model = make_plan(a, bk, speed);
+    const Plan model = make_plan(a, bk, speed, n80);
     const double t_model = (model.splitk <= 1 || (size_t)model.splitk * a.M * a.N * sizeof(float) <= ws_max) ? time_plan(model) : -1.0;
     double best = 1e30; Plan bp = model;
     for (int ti = 0; ti < ntile; ++ti) {
         const int BM = tiles[ti][0], BN = tiles[ti][1];
+        if (BM == 256 && !(sizeof(T) == 2 && bk == 64)) continue;
         if ((BM >= 128 && a.M <= 64) || (BN == 128 && a.N <= 64) || (BM == 256 && a.M <= 128)) continue;
         for (int sp : splits) {
             if (sp > 1 && ksteps / sp < 2) break;
@@ -563,6 +793,15 @@ template <> void launch_problem<float>(hipStream_t s, const GemmArgs& a, const P
     }
 }
 
+// CB_GEMM_LOG=<file>: one "<plan_key> <BM> <BN> <split>" line per problem handed to the LDS-DMA kernels, dry contexts included — the
+// launch histogram of a step without a GPU (tools/gemm_histogram.py joins it with the autotune records' measured times).
+static void gemm_log(const GemmArgs& a, const Plan& pl, int bk) {
+    static FILE* f = [] { const char* p = getenv("CB_GEMM_LOG"); return (p && *p) ? fopen(p, "a") : (FILE*)nullptr; }();
+    if (!f) return;
+    fprintf(f, "%s %d %d %d\n", plan_key(a, bk).c_str(), pl.BM, pl.BN, pl.splitk);
+    fflush(f);
+}
+
 // returns false (nothing launched, nothing counted) when the problem is not eligible
 bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     if (!gemm_f32_glds_shape_ok(a)) return false;
@@ -573,9 +812,10 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
         CB_CHECK(!(a.g.up && a.g.tr), CB_ERR_ARG, "conv: up and tr are exclusive");
     }
     const int bk = f32_glds_bk();
-    Plan pl = make_plan(a, bk, f32_glds_speed());
+    Plan pl = make_plan(a, bk, f32_glds_speed(), n80_ok(a));
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
     L.count(pl.splitk > 1 ? 2 : 1);
+    gemm_log(a, pl, bk);
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
         CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
@@ -604,7 +844,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
     CB_HIP(hipGetLastError());
     if (prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_glds_kernel<float,%d,%d,%s>", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        snprintf(nm, sizeof nm, "gemm_glds%s_kernel<float,%d,%d,%s>", pl.BN == 80 ? "80" : "", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }

@@ -206,7 +206,7 @@ struct Plan { int BM, BN, tiles_m, tiles_n, splitk, k_per_split; };
 //   CB_PLAN_MINK       fewest k-tiles a split may get
 //   CB_PLAN_EFF        relative MFMA efficiency of the 128x128,128x64,64x128,64x64 tiles
 //   CB_PLAN_BF16_SPEED how many times faster than the fp32 kernel the bf16 kernel retires MACs (scales the MFMA term only)
-struct PlanKnobs { double splitk_cost, traffic, block_ovh; int mink; double eff[4]; double bf16_speed; };
+struct PlanKnobs { double splitk_cost, traffic, block_ovh; int mink; double eff[4]; double bf16_speed; double eff80 = 0.70; };
 inline const PlanKnobs& plan_knobs() {
     static const PlanKnobs k = [] {
         PlanKnobs k{0.25e6, 0.41, 0.0, 4, {1.0, 0.80, 0.80, 0.58}, 6.0};
@@ -216,6 +216,7 @@ inline const PlanKnobs& plan_knobs() {
         if (const char* e = getenv("CB_PLAN_MINK")) k.mink = atoi(e) > 0 ? atoi(e) : 1;
         if (const char* e = getenv("CB_PLAN_EFF")) sscanf(e, "%lf,%lf,%lf,%lf", &k.eff[0], &k.eff[1], &k.eff[2], &k.eff[3]);
         if (const char* e = getenv("CB_PLAN_BF16_SPEED")) k.bf16_speed = atof(e) > 0 ? atof(e) : 6.0;
+        if (const char* e = getenv("CB_PLAN_EFF80")) k.eff80 = atof(e) > 0 ? atof(e) : 0.70;
         return k;
     }();
     return k;
@@ -240,7 +241,10 @@ inline void plan_table_parse(std::unordered_map<std::string, PlanEntry>& t, cons
         const char* e = strchr(p, '\n');
         std::string line(p, e ? (size_t)(e - p) : strlen(p));
         char key[160]; int bm, bn, sp;
-        if (sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && ((bm == 64 || bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (bm != 256 || bn == 128)) && sp >= 1)
+        const bool ok = sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && sp >= 1;
+        const bool pow2 = (bm == 64 || bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (bm != 256 || bn == 128);
+        const bool n80 = bn == 80 && (bm == 16 || bm == 32 || bm == 64);          // fp32 80-column tiles (cb_gemm_glds.hip)
+        if (ok && (pow2 || n80))
             t[key] = PlanEntry{bm, bn, sp};
         if (!e) break;
         p = e + 1;
@@ -275,34 +279,37 @@ inline PlanForce& plan_force() {
     return f;
 }
 // bke = elements of k per tile (16 for fp32, 32 for bf16); speed = MFMA rate relative to the fp32 kernel
-inline Plan make_plan(const GemmArgs& a, int bke, double speed) {
+// n80: the caller can run the fp32 80-column tiles (64 / 32 / 16 rows x 80 columns, k-groups inside the block) on this problem
+inline Plan make_plan(const GemmArgs& a, int bke, double speed, bool n80 = false) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
     // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
     // the fifth shape (8-wave 256x128 tile of the bf16 LDS-DMA kernel) is never chosen by the model: only a measured table entry
     // or cb_debug_force_plan selects it
-    static const int tiles[5][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}};
+    static const int tiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}};
     const PlanKnobs& kn = plan_knobs();
-    const double eff[5] = {kn.eff[0], kn.eff[1], kn.eff[2], kn.eff[3], 1.0};
+    const double eff[8] = {kn.eff[0], kn.eff[1], kn.eff[2], kn.eff[3], 1.0, kn.eff80, kn.eff80, kn.eff80};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const int ksteps = cdiv(a.K, bke);
     double best = 1e300;
     Plan pl{128, 128, 1, 1, 1, ksteps * bke};
-    if (!plan_force().BM && !plan_force().split) {
+    PlanForce pf = plan_force();
+    if (pf.BN == 80 && !n80) pf = PlanForce{};                      // a pinned 80-column tile only binds the problems that can run it
+    if (!pf.BM && !pf.split) {
         const auto& tab = plan_table();
         if (!tab.empty()) {
             auto it = tab.find(plan_key(a, bke));
-            if (it != tab.end() && it->second.split <= ksteps) {
+            if (it != tab.end() && it->second.split <= ksteps && (it->second.BN != 80 || n80)) {
                 const PlanEntry& e = it->second;
                 const int kps = cdiv(ksteps, e.split) * bke;
                 return Plan{e.BM, e.BN, (int)cdiv(a.M, e.BM), (int)cdiv(a.N, e.BN), (int)cdiv(a.K, kps), kps};
             }
         }
     }
-    for (int t = 0; t < 5; ++t) {
+    for (int t = 0; t < 8; ++t) {
         const int BM = tiles[t][0], BN = tiles[t][1];
-        const PlanForce& pf = plan_force();
         if (t == 4 && pf.BM != 256) continue;
+        if (t > 4 && !n80) continue;
         if (pf.BM && (pf.BM != BM || pf.BN != BN)) continue;
         if (!pf.BM && BM == 128 && a.M <= 64) continue;
         if (!pf.BM && BN == 128 && a.N <= 64) continue;

@@ -33,6 +33,9 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # (summation order inside 1.7 TFLOP of fp32 convolutions). AdamW turns that into weight differences of order lr on the
             # elements whose gradient is round-off sized; this trajectory shows how fast ANY fp32 evaluation with such an error separates.
             fp32pert=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1_pert.pt", grad_steps=(), slim=True, grad_noise=4e-5),
+            # BASELINE config 2's own length (aigc_id.yaml:135 max_steps: 800): the `fp32` run continued to 800 optimiser steps (≈ 2 h on 8 host
+            # threads); its first 100 steps are the `fp32` fixture's. slim800 keeps loss, step coefficients and dictionary rows per step.
+            fp32long=dict(B=1, steps=800, lr=5e-3, seed=8, out="horizon_sd14_b1_800.pt", grad_steps=(), slim=True),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 

@@ -191,6 +191,74 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
                 close(tag + f".dgrad4x4(beta={beta})", dx.permute(0, 3, 1, 2), dx_ref + beta * dx0.permute(0, 3, 1, 2), 2e-5)
 
 
+# ------------------------------------------------------------------------------------------------ the 80-column tiles
+# cb_gemm_glds.hip::gemm_glds80_kernel (BM = 64 / 32 / 16 rows x 80 columns, 1 / 2 / 4 k-groups inside the block), pinned through
+# cb_debug_force_plan; `split` > 1 adds the cross-block split-K on top. Same references and tolerance as the planner's own tiles.
+@pytest.mark.parametrize("bm", [64, 32, 16])
+@pytest.mark.parametrize("M,N,K,extra,split", [
+    (4096, 320, 320, "bias+res", 1),       # the 64x64-level Linear: 64 x 4 = 256 blocks at BM = 64
+    (256, 1280, 1280, "bias", 1),          # the 16x16 level: 16 x 16 blocks at BM = 16
+    (77, 200, 96, "alpha", 1),             # ragged rows / columns (200 = 2.5 tiles), 3 k-tiles: fewer than k-groups at BM = 16
+    (130, 88, 52, "beta", 1),              # K = 52: one full and one partial k-tile
+    (64, 1280, 2560, "bias", 4),           # 8x8 level: k-groups inside the block AND a split-K over blocks
+    (300, 84, 4, "none", 1),               # a single 16-byte chunk of K
+])
+def test_gemm_n80_tiles(cb, bm, M, N, K, extra, split):
+    lib, ctx = cb
+    lib.check(lib.load().cb_debug_force_plan(bm, 80, split))
+    try:
+        test_gemm(cb, M, N, K, 0, 0, 1, extra)
+    finally:
+        lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+    key = f"gemm[{M}x{N}x{K},a0b0,batch1,{extra}]"
+    REPORT[f"n80.{bm}/{split}." + key] = REPORT.pop(key)
+
+
+@pytest.mark.parametrize("bm", [64, 32, 16])
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,mode,extra,split", [
+    (1, 64, 64, 320, 320, 3, "same", "none", 1),        # level-0 ResBlock conv: k-groups start in the middle of a tap at BM = 16 / 32
+    (2, 16, 16, 32, 64, 3, "same", "rowbias+res", 1),   # one k-tile per tap, Cout = 64 < 80
+    (1, 8, 8, 1280, 1280, 3, "same", "none", 3),        # 8x8 level with a split-K over blocks on top
+    (2, 16, 16, 32, 160, 3, "down", "none", 1),         # stride 2
+    (2, 16, 16, 64, 96, 1, "same", "none", 1),          # 1x1
+])
+def test_conv_n80_tiles(cb, bm, N, H, W, Cin, Cout, ks, mode, extra, split):
+    lib, ctx = cb
+    lib.check(lib.load().cb_debug_force_plan(bm, 80, split))
+    try:
+        test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra)
+    finally:
+        lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+
+
+def test_n80_counted_wait_matches_safe_mode(cb):
+    """the 80-column kernel shares the counted `s_waitcnt vmcnt(N)` + raw `s_barrier` ring of the LDS-DMA GEMM: with
+    cb_debug_glds_safe(1) (queue drained + full barrier per k-tile) the results must be the same BIT FOR BIT"""
+    lib, ctx = cb
+    L = lib.load()
+    outs = {}
+    try:
+        for safe in (0, 1):
+            lib.check(L.cb_debug_glds_safe(safe))
+            for bm in (64, 32, 16):
+                lib.check(L.cb_debug_force_plan(bm, 80, 1))
+                for (M, N, K) in [(4096, 320, 2560), (1024, 640, 640), (256, 1280, 5120), (77, 200, 96)]:
+                    A = rnd(1, M, K, seed=M + 1).to(_dev()); B = rnd(1, N, K, seed=N + 2).to(_dev())
+                    Cd = torch.zeros(M, N, device=_dev())
+                    d = lib.GemmDesc()
+                    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cd.data_ptr()
+                    d.M, d.N, d.K = M, N, K
+                    d.lda = d.ldb = K; d.ldc = N; d.batch = 1; d.alpha = 1.0
+                    lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+                    ctx.sync()
+                    outs[(safe, bm, M, N, K)] = Cd.cpu()
+    finally:
+        lib.check(L.cb_debug_glds_safe(0)); lib.check(L.cb_debug_force_plan(0, 0, 0))
+    for (safe, bm, M, N, K), v in outs.items():
+        if safe == 0:
+            assert v.abs().max() > 0 and torch.equal(v, outs[(1, bm, M, N, K)]), (bm, M, N, K)
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("N,HW,C,silu,eps", [(2, 64, 320, 1, 1e-5), (1, 4096, 320, 1, 1e-5), (2, 100, 64, 0, 1e-6),
                                              (1, 64, 2560, 1, 1e-5), (1, 5000, 128, 1, 1e-6), (2, 256, 960, 0, 1e-6),

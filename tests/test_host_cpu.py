@@ -494,6 +494,41 @@ x.hip:9:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-reso
     assert set(build.NO_SCRATCH) == {"cb_gemm_glds.hip", "cb_flash_bf16_v2.hip"}
 
 
+def test_four_ranks_against_a_deleted_build_dir_compile_once(tmp_path):
+    """N ranks importing the package against a missing library all call build(): the flock in celebbasis_amd/build.py lets one of them
+    compile while the others wait and then find everything up to date. Four processes start together against an empty build directory
+    with a stub compiler that logs every invocation: each source is compiled exactly once, the library is linked exactly once."""
+    stub = tmp_path / "hipcc_stub.py"
+    stub.write_text("""#!/usr/bin/env python3
+import os, sys, time
+a = sys.argv[1:]
+out = a[a.index('-o') + 1]
+with open(os.environ['STUB_LOG'], 'a') as f:
+    f.write(('link ' if '-shared' in a else 'cc ') + os.path.basename(out) + '\\n')
+time.sleep(0.15)
+if '-Rpass-analysis=kernel-resource-usage' in a:
+    sys.stderr.write('x.hip:1:1: remark: Function Name: gemm_glds_stub [-Rpass]\\nx.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\\n')
+open(out, 'w').write('stub')
+""")
+    stub.chmod(0o755)
+    rank = tmp_path / "rank.py"
+    rank.write_text(f"""import os, sys
+sys.path.insert(0, {ROOT!r})
+from celebbasis_amd import build
+build.BUILD = {str(tmp_path / '_build')!r}; build.LIB = {str(tmp_path / 'lib.so')!r}
+print(build.build(verbose=False))
+""")
+    env = dict(os.environ, HIPCC=str(stub), STUB_LOG=str(tmp_path / "log.txt"))
+    procs = [subprocess.Popen([sys.executable, str(rank)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True) for _ in range(4)]
+    outs = [p.communicate(timeout=120) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-400:] for o in outs]
+    assert all(o[0].strip().endswith("lib.so") for o in outs)
+    from celebbasis_amd import build
+    log = (tmp_path / "log.txt").read_text().split("\n")
+    assert sum(l.startswith("link ") for l in log) == 1, log
+    assert len([l for l in log if l.startswith("cc ") and "probe" not in l]) == len(build.SOURCES), log
+
+
 def test_bench_uses_committed_profiles_only_when_their_stamp_is_this_tree(tmp_path, monkeypatch):
     """bench.py quotes rocprofv3 / PMC numbers from profiles/ only if they were measured on the running tree (stamp = sha of the kernel
     sources + plan table); anything else is `profile_stale` and contributes nothing to the line"""
@@ -698,8 +733,9 @@ def test_argument_errors_on_a_dry_context(built_lib):
 
 def test_plan_table_is_well_formed(tmp_path):
     """celebbasis_amd/csrc/cb_plan_table.inc (generated by tools/make_plan_table.py from offline autotune records): every entry parses
-    as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (256x128 only for the bf16 64-element k-tile),
-    and the generator reproduces the committed table from the committed records (profiles/r02_autotune.txt)"""
+    as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (256x128 only for the bf16 64-element k-tile,
+    the 80-column tiles only for fp32 ROW / plain-conv problems without a batch), and the generator reproduces the committed table
+    from the committed records (round 4's fp32 re-measurement + the records carried over from round 2)"""
     import subprocess
     import sys
     inc = os.path.join(ROOT, "celebbasis_amd", "csrc", "cb_plan_table.inc")
@@ -713,15 +749,17 @@ def test_plan_table_is_well_formed(tmp_path):
         assert len(f) == 8 and key not in keys, key
         keys.add(key)
         bm, bn, sp = int(bm), int(bn), int(sp)
-        assert (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64), (256, 128)) and sp >= 1
+        assert (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64), (256, 128), (64, 80), (32, 80), (16, 80)) and sp >= 1
+        if bn == 80:                                      # fp32 (dtype 0), k-tile 32, ROW (0) or conv (2) without upsample / transposed flags, batch 1
+            assert f[0] == "32" and f[1] == "0" and f[2] in ("0", "2") and f[6] == "1" and (int(f[7]) & 3) == 0
         if bm == 256:
             assert f[0] == "64" and f[1] == "1"          # the 8-wave tile exists for bf16 (dtype code 1), 64-element k-tiles only
         assert -(-int(f[5]) // int(f[0])) >= sp           # never more splits than k-tiles
     before = open(inc).read()
     try:
-        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py"), os.path.join(ROOT, "profiles", "r02_autotune.txt")],
-                             capture_output=True, text=True, check=True).stdout
-        assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of profiles/r02_autotune.txt"
+        recs = [os.path.join(ROOT, "profiles", n) for n in ("r04_autotune_f32.txt", "r04_autotune_carried_from_r02.txt")]
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py")] + recs, capture_output=True, text=True, check=True).stdout
+        assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of the committed records"
     finally:
         open(inc, "w").write(before)
 
