@@ -243,8 +243,13 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
 // one tile (past the end of K the lanes are out of range and the DMA writes zeros into a slot nobody reads), so the number of
 // outstanding DMA instructions is constant and "tile t has landed" is the counted wait vmcnt((STAGES-2) * loads per tile)
 // followed by a raw s_barrier (a __syncthreads() would drain the whole queue with vmcnt(0)).
-template <typename T, int BM, int BN, int AK, int RB, int STAGES, int NTHR = 256>
+// FAST (two-stage rings, K a whole number of k-tiles, not the general gather): the k advance rides in the buffer instruction's SCALAR
+// offset — excluded from the hardware range check, so the 0xFFFFFFF0 lanes of out-of-range rows keep reading zeros — and the conv
+// gather's per-lane validity is re-evaluated only when the tap changes: a DMA piece then costs no vector instruction (5 before), and
+// with fp32 MFMAs every VALU instruction of the k loop is matrix-pipe time lost (profiles/r04_pmc_n80.txt, README round 4).
+template <typename T, int BM, int BN, int AK, int RB, int STAGES, int NTHR = 256, bool FAST = false>
 __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
+    static_assert(!FAST || (STAGES == 2 && AK != AK_CONV), "FAST: vmcnt(0) rings, ROW or plain-conv A operand");
     constexpr int ESZ = El<T>::ESZ;
     using G = GGeo<RB, ESZ>;
     using Frag = typename El<T>::Frag;
@@ -284,7 +289,14 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     for (int i = 0; i < NA; ++i) kca[i] = G::chunk(tid + i * NTHR) * G::EPC;
 #pragma unroll
     for (int i = 0; i < NB; ++i) kcb[i] = G::chunk(tid + i * NTHR) * G::EPC;
-    const __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    // FAST conv: the range check sees voffset alone, so the most negative row base (pad up and left of image 0) moves into the descriptor
+    const int abias = (FAST && AK == AK_CONVF) ? (a.g.pad * a.g.W + a.g.pad) * a.g.C * ESZ : 0;
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(reinterpret_cast<const char*>(Ap) - abias), srdB = make_srd(Bp);
+    int a_vo[NA];                                     // FAST conv: the slot's current voffset = valid(tap) ? base + bias : OOB
+    if constexpr (FAST && AK == AK_CONVF) {
+#pragma unroll
+        for (int i = 0; i < NA; ++i) a_vo[i] = ((cf.vmask[i] >> tap_u) & 1u) ? cf.base[i] + abias : OOB;
+    }
     constexpr int A_BUF = BM * RB, B_BUF = BN * RB;
     char* const As = lds;
     char* const Bs = lds + STAGES * A_BUF;
@@ -292,6 +304,31 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
 
     auto issue = [&](int k0, int buf) {
+        if constexpr (FAST) {
+            char* ad = As + buf * A_BUF + wbase;
+            char* bd = Bs + buf * B_BUF + wbase;
+            if constexpr (AK == AK_ROW) {
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, ra.off[i], k0 * ESZ, 0, 0);
+            } else {
+                const int ky = conv_tap_row(tap_u, a.g.ks), kx = tap_u - ky * a.g.ks;
+                const int delta = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
+#pragma unroll
+                for (int i = 0; i < NA; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, a_vo[i], delta, 0, 0);
+                ci_u += BKT;
+                if (ci_u >= a.g.C) {
+                    ci_u -= a.g.C; ++tap_u;
+#pragma unroll
+                    for (int i = 0; i < NA; ++i) a_vo[i] = ((cf.vmask[i] >> (tap_u & 31)) & 1u) ? cf.base[i] + abias : OOB;
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < NB; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(bd + i * (NTHR * 16)), 16, rb.off[i], k0 * ESZ, 0, 0);
+            return;
+        }
         int oa[NA], ob[NB];
         if constexpr (AK == AK_ROW) {
 #pragma unroll
@@ -332,7 +369,8 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
         // (tests/test_gpu_ops.py::test_glds_counted_wait_matches_safe_mode).
         if (p.safe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
         else { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory"); __builtin_amdgcn_s_barrier(); }
-        issue(k0 + (STAGES - 1) * BKT, nxt);
+        // (FAST has no per-lane k limit: the tile past the end of K is not issued; its ring wait is vmcnt(0), nothing counts pieces)
+        if (!FAST || k0 + (STAGES - 1) * BKT < kend) issue(k0 + (STAGES - 1) * BKT, nxt);
         const char* arow = As + cur * A_BUF + (wm * (BM / WM) + ml) * RB;
         const char* brow = Bs + cur * B_BUF + (wn * (BN / 2) + ml) * RB;
 #pragma unroll
@@ -376,11 +414,11 @@ __global__ __launch_bounds__(512) void gemm_glds256_kernel(const KArgs p) {
 }
 constexpr int GLDS256_LDS = 3 * (256 + 128) * 128;
 
-template <typename T, int BM, int BN, int AK, int RB, int STAGES>
+template <typename T, int BM, int BN, int AK, int RB, int STAGES, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_glds_kernel(const KArgs p) {
     constexpr int RING = STAGES * (BM + BN) * RB, CTILE = BM * BN * 4;        // the epilogue parks the fp32 output tile in the ring
     __shared__ __attribute__((aligned(16))) char lds[RING > CTILE ? RING : CTILE];
-    gemm_glds_body<T, BM, BN, AK, RB, STAGES>(p, lds);
+    gemm_glds_body<T, BM, BN, AK, RB, STAGES, 256, FAST>(p, lds);
 }
 
 
@@ -405,7 +443,11 @@ template <int BM, int STAGES> struct G80 {
     static_assert(64 * SLD * 4 <= LDS, "the epilogue parks KW x BM x 80 fp32 partials in the ring");
 };
 
-template <int BM, int AK, int STAGES>
+// FAST: every k-group of every split owns the same whole number of k-tiles (host: (k range) % (32 * KW) == 0 — all SD v1-4 shapes at
+// BM = 64 / 32, most at 16). The k advance of a ROW operand then rides in the buffer instruction's SCALAR offset (excluded from the
+// range check, so the 0xFFFFFFF0 lanes of out-of-range rows still read zeros) and a piece costs no VALU at all: with fp32 MFMAs every
+// vector instruction in the k loop is matrix-pipe time lost (profiles/r04_pmc_n80.txt: 30 - 50 VALU per 40 MFMAs before this).
+template <int BM, int AK, int STAGES, bool FAST>
 __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
     using Q = G80<BM, STAGES>;
     using G = GGeo<128, 4>;
@@ -470,8 +512,14 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         b_klim[i] = ok ? kge - kg0 - lc : 0;
         b_off[i] = ok ? (int)(((long)(n0 + r) * a.ldb + kg0 + lc) * 4) : OOB;
     }
-    const __amdgpu_buffer_rsrc_t srdA = make_srd(Ap), srdB = make_srd(Bp);
+    // FAST conv gather: voffset = the row's (tap-independent) base, soffset = the tap / channel walk. The range check sees voffset alone,
+    // so it must not be negative for a valid lane: the most negative base (row 0, pad up and left) is folded into the descriptor's base.
+    const int abias = (FAST && AK != AK_ROW) ? (a.g.pad * a.g.W + a.g.pad) * a.g.C * 4 : 0;
+    const __amdgpu_buffer_rsrc_t srdA = make_srd(reinterpret_cast<const char*>(Ap) - abias), srdB = make_srd(Bp);
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
+    int a_vo[NA];                                            // FAST conv: current voffset of the slot = valid(tap) ? base + bias : OOB
+#pragma unroll
+    for (int i = 0; i < NA; ++i) a_vo[i] = ((a_vmask[i] >> (a_tap[i] & 31)) & 1u) ? a_off[i] + abias : OOB;
 
     // one LDS-DMA piece (slot `pc`: A slots first, then B) of k-tile kt -> ring slot `stage`
     auto piece = [&](int pc, int kt, char* stage) {
@@ -479,8 +527,21 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         if (pc < NA) {
             const int i = pc;
             int oa;
-            if constexpr (AK == AK_ROW) oa = (a_off[i] != OOB && ko < a_klim[i]) ? a_off[i] + ko * 4 : OOB;
-            else {
+            if constexpr (AK == AK_ROW && FAST) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, a_off[i], ko * 4, 0, 0);
+                return;
+            } else if constexpr (AK == AK_ROW) oa = (a_off[i] != OOB && ko < a_klim[i]) ? a_off[i] + ko * 4 : OOB;
+            else if constexpr (FAST) {
+                const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
+                const int delta = ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;                 // scalar: the k-group is wave-uniform
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, a_vo[i], delta, 0, 0);
+                a_ci[i] += BKT;
+                if (a_ci[i] >= a.g.C) {                                                      // next tap: the only vector work of the walk
+                    a_ci[i] -= a.g.C; ++a_tap[i];
+                    a_vo[i] = ((a_vmask[i] >> (a_tap[i] & 31)) & 1u) ? a_off[i] + abias : OOB;
+                }
+                return;
+            } else {
                 const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
                 const int delta = ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;
                 oa = (ko < a_klim[i] && ((a_vmask[i] >> (a_tap[i] & 31)) & 1u)) ? a_off[i] + delta : OOB;
@@ -490,6 +551,10 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, oa, 0, 0, 0);
         } else {
             const int i = pc - NA;
+            if constexpr (FAST) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(stage + Q::A_BUF + wbase + i * 4096), 16, b_off[i], ko * 4, 0, 0);
+                return;
+            }
             const int ob = (ko < b_klim[i]) ? b_off[i] + ko * 4 : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(srdB, (lds_ptr_t)(stage + Q::A_BUF + wbase + i * 4096), 16, ob, 0, 0, 0);
         }
@@ -513,8 +578,13 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         else { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory"); __builtin_amdgcn_s_barrier(); }
         const char* st = lds80 + cur * Q::STAGE;
         // the next tile's pieces go out in one clump: spreading them between the MFMAs was measured and changes nothing (profiles/README.md, round 4)
+        // (FAST has no per-lane k limit: the tile past the group's end is simply not issued — with two stages the wait above is vmcnt(0),
+        // nothing counts on a constant number of outstanding pieces)
+        static_assert(!FAST || STAGES == 2, "FAST skips the tail issue: only valid when the ring wait is vmcnt(0)");
+        if (!FAST || kt + STAGES - 1 < ktg) {
 #pragma unroll
-        for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + STAGES - 1, lds80 + nxt * Q::STAGE);
+            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + STAGES - 1, lds80 + nxt * Q::STAGE);
+        }
         // all twelve fragment reads of the k-tile first (chunk 4s + lg is the lane's k-slot quadruple of half tile s), then the 40 MFMAs:
         // with one wave per SIMD nobody else covers the LDS latency, so it is paid once per k-tile instead of once per half tile
         f32x4a av[2], bv[2][5];
@@ -579,10 +649,10 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
     }
 }
 // (the body lives in a __device__ function: target builtins used directly inside a __global__ template make the HOST pass drop the stub)
-template <int BM, int AK, int STAGES>
+template <int BM, int AK, int STAGES, bool FAST>
 __global__ __launch_bounds__(256) void gemm_glds80_kernel(const KArgs p) {
     extern __shared__ __attribute__((aligned(16))) char lds80_dyn[];
-    gemm_glds80_body<BM, AK, STAGES>(p, lds80_dyn);
+    gemm_glds80_body<BM, AK, STAGES, FAST>(p, lds80_dyn);
 }
 
 // ---------------------------------------------------------------- host side
@@ -601,8 +671,23 @@ static const GVariant& gvariant() {
     return v;
 }
 static int bf16_bk() { return gvariant().rb / 2; }
+template <typename T, int AK, int RB, int ST, bool FAST>
+static void launch_glds_go(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 128, AK, RB, ST, FAST>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 64, AK, RB, ST, FAST>), grid, dim3(256), 0, s, ka);
+    else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 64, 128, AK, RB, ST, FAST>), grid, dim3(256), 0, s, ka);
+    else hipLaunchKernelGGL((gemm_glds_kernel<T, 64, 64, AK, RB, ST, FAST>), grid, dim3(256), 0, s, ka);
+}
+static bool glds_fast_on() {
+    static const bool on = [] { const char* e = getenv("CB_GLDS_FAST"); return !(e && e[0] == '0'); }();
+    return on;
+}
 template <typename T, int AK, int RB, int ST>
 static void launch_glds(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
+    if constexpr (ST == 2 && RB == 128 && AK != AK_CONV) {        // the default ring only: the experiment variants keep the per-lane path
+        constexpr int BK = RB / (int)sizeof(T);
+        if (glds_fast_on() && !ka.safe && ka.a.K % BK == 0) { launch_glds_go<T, AK, RB, ST, true>(pl, grid, s, ka); return; }
+    }
     if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 128, AK, RB, ST>), grid, dim3(256), 0, s, ka);
     else if (pl.BM == 128 && pl.BN == 64) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 64, AK, RB, ST>), grid, dim3(256), 0, s, ka);
     else if (pl.BM == 64 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 64, 128, AK, RB, ST>), grid, dim3(256), 0, s, ka);
@@ -668,11 +753,19 @@ size_t gemm_f32_glds_ws_bytes(const GemmArgs& a) {
     return pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
 }
 // the 80-column tiles: dynamic LDS (40 / 56 / 96 KB for BM = 64 / 32 / 16), two ring stages (three were measured slower: fewer blocks per CU)
+template <int BM, int AK, bool FAST>
+static void launch_n80_go(dim3 grid, hipStream_t s, const KArgs& ka) {
+    constexpr int LDS = G80<BM, 2>::LDS;
+    set_dyn_lds(reinterpret_cast<const void*>(&gemm_glds80_kernel<BM, AK, 2, FAST>), LDS);
+    hipLaunchKernelGGL((gemm_glds80_kernel<BM, AK, 2, FAST>), grid, dim3(256), LDS, s, ka);
+}
 template <int BM, int AK>
 static void launch_n80_one(dim3 grid, hipStream_t s, const KArgs& ka) {
-    constexpr int LDS = G80<BM, 2>::LDS;
-    set_dyn_lds(reinterpret_cast<const void*>(&gemm_glds80_kernel<BM, AK, 2>), LDS);
-    hipLaunchKernelGGL((gemm_glds80_kernel<BM, AK, 2>), grid, dim3(256), LDS, s, ka);
+    // FAST: every split's k range is a whole number of k-tiles per k-group (the last split included)
+    static const bool allow = [] { const char* e = getenv("CB_N80_FAST"); return !(e && e[0] == '0'); }();
+    const int unit = 32 * (64 / BM), last = ka.a.K - (ka.splitk - 1) * ka.k_per_split;
+    if (allow && ka.k_per_split % unit == 0 && last % unit == 0 && !ka.safe) launch_n80_go<BM, AK, true>(grid, s, ka);
+    else launch_n80_go<BM, AK, false>(grid, s, ka);
 }
 template <int AK>
 static void launch_n80(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {

@@ -522,6 +522,21 @@ def gen_step(manifest):
     The one piece that is NOT reference code is the CLIP layer stack (the reference wrapper cannot be imported offline, SURVEY
     C-5): the oracle's restatement, wired at the reference's hook point (token embedding -> manager -> + positions, layers).
     Two runs: the default MLP path (3 steps) and `use_rm_mlp` (2 steps, incl. the reference's flatten(ids) pairing)."""
+    out, run = step_harness()
+    run(False, 3, 3, lambda s_: torch.tensor([[1, 1], [2, 2]]), "mlp")
+    run(True, 2, 10, lambda s_: torch.tensor([[1, 1], [2, 2]]) if s_ == 0 else torch.tensor([[4, 4], [4, 4]]), "rm_mlp")
+    torch.save(out, os.path.join(OUT, "step_mini.pt"))
+    manifest["step_mini.pt"] = ("ldm/models/diffusion/ddpm.py LatentDiffusion.forward:926-936, get_learned_conditioning:599-611, p_losses:1069-1116, "
+                                "apply_model:948-1049, DDPM.register_schedule:126-178, q_sample:289-292, get_loss:294-307, DiffusionWrapper.forward:"
+                                "1537-1556, torch.optim.AdamW as configure_optimizers:1442-1454 — over the reference UNetModel, Encoder, "
+                                "DiagonalGaussianDistribution, EmbeddingManagerId / MetaIdNet (default and use_rm_mlp); CLIP layers = oracle restatement")
+
+
+def step_harness():
+    """the reference's composed training step on stand-in objects (see gen_step): returns (out, run) where
+    run(use_rm_mlp, K, max_ids, ids_of, tag, slim=False, fr_noise=0.0) records a K-step trajectory into out[tag].
+    slim: per step only the loss and the EMA dictionary rows (inputs are re-drawn from their seeds: oracle/replay.py::ref_stream_batch);
+    fr_noise: relative size of seeded noise added to the FR-net's features (sensitivity runs of oracle/gen_horizon_ref.py)."""
     import ldm.modules.id_embedding.meta_net as meta_net
     from ldm.modules.id_embedding.iresnet import IResNet, IBasicBlock
     from ldm.models.diffusion.ddpm import LatentDiffusion, DDPM, DiffusionWrapper
@@ -595,8 +610,12 @@ def gen_step(manifest):
         def device(self):
             return torch.device("cpu")
 
-    def run(use_rm_mlp, K, max_ids, ids_of, tag):
+    def run(use_rm_mlp, K, max_ids, ids_of, tag, slim=False, fr_noise=0.0):
         mgr = make_manager(use_rm_mlp, max_ids)
+        if fr_noise:
+            gn = torch.Generator().manual_seed(4242)
+            mgr.meta_id_net.id_model.register_forward_hook(
+                lambda mod, inp, o: o + fr_noise * o.norm() / (o.numel() ** 0.5) * torch.randn(o.shape, generator=gn))
         g = torch.Generator().manual_seed(81 + int(use_rm_mlp))
         Wm = torch.randn(es * inner, 512, generator=g); bm = 0.1 * torch.randn(es * inner, generator=g)
         with torch.no_grad():
@@ -653,6 +672,11 @@ def gen_step(manifest):
             opt.step()
             mgr.id_coefficients = [c.detach() for c in mgr.id_coefficients]                 # cut the EMA's autograd chain (values unchanged)
             mgr.id_embeddings = [e.detach() for e in mgr.id_embeddings]
+            if slim:
+                rec["steps"].append(dict(loss=float(loss.detach()), id_coef=torch.stack([c.reshape(-1) for c in mgr.id_coefficients]).clone()))
+                if (s_ + 1) % 100 == 0:
+                    print(f"[gen_step {tag}] step {s_ + 1}/{K} loss {float(loss):.6f}", flush=True)
+                continue
             rec["steps"].append(dict(image_seed=2000 + 10 * int(use_rm_mlp) + s_, ids=ids, tokens=tokens, t=t, noise=noise, post_noise=post_noise,
                                      loss=loss.detach().clone(), z0=x, grad=gmain if s_ == 0 else None,
                                      loss_simple=loss_dict["train/loss_simple"].detach().clone()))
@@ -663,13 +687,7 @@ def gen_step(manifest):
         rec["id_emb_final"] = torch.stack([e.reshape(-1) for e in mgr.id_embeddings])
         out[tag] = rec
 
-    run(False, 3, 3, lambda s_: torch.tensor([[1, 1], [2, 2]]), "mlp")
-    run(True, 2, 10, lambda s_: torch.tensor([[1, 1], [2, 2]]) if s_ == 0 else torch.tensor([[4, 4], [4, 4]]), "rm_mlp")
-    torch.save(out, os.path.join(OUT, "step_mini.pt"))
-    manifest["step_mini.pt"] = ("ldm/models/diffusion/ddpm.py LatentDiffusion.forward:926-936, get_learned_conditioning:599-611, p_losses:1069-1116, "
-                                "apply_model:948-1049, DDPM.register_schedule:126-178, q_sample:289-292, get_loss:294-307, DiffusionWrapper.forward:"
-                                "1537-1556, torch.optim.AdamW as configure_optimizers:1442-1454 — over the reference UNetModel, Encoder, "
-                                "DiagonalGaussianDistribution, EmbeddingManagerId / MetaIdNet (default and use_rm_mlp); CLIP layers = oracle restatement")
+    return out, run
 
 
 def main():

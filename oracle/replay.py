@@ -14,3 +14,22 @@ def make_batch(B, S, lat, vocab, placeholder, seed, n_ids):
                 ids=torch.stack([torch.tensor([1 + (b % (n_ids - 1))] * 2) for b in range(B)]), tokens=tokens,
                 t=torch.randint(0, 1000, (B,), generator=g), noise=torch.randn(B, 4, lat, lat, generator=g),
                 post_noise=torch.randn(B, 4, lat, lat, generator=g))
+
+
+def ref_stream_batch(s, lat, S=64, B=2):
+    """element s of the replay stream that oracle/gen_golden.py::step_harness feeds the REFERENCE's composed step (the default MLP
+    run): images from seed 2000 + s, posterior noise from manual_seed(900 + s), (t, noise) from manual_seed(1000 + s) in the order
+    LatentDiffusion.forward / p_losses draw them (ddpm.py:926-936, 1069-1075). Uses the global torch RNG like the reference does."""
+    gi = torch.Generator().manual_seed(2000 + s)
+    image = torch.rand(B, S, S, 3, generator=gi) * 2 - 1
+    faces = torch.rand(B, S, S, 6, generator=gi) * 2 - 1
+    tokens = torch.full((B, 77), 49407, dtype=torch.long); tokens[:, 0] = 49406
+    tokens[0, 1:9] = torch.tensor([320, 1125, 539, 320, 1710, 539, 48136, 2533]); tokens[1, 1:5] = torch.tensor([1125, 48136, 1125, 320])
+    torch.manual_seed(900 + s)
+    post_noise = torch.randn(B, 4, lat, lat)
+    torch.manual_seed(1000 + s)
+    # p_losses draws randn_like(x_start), and the reference's latent is channels_last (the encoder is fed a permuted HWC image): the fill
+    # of a non-contiguous tensor walks storage order with the scalar sampler, so the draw has to be made on the same memory format
+    t = torch.randint(0, 1000, (B,)).long()
+    noise = torch.randn_like(torch.empty(B, 4, lat, lat).contiguous(memory_format=torch.channels_last)).contiguous()
+    return dict(image=image, faces=faces, ids=torch.tensor([[1, 1], [2, 2]]), tokens=tokens, t=t, noise=noise, post_noise=post_noise)

@@ -757,7 +757,7 @@ def test_plan_table_is_well_formed(tmp_path):
         assert -(-int(f[5]) // int(f[0])) >= sp           # never more splits than k-tiles
     before = open(inc).read()
     try:
-        recs = [os.path.join(ROOT, "profiles", n) for n in ("r04_autotune_f32.txt", "r04_autotune_carried_from_r02.txt")]
+        recs = [os.path.join(ROOT, "profiles", n) for n in ("r04_autotune.txt", "r04_autotune_carried_from_r02.txt")]
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py")] + recs, capture_output=True, text=True, check=True).stdout
         assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of the committed records"
     finally:
