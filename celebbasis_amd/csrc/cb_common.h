@@ -113,6 +113,10 @@ struct GemmArgs {
     const void* rowbias = nullptr; int rows_per_img = 1; long ld_rowbias = 0;   // ld 0 = N
     const void* R = nullptr; long ldr = 0; long sRb = 0, sRh = 0;
     float alpha = 1.f, beta = 0.f;
+    // LDS-DMA kernels only (the frozen FR backbone, iresnet.py:44-63): v = PReLU(v, prelu[n]) before the store, and a second output
+    // C2[m][n] = c2_scale[n] * v + c2_shift[n] (leading dimension ldc) — the NEXT block's eval BatchNorm of this block's output
+    const float* prelu = nullptr;
+    void* C2 = nullptr; const float* c2_scale = nullptr; const float* c2_shift = nullptr;
     ConvGeom g;
 };
 

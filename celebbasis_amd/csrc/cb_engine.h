@@ -126,7 +126,9 @@ struct Graph {
     void backward();
 
     // ops (forward now, backward pushed on the tape when an input requires grad)
-    Ten* conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias = nullptr, Ten* residual = nullptr, int rowbias_col = 0);
+    // epi (no-grad fp32 layers: the frozen FR backbone): PReLU on the output and / or a second output tensor c2 = scale[c] * y + shift[c]
+    struct ConvEpi { const float* prelu = nullptr; const float* c2_scale = nullptr; const float* c2_shift = nullptr; Ten** c2_out = nullptr; };
+    Ten* conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias = nullptr, Ten* residual = nullptr, int rowbias_col = 0, const ConvEpi* epi = nullptr);
     Ten* linear(Ten* x, const Lin& l, Ten* residual = nullptr);
     Ten* groupnorm(Ten* x, const Norm& nm, bool silu);
     Ten* layernorm(Ten* x, const Norm& nm);

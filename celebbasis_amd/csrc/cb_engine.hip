@@ -320,7 +320,7 @@ void conv_dgrad(Graph* G, const void* dy, const Conv& cv, ConvMode mode, int N, 
     }
 }
 
-Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* residual, int rowbias_col) {
+Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* residual, int rowbias_col, const ConvEpi* epi) {
     CB_CHECK(x->c == cv.cin, CB_ERR_SHAPE, "conv: input has %d channels, weight expects %d", x->c, cv.cin);
     CB_CHECK(x->dt == cv.dt, CB_ERR_ARG, "conv: activation / weight element types differ");
     const int H = x->h, W = x->w;
@@ -340,6 +340,15 @@ Ten* Graph::conv(Ten* x, const Conv& cv, ConvMode mode, Ten* rowbias, Ten* resid
     if (rowbias) { a.rowbias = rowbias->at(rowbias_col); a.ld_rowbias = rowbias->c; a.rows_per_img = Ho * Wo; }   // column view of a wider table
     if (residual) { a.R = residual->p; a.ldr = cv.cout; }
     a.g = g;
+    if (epi) {
+        CB_CHECK(!rg && x->dt == DT_F32, CB_ERR_STATE, "conv: the PReLU / second-output epilogue is a no-grad fp32 path (frozen FR-net)");
+        a.prelu = epi->prelu;
+        if (epi->c2_out) {
+            Ten* y2 = make(x->n, Ho, Wo, cv.cout, false, x->dt);
+            a.C2 = y2->p; a.c2_scale = epi->c2_scale; a.c2_shift = epi->c2_shift;
+            *epi->c2_out = y2;
+        }
+    }
     run_gemm(this, a);
     if (rg) {
         CB_CHECK(!x->rg || cv.wd, CB_ERR_STATE, "conv: dgrad weights were not packed for a layer on the gradient path");

@@ -450,6 +450,7 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     }
     CB_CHECK(a.dt == DT_F32, CB_ERR_ARG, "gemm: the fp32 kernel was handed a bf16 problem");
     if (gemm_f32_glds(L, a, ws, ws_bytes)) return;          // k-contiguous operands: the LDS-DMA kernel (cb_gemm_glds.hip)
+    CB_CHECK(!a.prelu && !a.C2, CB_ERR_ARG, "gemm: the PReLU / second-output epilogue exists on the LDS-DMA kernels only");
     if (a.a_kind == LD_CONV)
         CB_CHECK(a.g.ks == 1 || a.g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d exists on the LDS-DMA kernel only (16-byte aligned operands, C %% 4 == 0)", a.g.ks);
     Plan pl = make_plan(a, BK, 1.0);

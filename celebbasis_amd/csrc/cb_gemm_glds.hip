@@ -173,14 +173,27 @@ __device__ __forceinline__ void glds_finish_piece(const GemmArgs& a, float (&v)[
         if (a.beta != 0.f) { ld8(c, t);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
+        if (a.prelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : a.prelu[col + e] * v[e]; }
         st8(c, v);
+        if (a.C2) {                                                   // second output: the next layer's per-channel affine of this one
+            T* c2 = static_cast<T*>(a.C2) + (long)row * a.ldc + col;
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = a.c2_scale[col + e] * v[e] + a.c2_shift[col + e];
+            if (al16(c2)) st8(c2, w);
+            else for (int e = 0; e < 8; ++e) c2[e] = (T)w[e];
+        }
     } else {
         for (int e = 0; e < 8 && col + e < a.N; ++e) {
             float x = v[e];
             if (rb) x += (float)rb[e];
             if (rr) x += (float)rr[e];
             if (a.beta != 0.f) x += a.beta * (float)c[e];
+            if (a.prelu) x = x > 0.f ? x : a.prelu[col + e] * x;
             c[e] = (T)x;
+            if (a.C2) (static_cast<T*>(a.C2) + (long)row * a.ldc + col)[e] = (T)(a.c2_scale[col + e] * x + a.c2_shift[col + e]);
         }
     }
 }

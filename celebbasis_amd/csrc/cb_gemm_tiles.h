@@ -191,7 +191,9 @@ __global__ void splitk_reduce_kernel(const KArgs p) {
         if (Rb) v += ld1(Rb + zb * a.sRb + zh * a.sRh + (long)row * a.ldr + col);
         T* c = Cb + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col;
         if (a.beta != 0.f) v += a.beta * ld1(c);
+        if (a.prelu) v = v > 0.f ? v : a.prelu[col] * v;
         st1(c, v);
+        if (a.C2) st1(static_cast<T*>(a.C2) + zb * a.sCb + zh * a.sCh + (long)row * a.ldc + col, a.c2_scale[col] * v + a.c2_shift[col]);
     }
 }
 

@@ -431,16 +431,23 @@ void frnet_load(Ctx* ctx, const WTab& wt, const std::string& pre, FrNet* F, cons
     k_channel_affine(ctx->launch(), F->fc.b, fcb, fs_, ft_, nullptr, 1, F->feat);   // b*s + t
 }
 Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
-    Ten* x = G.conv(img, F.conv1, CONV_SAME);
+    // iresnet.py:52-63 IBasicBlock: x -> bn1 -> conv1 -> bn2 -> PReLU -> conv2 -> bn3, + identity. bn2 / bn3 are folded into the conv
+    // weights at load; the PReLU runs in conv1's epilogue; bn1 cannot be folded (the conv pads bn1(x) with zeros, not bn1(0)), so the
+    // conv2 that PRODUCES x also writes the next block's bn1(x) as a second output. Two channel_affine launches are left (100 before).
+    Ten* x = G.conv(img, F.conv1, CONV_SAME);                         // 3-channel gather: register-staged kernel, no fused epilogue
     x = G.channel_affine(x, nullptr, nullptr, F.prelu1);
-    for (const IBlockW& b : F.blocks) {      // iresnet.py:52-63 IBasicBlock
-        Ten* o = G.channel_affine(x, b.bn1_s, b.bn1_b, nullptr);
-        o = G.conv(o, b.c1, CONV_SAME);
-        o = G.channel_affine(o, nullptr, nullptr, b.prelu);
+    Ten* o = F.blocks.empty() ? nullptr : G.channel_affine(x, F.blocks[0].bn1_s, F.blocks[0].bn1_b, nullptr);
+    for (size_t i = 0; i < F.blocks.size(); ++i) {
+        const IBlockW& b = F.blocks[i];
+        Graph::ConvEpi e1; e1.prelu = b.prelu;
+        Ten* h = G.conv(o, b.c1, CONV_SAME, nullptr, nullptr, 0, &e1);
         Ten* idn = b.has_ds ? G.conv(x, b.ds, CONV_S2_1x1) : x;
-        x = G.conv(o, b.c2, b.stride == 2 ? CONV_DOWN : CONV_SAME, nullptr, idn);
+        Graph::ConvEpi e2;                                             // next block's bn1, or the backbone's final bn2
+        const bool last = i + 1 == F.blocks.size();
+        e2.c2_scale = last ? F.bn2_s : F.blocks[i + 1].bn1_s; e2.c2_shift = last ? F.bn2_b : F.blocks[i + 1].bn1_b; e2.c2_out = &o;
+        x = G.conv(h, b.c2, b.stride == 2 ? CONV_DOWN : CONV_SAME, nullptr, idn, 0, &e2);
     }
-    x = G.channel_affine(x, F.bn2_s, F.bn2_b, nullptr);
+    x = F.blocks.empty() ? G.channel_affine(x, F.bn2_s, F.bn2_b, nullptr) : o;
     Ten* flat = G.wrap(x->p, x->n, 1, 1, x->h * x->w * x->c, false, DT_F32);
     Ten* f = G.linear(flat, F.fc);
     G.tap("frnet.features", f);
