@@ -532,7 +532,7 @@ def gen_step(manifest):
                                 "DiagonalGaussianDistribution, EmbeddingManagerId / MetaIdNet (default and use_rm_mlp); CLIP layers = oracle restatement")
 
 
-def step_harness():
+def step_harness(inner=16):
     """the reference's composed training step on stand-in objects (see gen_step): returns (out, run) where
     run(use_rm_mlp, K, max_ids, ids_of, tag, slim=False, fr_noise=0.0) records a K-step trajectory into out[tag].
     slim: per step only the loss and the EMA dictionary rows (inputs are re-drawn from their seeds: oracle/replay.py::ref_stream_batch);
@@ -552,7 +552,7 @@ def step_harness():
     from ldm.modules.embedding_manager import EmbeddingManagerId
 
     ucfg, vcfg, ccfg, frcfg = STEP_UNET, MINI_VAE, STEP_CLIP, MINI_FR
-    es, inner, width, scale = 2, 16, 768, 0.18215
+    es, width, scale = 2, 768, 0.18215                          # inner: 16 in every fixture; 512 (the real head width) in gen_horizon_ref.py --inner 512
     table = O.formula_table(ccfg["vocab"], width)
     tok_of = {"sks": 48136, "ks": 662, "face": 1710}
     lr = 2 * 5e-3                                              # bs * base_lr (main_id_embed.py:778-782)

@@ -30,6 +30,31 @@ K = 800
 NOISE = (("ref", 0.0), ("ref_fr3e-6", 3e-6), ("ref_fr2.5e-5", 2.5e-5), ("ref_fr2e-4", 2e-4))
 
 
+def sensitivity(inner):
+    """--inner N: the same four reference runs with an N-wide head (N = 512: the real head on the mini networks, 1024 learned coefficients
+    per identity): how the distance between two runs of the REFERENCE depends on the size of an FR-feature perturbation when the head has
+    the real number of LeakyReLU kinks. Evidence only (profiles/r04_horizon_ref_w<N>_sensitivity.json), not a fixture."""
+    import json
+    import transformers  # noqa: F401
+    from transformers import CLIPTokenizer, CLIPTextModel  # noqa: F401
+    GG.install_shims()
+    torch.set_num_threads(4)
+    out, run = GG.step_harness(inner=inner)
+    ids = lambda s_: torch.tensor([[1, 1], [2, 2]])
+    for tag, eps in NOISE:
+        run(False, K, 3, ids, tag, slim=True, fr_noise=eps)
+    ref = torch.stack([s["id_coef"] for s in out["ref"]["steps"]])
+    res = dict(inner=inner, steps=K, lr=out["lr"], learned_coefficient_l2_vs_unperturbed_reference={})
+    for tag, eps in NOISE[1:]:
+        d = (torch.stack([s["id_coef"] for s in out[tag]["steps"]]) - ref).norm(dim=2).max(dim=1).values
+        res["learned_coefficient_l2_vs_unperturbed_reference"][tag] = {str(k): float(d[k - 1]) for k in (1, 10, 50, 100, 200, 400, 800)}
+        res["learned_coefficient_l2_vs_unperturbed_reference"][tag]["max"] = float(d.max())
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", f"r04_horizon_ref_w{inner}_sensitivity.json")
+    with open(path, "w") as f:
+        json.dump(res, f, indent=1)
+    print(json.dumps(res, indent=1))
+
+
 def main(only_oracle=False):
     import transformers  # noqa: F401
     from transformers import CLIPTokenizer, CLIPTextModel  # noqa: F401
@@ -84,4 +109,7 @@ def main(only_oracle=False):
 
 
 if __name__ == "__main__":
-    main(only_oracle="--oracle" in sys.argv)
+    if "--inner" in sys.argv:
+        sensitivity(int(sys.argv[sys.argv.index("--inner") + 1]))
+    else:
+        main(only_oracle="--oracle" in sys.argv)
