@@ -306,9 +306,12 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
     const int abias = (FAST && AK == AK_CONVF) ? (a.g.pad * a.g.W + a.g.pad) * a.g.C * ESZ : 0;
     const __amdgpu_buffer_rsrc_t srdA = make_srd(reinterpret_cast<const char*>(Ap) - abias), srdB = make_srd(Bp);
     int a_vo[NA];                                     // FAST conv: the slot's current voffset = valid(tap) ? base + bias : OOB
+    int delta_u = 0;                                  // FAST conv: byte offset of the current (tap, channel), scalar
     if constexpr (FAST && AK == AK_CONVF) {
 #pragma unroll
         for (int i = 0; i < NA; ++i) a_vo[i] = ((cf.vmask[i] >> tap_u) & 1u) ? cf.base[i] + abias : OOB;
+        const int ky = conv_tap_row(tap_u, a.g.ks), kx = tap_u - ky * a.g.ks;
+        delta_u = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
     }
     constexpr int A_BUF = BM * RB, B_BUF = BN * RB;
     char* const As = lds;
@@ -325,14 +328,14 @@ __device__ __forceinline__ void gemm_glds_body(const KArgs& p, char* lds) {
                 for (int i = 0; i < NA; ++i)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, ra.off[i], k0 * ESZ, 0, 0);
             } else {
-                const int ky = conv_tap_row(tap_u, a.g.ks), kx = tap_u - ky * a.g.ks;
-                const int delta = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
 #pragma unroll
                 for (int i = 0; i < NA; ++i)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, a_vo[i], delta, 0, 0);
-                ci_u += BKT;
-                if (ci_u >= a.g.C) {
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(ad + i * (NTHR * 16)), 16, a_vo[i], delta_u, 0, 0);
+                ci_u += BKT; delta_u += BKT * ESZ;                         // the (tap, channel) byte offset walks with the k-tiles ...
+                if (ci_u >= a.g.C) {                                       // ... and is re-derived, like the lanes' validity, only at a tap change
                     ci_u -= a.g.C; ++tap_u;
+                    const int ky = conv_tap_row(tap_u, a.g.ks), kx = tap_u - ky * a.g.ks;
+                    delta_u = ((ky * a.g.W + kx) * a.g.C + ci_u) * ESZ;
 #pragma unroll
                     for (int i = 0; i < NA; ++i) a_vo[i] = ((cf.vmask[i] >> (tap_u & 31)) & 1u) ? cf.base[i] + abias : OOB;
                 }
@@ -530,9 +533,13 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
     const int abias = (FAST && AK != AK_ROW) ? (a.g.pad * a.g.W + a.g.pad) * a.g.C * 4 : 0;
     const __amdgpu_buffer_rsrc_t srdA = make_srd(reinterpret_cast<const char*>(Ap) - abias), srdB = make_srd(Bp);
     const int wbase = __builtin_amdgcn_readfirstlane(wave * 64 * 16);
-    int a_vo[NA];                                            // FAST conv: current voffset of the slot = valid(tap) ? base + bias : OOB
+    int a_vo[NA], a_dl[NA];                                  // FAST conv: current voffset of the slot = valid(tap) ? base + bias : OOB; tap/channel offset
 #pragma unroll
-    for (int i = 0; i < NA; ++i) a_vo[i] = ((a_vmask[i] >> (a_tap[i] & 31)) & 1u) ? a_off[i] + abias : OOB;
+    for (int i = 0; i < NA; ++i) {
+        a_vo[i] = ((a_vmask[i] >> (a_tap[i] & 31)) & 1u) ? a_off[i] + abias : OOB;
+        const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
+        a_dl[i] = (AK == AK_ROW) ? 0 : ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;
+    }
 
     // one LDS-DMA piece (slot `pc`: A slots first, then B) of k-tile kt -> ring slot `stage`
     auto piece = [&](int pc, int kt, char* stage) {
@@ -545,12 +552,14 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
                 return;
             } else if constexpr (AK == AK_ROW) oa = (a_off[i] != OOB && ko < a_klim[i]) ? a_off[i] + ko * 4 : OOB;
             else if constexpr (FAST) {
-                const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
-                const int delta = ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;                 // scalar: the k-group is wave-uniform
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, a_vo[i], delta, 0, 0);
-                a_ci[i] += BKT;
-                if (a_ci[i] >= a.g.C) {                                                      // next tap: the only vector work of the walk
+                // a_dl = byte offset of (tap, channel) — scalar (the k-group is wave-uniform), advanced by one k-tile per piece and
+                // re-derived only when the tap changes, like the per-lane validity: two scalar adds and a compare per tile otherwise
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(srdA, (lds_ptr_t)(stage + wbase + i * 4096), 16, a_vo[i], a_dl[i], 0, 0);
+                a_ci[i] += BKT; a_dl[i] += BKT * 4;
+                if (a_ci[i] >= a.g.C) {
                     a_ci[i] -= a.g.C; ++a_tap[i];
+                    const int ky = conv_tap_row(a_tap[i], a.g.ks), kx = a_tap[i] - ky * a.g.ks;
+                    a_dl[i] = ((ky * a.g.W + kx) * a.g.C + a_ci[i]) * 4;
                     a_vo[i] = ((a_vmask[i] >> (a_tap[i] & 31)) & 1u) ? a_off[i] + abias : OOB;
                 }
                 return;
