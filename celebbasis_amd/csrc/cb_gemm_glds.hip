@@ -594,18 +594,19 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
     const int g = wave / WMV, wm = wave - g * WMV;
     const int lg = lane >> 4, lr = lane & 15, sw = lr >> 1;
     const int arow_off = (g * BM + wm * 16 + lr) * 128, brow_off = Q::A_BUF + (g * 80 + lr) * 128;
-    int cur = 0, nxt = STAGES - 1;
-    for (int kt = 0; kt < ktg; ++kt) {
+    static_assert(STAGES == 2, "two ring slots: the slot of a k-tile is its parity");
+    // one k-tile; `slot` = kt & 1 is a compile-time constant at both call sites (the loop runs in pairs), so every LDS address of the tile
+    // is an immediate offset: no vector adds for the fragment reads, no scalar ring bookkeeping
+    auto tile = [&](int kt, int slot) {
         if (p.safe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-        else { asm volatile("s_waitcnt vmcnt(%0)" ::"n"((STAGES - 2) * (NA + NB)) : "memory"); __builtin_amdgcn_s_barrier(); }
-        const char* st = lds80 + cur * Q::STAGE;
-        // the next tile's pieces go out in one clump: spreading them between the MFMAs was measured and changes nothing (profiles/README.md, round 4)
-        // (FAST has no per-lane k limit: the tile past the group's end is simply not issued — with two stages the wait above is vmcnt(0),
-        // nothing counts on a constant number of outstanding pieces)
-        static_assert(!FAST || STAGES == 2, "FAST skips the tail issue: only valid when the ring wait is vmcnt(0)");
-        if (!FAST || kt + STAGES - 1 < ktg) {
+        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        const char* st = lds80 + slot * Q::STAGE;
+        // the next tile's pieces go out in one clump: spreading them between the MFMAs was measured and changes nothing (profiles/README.md,
+        // round 4). FAST has no per-lane k limit: the tile past the group's end is simply not issued (the wait above is vmcnt(0), nothing
+        // counts on a constant number of outstanding pieces)
+        if (!FAST || kt + 1 < ktg) {
 #pragma unroll
-            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + STAGES - 1, lds80 + nxt * Q::STAGE);
+            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + 1, lds80 + (slot ^ 1) * Q::STAGE);
         }
         // all twelve fragment reads of the k-tile first (chunk 4s + lg is the lane's k-slot quadruple of half tile s), then the 40 MFMAs:
         // with one wave per SIMD nobody else covers the LDS latency, so it is paid once per k-tile instead of once per half tile
@@ -623,9 +624,10 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
             const int s = q / 20, e = (q / 5) & 3, j = q % 5;
             acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][e], bv[s][j][e], acc[j], 0, 0, 0);
         }
-        cur = (cur + 1 == STAGES) ? 0 : cur + 1;
-        nxt = (nxt + 1 == STAGES) ? 0 : nxt + 1;
-    }
+    };
+    int kt = 0;
+    for (; kt + 1 < ktg; kt += 2) { tile(kt, 0); tile(kt + 1, 1); }
+    if (kt < ktg) tile(kt, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- the KW partial strips meet in LDS; D layout of 16x16x4: lane holds column lr, rows 4 * lg + r
