@@ -134,6 +134,11 @@ template <int KS> __device__ __forceinline__ void f2_lane_offsets(int (&lor)[KS]
 // position order = the k-slot order of a 32-row group in the S^T accumulators (lane (col, g) holds rows 4g .. 4g+3 of sub-tiles 2G, 2G+1).
 // ones_row != 0 (forward V^T only, d < DR): row d of the image is 1.0 for every real key — the P.V MFMA that contracts P with V^T then also
 // produces the softmax denominator sum_k P in its accumulator row d, for free (f2_fwd_kernel<.., ONES = true>).
+// LSE definition with ONES (d % 16 != 0, e.g. d = 40): that denominator is the sum of the bf16-ROUNDED probabilities (the MFMA's B operand),
+// not of the fp32 ones the round-2 kernels add up, so the stored log-sum-exp differs from theirs by up to 2^-9 relative. The backward
+// kernels (v2, and the v1 fallback when v2 is not eligible) recompute P in fp32 against whichever LSE the forward stored: with a v2 forward
+// a recomputed row then sums to 1 only to ~2^-9 — inside every bf16 tolerance of tests/test_gpu_bf16_*.py, and the same order as the
+// rounding of P itself that the forward output already carries.
 __global__ __launch_bounds__(256) void f2_transpose_kernel(const bf16_t* __restrict__ X, long ld, long sb, long sh, int H, int N, int d,
                                                            int DR, int Np, bf16_t* __restrict__ XT, int ones_row) {
     __shared__ __attribute__((aligned(16))) unsigned short tile[64][98];      // 64 rows x DR <= 96 head-dim values (+2: the row pitch stays a multiple of 4 bytes and off the banks' period)

