@@ -15,7 +15,7 @@ collective is the checkpoint-merge all_gather after the timed region (RCCL), who
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   `roofline`      dominant kernel of the fp32 step, measured live with HIP events around every GEMM-class launch of one extra
-                  step. Numbers of the committed rocprofv3 trace / PMC passes (profiles/r03*) are added next to the live ones ONLY
+                  step. Numbers of the committed rocprofv3 trace / PMC passes (profiles/r04*) are added next to the live ones ONLY
                   when their stamp (sha of the kernel sources + plan table, `build`) is this tree's; otherwise `profile_stale` is
                   true and the line carries live measurements alone;
   `cpu_baseline`  the CPU oracle (a from-scratch restatement = kind "port") timed on this box's host cores on a bounded sample;
@@ -43,21 +43,26 @@ PEAK_HBM_GBPS = 8000.0
 STEPS_PER_IDENTITY = 800           # aigc_id.yaml:135 max_steps
 
 
-def trace_symbol(kernel):
-    """profiler label (`gemm_glds_kernel<float,128,128,CONVF>`) -> rocprofv3 symbol as tools/prof_stats.py / pmc_traffic.py write it"""
+def trace_symbols(kernel):
+    """profiler label (`gemm_glds_kernel<float,128,128,CONVF>`) -> the rocprofv3 symbols it may run as, as tools/prof_stats.py / pmc_traffic.py
+    write them. The LDS-DMA kernels exist in a scalar-offset (FAST) and a per-lane form: one label, up to two symbols."""
     import re
     kinds = {"ROW": 0, "COL": 1, "CONV": 2, "CONVF": 3}
     m = re.match(r"gemm_kernel<(\d+),(\d+),(\w+),(\w+)(,generic)?>", kernel)
     m4 = re.match(r"gemm_kernel_occ4<(\w+),(\w+)>", kernel)
-    mg = re.match(r"gemm_glds_kernel<(float|bf16),(\d+),(\d+),(\w+)>", kernel)       # LDS-DMA kernel: <T, BM, BN, AK, row bytes, stages>
+    mg = re.match(r"gemm_glds_kernel<(float|bf16),(\d+),(\d+),(\w+)>", kernel)       # <T, BM, BN, AK, row bytes, stages, FAST>
+    m80 = re.match(r"gemm_glds80_kernel<float,(\d+),80,(\w+)>", kernel)               # <BM, AK, stages, FAST>
+    ak3 = {"ROW": 0, "CONV": 1, "CONVF": 2}
     if mg:
-        ak = {"ROW": 0, "CONV": 1, "CONVF": 2}[mg.group(4)]
-        return f"gemm_glds_kernel<{'float' if mg.group(1) == 'float' else '__bf16'}, {mg.group(2)}, {mg.group(3)}, {ak}, 128, 2>"
+        t = "float" if mg.group(1) == "float" else "__bf16"
+        return [f"gemm_glds_kernel<{t}, {mg.group(2)}, {mg.group(3)}, {ak3[mg.group(4)]}, 128, 2, {f}>" for f in ("true", "false")]
+    if m80:
+        return [f"gemm_glds80_kernel<{m80.group(1)}, {ak3[m80.group(2)]}, 2, {f}>" for f in ("true", "false")]
     if m:
-        return f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"
+        return [f"gemm_kernel<{m.group(1)}, {m.group(2)}, {kinds[m.group(3)]}, {kinds[m.group(4)]}, {'false' if m.group(5) else 'true'}>"]
     if m4:
-        return f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"
-    return None
+        return [f"gemm_kernel_occ4<{kinds[m4.group(1)]}, {kinds[m4.group(2)]}>"]
+    return []
 
 
 def tree_stamp():
@@ -67,22 +72,24 @@ def tree_stamp():
 
 def pmc_traffic(kernel, bf16=False):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
-    separate passes and cannot be collected inside this process): profiles/r03*_pmc_hbm_traffic{,_config3}.json, written by
+    separate passes and cannot be collected inside this process): profiles/r04*_pmc_hbm_traffic{,_config3}.json, written by
     tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Corrected as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950: FETCH_SIZE tallies the 128-B requests of 16-B/lane reads and `buffer_load ... lds` at 64 B, so
     traffic = 2 x FETCH_SIZE + WRITE_SIZE. The file is used only when it was measured on THIS tree (stamp = sha of the kernel
     sources + plan table); otherwise (None, {"stale": ...}). Returns (bytes | None, detail)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r03*_pmc_hbm_traffic{'_config3' if bf16 else ''}.json")))
-    sym = trace_symbol(kernel)
-    if not files or sym is None:
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r04*_pmc_hbm_traffic{'_config3' if bf16 else ''}.json")))
+    syms = trace_symbols(kernel)
+    if not files or not syms:
         return None, None
     d = json.load(open(files[-1]))
     if d.get("stamp") != tree_stamp():
         return None, dict(source=os.path.basename(files[-1]), stale=True, file_stamp=d.get("stamp"), tree_stamp=tree_stamp())
-    e = d.get("per_symbol", {}).get(sym)
-    if not e or e["fetch_bytes_per_launch"] is None or e["write_bytes_per_launch"] is None:
+    cands = [(s_, d.get("per_symbol", {}).get(s_)) for s_ in syms]
+    cands = [(s_, e) for s_, e in cands if e and e["fetch_bytes_per_launch"] is not None and e["write_bytes_per_launch"] is not None]
+    if not cands:
         return None, None
+    sym, e = max(cands, key=lambda c: c[1]["launches"])            # the form that carries the launches (FAST on every SD v1-4 shape)
     corrected = 2 * e["fetch_bytes_per_launch"] + e["write_bytes_per_launch"]
     detail = dict(source=os.path.basename(files[-1]), symbol=sym, launches=e["launches"], stale=False,
                   fetch_size_bytes_per_launch_raw=round(e["fetch_bytes_per_launch"]), write_size_bytes_per_launch=round(e["write_bytes_per_launch"]),
@@ -100,7 +107,7 @@ HBM_GROUP_SYMBOLS = {
 }
 
 
-def rocprof_trace(bf16=False, prefix="r03"):
+def rocprof_trace(bf16=False, prefix="r04"):
     """the newest committed rocprofv3 kernel trace of this leg — profiles/<prefix>*_bench_kernel_stats.csv = `bench.py --no-config3`
     (the fp32 step alone), profiles/<prefix>*_config3_kernel_stats.csv = `bench.py --trace-leg config3` — if and only if its
     stamp line says it was taken on THIS tree. Returns (file | None, stale, {symbol: (calls_per_step, ms_per_step, avg_us)},
@@ -200,9 +207,9 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
 
     def trace_ms(p):
         """(ms per step, launches per step) of a profiler row in the matching trace, or (None, None)"""
-        sym = trace_symbol(p["kernel"])
-        if sym in per_sym:
-            return per_sym[sym][1], per_sym[sym][0]
+        hit = [per_sym[s_] for s_ in trace_symbols(p["kernel"]) if s_ in per_sym]
+        if hit:
+            return sum(h[1] for h in hit), sum(h[0] for h in hit)
         grp = FLASH_SYMS.get(p["kernel"])
         if grp and any(b_ in sym_ms for b_, _ in grp):
             return sum(sym_ms.get(b_, 0.0) * w for b_, w in grp), None
@@ -263,11 +270,11 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
 
 
 def frac_range(value, bf16=False):
-    """roofline.frac of the dominant kernel over the committed bench lines of THIS tree (profiles/BENCH_r03_run*.json with the same
+    """roofline.frac of the dominant kernel over the committed bench lines of THIS tree (profiles/BENCH_r04_run*.json with the same
     stamp: other boxes of the pool) plus this run: [min, max, n]"""
     import glob
     st, vals = tree_stamp(), [value]
-    for p in glob.glob(os.path.join(ROOT, "profiles", "BENCH_r03_run*.json")):
+    for p in glob.glob(os.path.join(ROOT, "profiles", "BENCH_r04_run*.json")):
         try:
             d = json.load(open(p))
             if d.get("build") == st:
