@@ -316,7 +316,9 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
         loss = float(tr.get_state("loss")[0])
         idc = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)[ids]
         row = dict(step=s + 1, loss_rel=abs(loss - float(fx["loss"][s])) / abs(float(fx["loss"][s])),
-                   coef_l2=(coef - fx["coef"][s]).norm(dim=1).max().item(), id_coef_l2=(idc - fx["id_coef"][s]).norm(dim=1).max().item())
+                   id_coef_l2=(idc - fx["id_coef"][s]).norm(dim=1).max().item())
+        if s < fx["coef"].shape[0]:                   # slim long-horizon fixtures keep the step coefficients of their first steps only
+            row["coef_l2"] = (coef - fx["coef"][s]).norm(dim=1).max().item()
         if s + 1 in fx.get("gW_rows", {}):
             g = tr.get_state("mlp.grad_weight").reshape(-1, 512)[::rs]
             ref = fx["gW_rows"][s + 1]
@@ -336,10 +338,10 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     tr.close()
     report[tag + ".table"] = table
     n = len(table)
-    fit = lambda k: (table[-1][k] - table[n // 2 - 1][k]) / max(n - n // 2, 1)          # slope over the second half of the run
-    summary = dict(steps=n, coef_l2_max=max(r["coef_l2"] for r in table), coef_l2_last=table[-1]["coef_l2"],
-                   coef_l2_slope_per_step=fit("coef_l2"), id_coef_l2_last=table[-1]["id_coef_l2"], loss_rel_max=max(r["loss_rel"] for r in table),
-                   extrapolated_coef_l2_at_800_steps=table[-1]["coef_l2"] + fit("coef_l2") * (800 - n))
+    ctab = [r for r in table if "coef_l2" in r]
+    summary = dict(steps=n, coef_l2_max=max(r["coef_l2"] for r in ctab), coef_l2_last=ctab[-1]["coef_l2"], coef_l2_steps=len(ctab),
+                   id_coef_l2_last=table[-1]["id_coef_l2"], id_coef_l2_max=max(r["id_coef_l2"] for r in table),
+                   loss_rel_max=max(r["loss_rel"] for r in table))
     report[tag + ".summary"] = summary
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/{tag}.json", "w") as f:
@@ -377,22 +379,22 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     run_horizon(lib, ctx, fx, 800, "horizon_sd14_b1_800", REPORT, dict(loss_rel_max=5e-3), save_traj=traj)
     tab = REPORT["horizon_sd14_b1_800.table"]
     hip = torch.load(traj, weights_only=False)["coef"]
-    ref = fx["coef"][:hip.shape[0]]
+    ref = fx["coef"]                                   # the fixture keeps the per-step coefficients of the first 200 steps (the crossings analysed)
     seen, events, first = set(), [], None
-    for s_ in range(hip.shape[0]):
+    for s_ in range(min(hip.shape[0], ref.shape[0])):
         for face, el in (torch.sign(hip[s_]) != torch.sign(ref[s_])).nonzero().tolist():
             if el not in seen:          # a row that crossed once keeps differing: only its FIRST appearance must sit at the kink
                 seen.add(el)
                 events.append(dict(step=s_ + 1, face=face, element=el, oracle=float(ref[s_][face, el]), hip=float(hip[s_][face, el])))
                 first = first or (s_ + 1)
-    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1]["coef_l2"], loss_rel=tab[k - 1]["loss_rel"])
+    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1].get("coef_l2"), loss_rel=tab[k - 1]["loss_rel"])
           for k in (10, 50, 75, 100, 200, 400, 800)}
     REPORT["horizon_sd14_b1_800.at_steps"] = at
     REPORT["horizon_sd14_b1_800.kink_crossings"] = events[:20]
     REPORT["horizon_sd14_b1_800.first_kink_crossing_step"] = first
     with open("gpurun_out/horizon_sd14_b1_800.json") as f:
         rec = json.load(f)
-    rec.update(at_steps=at, first_kink_crossing_step=first, kink_crossings=events[:20], sign_disagreeing_coefficients_at_800=len(seen))
+    rec.update(at_steps=at, first_kink_crossing_step=first, kink_crossings=events[:20], sign_disagreeing_coefficients_at_200=len(seen))
     with open("gpurun_out/horizon_sd14_b1_800.json", "w") as f:
         json.dump(rec, f, indent=1)
     smooth = tab[:(first - 1) if first else len(tab)]
