@@ -7,6 +7,8 @@ instead of on the CPU oracle:
     python oracle/gen_horizon.py fp32alt  -> horizon_sd14_b1_alt.pt   20 steps of `fp32` on 3 instead of 8 host threads (torch-CPU's convolutions
                                             do not change their summation order with the thread count: the two runs agree to 1.5e-6)
     python oracle/gen_horizon.py fp32pert -> horizon_sd14_b1_pert.pt  `fp32` with every step's MLP gradient perturbed by 4e-5 relative noise
+    python oracle/gen_horizon.py fp32long -> horizon_sd14_b1_800.pt   `fp32` continued to 800 steps (config 2's own length; 3.5 h)
+    python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 200 steps of the same stream with low-pass ("photo-like") face crops
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
@@ -36,6 +38,9 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # BASELINE config 2's own length (aigc_id.yaml:135 max_steps: 800): the `fp32` run continued to 800 optimiser steps (≈ 2 h on 8 host
             # threads); its first 100 steps are the `fp32` fixture's. slim800 keeps loss, step coefficients and dictionary rows per step.
             fp32long=dict(B=1, steps=800, lr=5e-3, seed=8, out="horizon_sd14_b1_800.pt", grad_steps=(), slim=True, coef_steps=200),
+            # the fp32 stream with LOW-PASS ("photo-like") face crops: the HIP path's 4e-5 step-coefficient difference on the default stream is
+            # the fp32 rounding of the warp's sampling coordinate on WHITE-NOISE faces; on smooth faces it is 5e-6 (probe_warp_rounding.py)
+            fp32photo=dict(B=1, steps=200, lr=5e-3, seed=8, out="horizon_sd14_b1_photo.pt", grad_steps=(), slim=True, photo=True),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 
@@ -59,13 +64,13 @@ def main(which, steps=None):
     W = O.init_weights(shapes, seed=r["seed"])
     st = O.TrainState(W)
     ids = sorted({1 + (b % (m["max_ids"] - 1)) for b in range(r["B"])})
-    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=100, row_stride=ROW_STRIDE, ids=ids,
+    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=100, row_stride=ROW_STRIDE, ids=ids, photo=bool(r.get("photo")),
                         torch=torch.__version__, threads=torch.get_num_threads()),
                loss=[], coef=[], id_coef=[], id_emb_norm=[], gW_rows={}, gb={})
     W0 = st.Wm.clone()
     t0 = time.time()
     for s in range(r["steps"]):
-        batch = make_batch(r["B"], 512, 64, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"])
+        batch = make_batch(r["B"], 512, 64, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"], photo=bool(r.get("photo")))
         loss, aux = O.train_step(W, st, batch, r["lr"], m["unet"], m["vae"], m["clip"], m["fr"], es=2, inner=512,
                                  placeholder=m["placeholder"], return_aux=True)
         rec["loss"].append(float(loss))

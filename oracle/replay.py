@@ -5,11 +5,32 @@ the posterior sample, all drawn from a torch CPU generator keyed by `seed` so th
 import torch
 
 
-def make_batch(B, S, lat, vocab, placeholder, seed, n_ids):
+def low_pass(x_hwc, sigma=4.0, radius=12):
+    """separable Gaussian blur of [B, S, S, C] noise (reflect borders, float64 accumulation, rescaled to max |x| = 1): "photo-like" faces —
+    neighbouring pixels differ by ~1e-2 instead of O(1), so the fp32 rounding of a warp coordinate (6e-5 pixel at 512 px) moves a sampled
+    value by ~1e-6 instead of ~3e-5 (tools/probes/probe_warp_rounding.py)"""
+    k = torch.arange(-radius, radius + 1, dtype=torch.float64)
+    ker = torch.exp(-k ** 2 / (2.0 * sigma ** 2)); ker = ker / ker.sum()
+    x = x_hwc.double().permute(0, 3, 1, 2)
+    B, C, H, W = x.shape
+    x = x.reshape(B * C, 1, H, W)
+    x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (radius, radius, 0, 0), mode="reflect"), ker.view(1, 1, 1, -1))
+    x = torch.nn.functional.conv2d(torch.nn.functional.pad(x, (0, 0, radius, radius), mode="reflect"), ker.view(1, 1, -1, 1))
+    x = x.reshape(B, C, H, W).permute(0, 2, 3, 1)
+    return (x / x.abs().amax()).float().contiguous()
+
+
+def make_batch(B, S, lat, vocab, placeholder, seed, n_ids, photo=False):
     g = torch.Generator().manual_seed(seed)
     tokens = torch.randint(0, vocab - 30, (B, 77), generator=g)
     for b in range(B):
         tokens[b, 3 + 2 * b] = placeholder
+    if photo:                                # same draws, the two face crops low-pass filtered (the `image` feeds the VAE: no sub-pixel sampling there)
+        image = torch.rand(B, S, S, 3, generator=g) * 2 - 1
+        faces = low_pass(torch.rand(B, S, S, 6, generator=g) * 2 - 1)
+        return dict(image=image, faces=faces, ids=torch.stack([torch.tensor([1 + (b % (n_ids - 1))] * 2) for b in range(B)]), tokens=tokens,
+                    t=torch.randint(0, 1000, (B,), generator=g), noise=torch.randn(B, 4, lat, lat, generator=g),
+                    post_noise=torch.randn(B, 4, lat, lat, generator=g))
     return dict(image=torch.rand(B, S, S, 3, generator=g) * 2 - 1, faces=torch.rand(B, S, S, 6, generator=g) * 2 - 1,
                 ids=torch.stack([torch.tensor([1 + (b % (n_ids - 1))] * 2) for b in range(B)]), tokens=tokens,
                 t=torch.randint(0, 1000, (B,), generator=g), noise=torch.randn(B, 4, lat, lat, generator=g),

@@ -25,7 +25,7 @@ CONVS = [(64, 64, 320, 320, 14), (64, 64, 640, 320, 4), (64, 64, 960, 320, 2), (
 # (rows per image, N, K, launches)
 LINS = [(4096, 320, 320, 30), (4096, 2560, 320, 10), (4096, 320, 1280, 10), (1024, 640, 640, 30), (1024, 5120, 640, 10),
         (1024, 640, 2560, 10), (256, 1280, 1280, 30), (256, 10240, 1280, 10), (256, 1280, 5120, 10), (77, 320, 768, 10), (77, 1280, 768, 12)]
-TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (256, 128)]       # the last one: bf16 only (8-wave LDS-DMA tile)
+TILES = [(128, 128), (128, 64), (64, 128), (64, 64), (256, 128), (64, 80), (32, 80), (16, 80)]   # 256x128: bf16 only; x80: fp32 only (round 4)
 SPLITS = [1, 2, 3, 4, 6, 8, 12, 16]
 
 
@@ -88,7 +88,7 @@ def main():
         if not a.quick:
             sweep = {}
             for (bm, bn) in TILES:
-                if (bm >= 128 and M <= 64) or (bn == 128 and N <= 64) or (bm == 256 and (a.dtype != "bf16" or M <= 128)):
+                if (bm >= 128 and M <= 64) or (bn == 128 and N <= 64) or (bm == 256 and (a.dtype != "bf16" or M <= 128)) or (bn == 80 and a.dtype != "f32"):
                     continue
                 for sp in SPLITS:
                     if sp > 1 and (K // ksz) // sp < 2:
