@@ -756,7 +756,8 @@ bool gemm_f32_glds_shape_ok(const GemmArgs& a) {
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
         if (g.C % 4 || g.ks < 1 || g.ks > 4 || a.K != g.ks * g.ks * g.C) return false;
-        return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C < lim;
+        // (+ the FAST path's descriptor bias: its voffsets are shifted up by the most negative row base)
+        return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C + (long)(g.pad * g.W + g.pad) * g.C < lim;
     }
     if (a.a_kind != LD_ROW || a.lda % 4 || a.sAb % 4 || a.sAh % 4) return false;
     return (long)a.M * a.lda < lim;
@@ -1020,7 +1021,8 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_CHECK(aligned16(a.A) && aligned16(a.B), CB_ERR_ARG, "gemm_bf16: operands must be 16-byte aligned");
     {   // 32-bit byte offsets inside one operand slice (buffer loads)
         const long lim = (1L << 31) - 64;
-        long ea = a.a_kind == LD_CONV ? (long)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C : (long)a.M * a.lda;
+        long ea = a.a_kind == LD_CONV ? (long)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C + (long)(a.g.pad * a.g.W + a.g.pad) * a.g.C
+                                      : (long)a.M * a.lda;           // conv: + the FAST path's descriptor bias
         long eb = (long)a.N * a.ldb;
         CB_CHECK(ea * 2 < lim && eb * 2 < lim, CB_ERR_SHAPE, "gemm_bf16: an operand slice exceeds 2 GiB");
     }

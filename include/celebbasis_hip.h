@@ -110,8 +110,9 @@ typedef struct {
     int dtype;                                   /* cb_dtype of A, B, C, R (descriptor-level: independent of the context's) */
 } cb_gemm_desc;
 int cb_gemm(cb_ctx* ctx, const cb_gemm_desc* d);
-/* diagnostics (tools/tune_gemm.py): pin the GEMM planner to one tile shape (64/128 x 64/128) and split-K count for every later
- * launch of this process; (0, 0, 0) releases it. Process-global, not thread safe — never call it in production code. */
+/* diagnostics (tools/tune_gemm.py, tools/pmc_n80.py): pin the GEMM planner to one tile shape — 64/128 x 64/128, 256 x 128 (bf16), or
+ * the fp32 80-column tiles 64/32/16 x 80, which bind only the problems that can run them — and split-K count for every later launch
+ * of this process; (0, 0, 0) releases it. Process-global, not thread safe — never call it in production code. */
 int cb_debug_force_plan(int BM, int BN, int split);
 /* diagnostics: the LDS-DMA GEMM / conv kernel synchronises its tile ring with a COUNTED `s_waitcnt vmcnt(N)` + raw `s_barrier`; on != 0
  * makes every later launch of this process drain the queue (`vmcnt(0)`) and use a full barrier instead — the slow reference pipeline the

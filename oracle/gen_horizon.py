@@ -8,7 +8,7 @@ instead of on the CPU oracle:
                                             do not change their summation order with the thread count: the two runs agree to 1.5e-6)
     python oracle/gen_horizon.py fp32pert -> horizon_sd14_b1_pert.pt  `fp32` with every step's MLP gradient perturbed by 4e-5 relative noise
     python oracle/gen_horizon.py fp32long -> horizon_sd14_b1_800.pt   `fp32` continued to 800 steps (config 2's own length; 3.5 h)
-    python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 200 steps of the same stream with low-pass ("photo-like") face crops
+    python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 800 steps of the same stream with low-pass ("photo-like") face crops (2.5 h)
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
@@ -40,7 +40,7 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             fp32long=dict(B=1, steps=800, lr=5e-3, seed=8, out="horizon_sd14_b1_800.pt", grad_steps=(), slim=True, coef_steps=200),
             # the fp32 stream with LOW-PASS ("photo-like") face crops: the HIP path's 4e-5 step-coefficient difference on the default stream is
             # the fp32 rounding of the warp's sampling coordinate on WHITE-NOISE faces; on smooth faces it is 5e-6 (probe_warp_rounding.py)
-            fp32photo=dict(B=1, steps=200, lr=5e-3, seed=8, out="horizon_sd14_b1_photo.pt", grad_steps=(), slim=True, photo=True),
+            fp32photo=dict(B=1, steps=800, lr=5e-3, seed=8, out="horizon_sd14_b1_photo.pt", grad_steps=(), slim=True, photo=True, coef_steps=200),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 

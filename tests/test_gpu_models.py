@@ -309,7 +309,7 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     traj = dict(coef=[], id_coef=[], gW_rows=[], loss=[])
     ctx.set_debug_taps(True)
     for s in range(steps):
-        batch = make_batch(B, 512, 64, m["clip"]["vocab"], m["placeholder"], c["batch_seed0"] + s, m["max_ids"])
+        batch = make_batch(B, 512, 64, m["clip"]["vocab"], m["placeholder"], c["batch_seed0"] + s, m["max_ids"], photo=bool(c.get("photo")))
         dev = {k: dv(v) for k, v in batch.items()}
         tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], c["lr"])
         coef = ctx.tap("coef").reshape(2 * B, -1)
@@ -405,6 +405,34 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     assert max(r["id_coef_l2"] for r in tab[:75]) <= 1e-3, "learned coefficients (EMA dictionary) left the 1e-3 bar inside 75 steps"
     assert max(r["loss_rel"] for r in tab[:100]) <= 2e-4
     assert max(r["id_coef_l2"] for r in tab) <= 1e-1, "learned coefficients far outside the reference-vs-reference envelope (measured 4.8e-2 at step 800)"
+
+
+def test_train_200_steps_sd14_photo_faces_horizon(cb, golden_dir):
+    """the same SD-size run on the replay stream with LOW-PASS ("photo-like") face crops (oracle/replay.py::low_pass; oracle trajectory
+    tests/golden/horizon_sd14_b1_photo.pt, 200 steps). The default stream's faces are white noise, the worst case for the one place where
+    the two paths' fp32 arithmetic differs by more than summation order: the warp's sampling coordinate (an ulp of 6e-5 pixel at 512 px
+    against O(1) differences between neighbouring pixels, tools/probes/probe_warp_rounding.py). On smooth faces the step coefficients
+    must agree to 1.5e-5 (4e-5 on noise) until the first LeakyReLU kink crossing; the table goes to gpurun_out/horizon_sd14_b1_photo.json
+    (committed: profiles/r04_sd14_horizon200_photo.json)."""
+    lib, ctx = cb
+    fx = dict(load(golden_dir, "horizon_sd14_b1_photo.pt"))
+    assert fx["cfg"]["photo"] and int(fx["steps"]) == 200
+    os.makedirs("gpurun_out", exist_ok=True)
+    traj = "gpurun_out/horizon_sd14_b1_photo_traj.pt"
+    run_horizon(lib, ctx, fx, 200, "horizon_sd14_b1_photo", REPORT, dict(loss_rel_max=5e-3), save_traj=traj)
+    tab = REPORT["horizon_sd14_b1_photo.table"]
+    hip, ref = torch.load(traj, weights_only=False)["coef"], fx["coef"]
+    first = next((s_ + 1 for s_ in range(hip.shape[0]) if bool((torch.sign(hip[s_]) != torch.sign(ref[s_])).any())), None)
+    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1]["coef_l2"]) for k in (1, 10, 50, 75, 100, 200)}
+    with open("gpurun_out/horizon_sd14_b1_photo.json") as f:
+        rec = json.load(f)
+    rec.update(at_steps=at, first_kink_crossing_step=first)
+    with open("gpurun_out/horizon_sd14_b1_photo.json", "w") as f:
+        json.dump(rec, f, indent=1)
+    REPORT["horizon_sd14_b1_photo.at_steps"] = at; REPORT["horizon_sd14_b1_photo.first_kink_crossing_step"] = first
+    smooth = tab[:(first - 1) if first else len(tab)]
+    assert len(smooth) >= 5 and max(r["coef_l2"] for r in smooth) <= 1.5e-5, (first, max(r["coef_l2"] for r in smooth) if smooth else None)
+    assert max(r["id_coef_l2"] for r in tab[:75]) <= 1e-3 and max(r["loss_rel"] for r in tab[:100]) <= 2e-4
 
 
 def test_train_800_steps_mini_vs_reference_run(cb, golden_dir):
