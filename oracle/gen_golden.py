@@ -741,7 +741,7 @@ def main():
     manifest["horizon_sd14_b4.pt"] = "oracle/gen_horizon.py bf16: the same for 20 steps at bs=4, lr 2e-2 (fp32 oracle; checks the bf16 step)"
     manifest["horizon_sd14_b1_800.pt"] = ("oracle/gen_horizon.py fp32long: the fp32 run continued to BASELINE config 2's own length, 800 optimiser steps "
                                           "(aigc_id.yaml:135); slim: losses, step coefficients, EMA dictionary rows")
-    manifest["horizon_sd14_b1_photo.pt"] = ("oracle/gen_horizon.py fp32photo: 200 steps of the fp32 run on the replay stream with low-pass (photo-like) face crops "
+    manifest["horizon_sd14_b1_photo.pt"] = ("oracle/gen_horizon.py fp32photo: 800 steps of the fp32 run on the replay stream with low-pass (photo-like) face crops "
                                             "(oracle/replay.py::low_pass); slim")
     manifest["horizon_mini_ref800.pt"] = ("oracle/gen_horizon_ref.py: 800 optimiser steps of the REFERENCE's composed step (the gen_step harness: ddpm.py "
                                           "LatentDiffusion.forward / p_losses / q_sample / get_loss, UNetModel, Encoder, EmbeddingManagerId + MetaIdNet, AdamW) at "

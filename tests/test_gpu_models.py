@@ -407,32 +407,36 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     assert max(r["id_coef_l2"] for r in tab) <= 1e-1, "learned coefficients far outside the reference-vs-reference envelope (measured 4.8e-2 at step 800)"
 
 
-def test_train_200_steps_sd14_photo_faces_horizon(cb, golden_dir):
-    """the same SD-size run on the replay stream with LOW-PASS ("photo-like") face crops (oracle/replay.py::low_pass; oracle trajectory
-    tests/golden/horizon_sd14_b1_photo.pt, 200 steps). The default stream's faces are white noise, the worst case for the one place where
-    the two paths' fp32 arithmetic differs by more than summation order: the warp's sampling coordinate (an ulp of 6e-5 pixel at 512 px
-    against O(1) differences between neighbouring pixels, tools/probes/probe_warp_rounding.py). On smooth faces the step coefficients
-    must agree to 1.5e-5 (4e-5 on noise) until the first LeakyReLU kink crossing; the table goes to gpurun_out/horizon_sd14_b1_photo.json
-    (committed: profiles/r04_sd14_horizon200_photo.json)."""
+def test_train_800_steps_sd14_photo_faces_horizon(cb, golden_dir):
+    """BASELINE config 2's full horizon at SD size on the replay stream with LOW-PASS ("photo-like") face crops (oracle/replay.py::low_pass;
+    oracle trajectory tests/golden/horizon_sd14_b1_photo.pt, 800 steps, 2.3 h of host time). The default stream's faces are white noise, the
+    worst case for the one place where the two paths' fp32 arithmetic differs by more than summation order: the warp's sampling coordinate
+    (an ulp of 6e-5 pixel at 512 px against O(1) differences between neighbouring pixels, tools/probes/probe_warp_rounding.py). On smooth
+    faces the step coefficients agree to ~6e-6 instead of 4e-5, far fewer pre-activations land within the difference of the head's
+    LeakyReLU kink, and north_star's bar — learned coefficients within 1e-3 L2 of the CPU path at fixed seed — is asserted over the WHOLE
+    800-step horizon, with every loss to 2e-4. Table: gpurun_out/horizon_sd14_b1_photo.json (committed: profiles/r04_sd14_horizon800_photo.json)."""
     lib, ctx = cb
     fx = dict(load(golden_dir, "horizon_sd14_b1_photo.pt"))
-    assert fx["cfg"]["photo"] and int(fx["steps"]) == 200
+    assert fx["cfg"]["photo"] and int(fx["steps"]) == 800
     os.makedirs("gpurun_out", exist_ok=True)
     traj = "gpurun_out/horizon_sd14_b1_photo_traj.pt"
-    run_horizon(lib, ctx, fx, 200, "horizon_sd14_b1_photo", REPORT, dict(loss_rel_max=5e-3), save_traj=traj)
+    run_horizon(lib, ctx, fx, 800, "horizon_sd14_b1_photo", REPORT, dict(loss_rel_max=2e-4), save_traj=traj)
     tab = REPORT["horizon_sd14_b1_photo.table"]
-    hip, ref = torch.load(traj, weights_only=False)["coef"], fx["coef"]
-    first = next((s_ + 1 for s_ in range(hip.shape[0]) if bool((torch.sign(hip[s_]) != torch.sign(ref[s_])).any())), None)
-    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1]["coef_l2"]) for k in (1, 10, 50, 75, 100, 200)}
+    hip, ref = torch.load(traj, weights_only=False)["coef"], fx["coef"]          # the fixture keeps the step coefficients of the first 200 steps
+    n = min(hip.shape[0], ref.shape[0])
+    first = next((s_ + 1 for s_ in range(n) if bool((torch.sign(hip[s_]) != torch.sign(ref[s_])).any())), None)
+    at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1].get("coef_l2")) for k in (1, 10, 100, 200, 400, 800)}
     with open("gpurun_out/horizon_sd14_b1_photo.json") as f:
         rec = json.load(f)
-    rec.update(at_steps=at, first_kink_crossing_step=first)
+    rec.update(at_steps=at, first_sign_disagreement_in_200_steps=first)
+    rec["table"] = [r for r in rec["table"] if r["step"] <= 20 or r["step"] % 10 == 0]
     with open("gpurun_out/horizon_sd14_b1_photo.json", "w") as f:
         json.dump(rec, f, indent=1)
-    REPORT["horizon_sd14_b1_photo.at_steps"] = at; REPORT["horizon_sd14_b1_photo.first_kink_crossing_step"] = first
-    smooth = tab[:(first - 1) if first else len(tab)]
+    REPORT["horizon_sd14_b1_photo.at_steps"] = at; REPORT["horizon_sd14_b1_photo.first_sign_disagreement_in_200_steps"] = first
+    smooth = [r for r in tab[:(first - 1) if first else n] if "coef_l2" in r]
     assert len(smooth) >= 5 and max(r["coef_l2"] for r in smooth) <= 1.5e-5, (first, max(r["coef_l2"] for r in smooth) if smooth else None)
-    assert max(r["id_coef_l2"] for r in tab[:75]) <= 1e-3 and max(r["loss_rel"] for r in tab[:100]) <= 2e-4
+    worst = max(r["id_coef_l2"] for r in tab)
+    assert worst <= 1e-3, f"learned coefficients left north_star's 1e-3 bar inside the 800-step horizon on photo-like faces: {worst:.3e}"
 
 
 def test_train_800_steps_mini_vs_reference_run(cb, golden_dir):
