@@ -407,6 +407,34 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     assert max(r["id_coef_l2"] for r in tab) <= 1e-1, "learned coefficients far outside the reference-vs-reference envelope (measured 4.8e-2 at step 800)"
 
 
+def test_two_gemm_tilings_stay_together_sd14(cb):
+    """the control behind the horizon tests' reading: the HIP path's OWN noise is far below what separates it from the oracle. Two HIP
+    runs of 40 SD-size steps on the white-noise stream that differ only in their GEMM tilings (the measured plan table against every
+    problem pinned to 64x64 tiles with the planner's split: other fp32 summation orders in every conv / Linear of the step) must keep
+    their learned coefficients within 1e-5 L2 of each other (measured 3e-6 in round 3) — while each of them is 3e-4 from the oracle by
+    then, because of the warp's coordinate rounding and the kink crossing at step 16 (test_train_800_steps_sd14_horizon)."""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    m = SD14(O)
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = O.init_weights(shapes, seed=8)
+    out = []
+    try:
+        for plan in ((0, 0, 0), (64, 64, 0)):
+            lib.check(lib.load().cb_debug_force_plan(*plan))
+            tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+            for s in range(40):
+                dev = {k: dv(v) for k, v in make_batch(1, 512, 64, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"]).items()}
+                tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], 5e-3)
+            out.append((tr.get_state("id_coefficients").reshape(m["max_ids"], -1).clone(), float(tr.get_state("loss")[0])))
+            tr.close()
+    finally:
+        lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+    d = (out[0][0] - out[1][0]).norm(dim=1).max().item()
+    REPORT["sd14.two_gemm_tilings.learned_coefficient_l2_after_40_steps"] = d
+    assert d <= 1e-5 and abs(out[0][1] - out[1][1]) <= 1e-5 * abs(out[0][1]), (d, out[0][1], out[1][1])
+
+
 def test_train_800_steps_sd14_photo_faces_horizon(cb, golden_dir):
     """BASELINE config 2's full horizon at SD size on the replay stream with LOW-PASS ("photo-like") face crops (oracle/replay.py::low_pass;
     oracle trajectory tests/golden/horizon_sd14_b1_photo.pt, 800 steps, 2.3 h of host time). The default stream's faces are white noise, the
