@@ -101,6 +101,33 @@ int cb_ctx_reset_stats(cb_ctx* ctx) {
     ctx->c.arena.peak = 0;
     CB_END
 }
+int cb_ctx_set_warp_grid(cb_ctx* ctx, const float* host_grid, int S) {
+    CB_TRY
+    require(ctx, "ctx");
+    Ctx& c = ctx->c;
+    if (!host_grid) {
+        if (c.warp_grid && !c.dry) { CB_HIP(hipStreamSynchronize(c.stream)); CB_HIP(hipFree(c.warp_grid)); }
+        c.warp_grid = nullptr; c.warp_S = 0;
+    } else {
+        CB_CHECK(S > 1 && S <= 4096, CB_ERR_ARG, "warp grid: S = %d", S);
+        // the table must be a plausible affine grid: finite, inside a few image widths
+        const size_t n = (size_t)S * S * 2;
+        for (size_t i = 0; i < n; i += (size_t)S * 2 - 1)
+            CB_CHECK(host_grid[i] == host_grid[i] && host_grid[i] > -8.f && host_grid[i] < 8.f, CB_ERR_ARG,
+                     "warp grid: element %zu = %g is not a normalised coordinate", i, (double)host_grid[i]);
+        if (c.dry) {
+            c.warp_grid = reinterpret_cast<float*>(0x200000); c.warp_S = S;
+        } else {
+            CB_HIP(hipStreamSynchronize(c.stream));
+            if (c.aux) CB_HIP(hipStreamSynchronize(c.aux));
+            if (c.warp_grid && c.warp_S != S) { CB_HIP(hipFree(c.warp_grid)); c.warp_grid = nullptr; }
+            if (!c.warp_grid) CB_HIP(hipMalloc(&c.warp_grid, n * sizeof(float)));
+            CB_HIP(hipMemcpy(c.warp_grid, host_grid, n * sizeof(float), hipMemcpyHostToDevice));
+            c.warp_S = S;
+        }
+    }
+    CB_END
+}
 int cb_ctx_set_debug_taps(cb_ctx* ctx, int enable) {
     CB_TRY
     require(ctx, "ctx");
@@ -374,7 +401,7 @@ int cb_face_warp_resize(cb_ctx* ctx, const float* faces, float* warped, float* o
     require(ctx, "ctx");
     static const float th[6] = {1.07695457f, -0.03625215f, -1.56352194f / 512.f, 0.03625215f, 1.07695457f, -5.32134629f / 512.f};
     Launch L = ctx->c.launch();
-    k_affine_warp(L, warped, faces, B, S, nface, th);
+    k_affine_warp(L, warped, faces, B, S, nface, th, ctx->c.warp_grid_for(S));
     k_resize_bilinear_ac(L, out, warped, nface * B, S, S, out_size, out_size, 3);
     CB_END
 }

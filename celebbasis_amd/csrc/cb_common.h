@@ -221,7 +221,8 @@ void k_vae_sample(const Launch& L, DType dt, void* z, const void* moments, const
 void k_gather_rows(const Launch& L, float* out, const float* table, const int64_t* idx, long rows, int C, long table_rows);
 void k_add_rowbcast(const Launch& L, DType dt, void* dst, const void* x, const float* pos, long rows, int period, int C);
 // face pre-processing (meta_net.py:250-260)
-void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* theta);
+void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* theta,
+                   const float* grid = nullptr /* [S][S][2] sampling grid of the caller (Ctx::warp_grid), or the analytic one */);
 void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C);
 // feeder augmentations (face_id.py:526-532, 712-730)
 size_t face_augment_ws_floats(int B);

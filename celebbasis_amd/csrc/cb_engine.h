@@ -73,6 +73,9 @@ struct Ctx {
     // creation: cb_ctx_create_dtype). The FR-net, the coefficient head, its gradient and AdamW are always fp32.
     DType dtype = DT_F32;
     DType load_dt = DT_F32;      // element type the weight loaders currently pack to (set by the *_load functions)
+    // the face warp's constant sampling grid [S][S][2] as the caller's host evaluated it (cb_ctx_set_warp_grid); nullptr = analytic
+    float* warp_grid = nullptr; int warp_S = 0;
+    const float* warp_grid_for(int S) const { return (warp_grid && warp_S == S) ? warp_grid : nullptr; }
     Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; return L; }
     void ensure_arena(size_t bytes);
     // upload a table entry to the device (raw fp32 copy); dims are checked against `expect` (-1 = any)

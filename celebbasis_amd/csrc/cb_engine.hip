@@ -46,6 +46,7 @@ Ctx::~Ctx() {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (arena.base) (void)hipFree(arena.base);
+        if (warp_grid) (void)hipFree(warp_grid);
         pool.release();
     }
 }

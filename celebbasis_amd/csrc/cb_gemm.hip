@@ -450,7 +450,17 @@ void gemm(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     }
     CB_CHECK(a.dt == DT_F32, CB_ERR_ARG, "gemm: the fp32 kernel was handed a bf16 problem");
     if (gemm_f32_glds(L, a, ws, ws_bytes)) return;          // k-contiguous operands: the LDS-DMA kernel (cb_gemm_glds.hip)
-    CB_CHECK(!a.prelu && !a.C2, CB_ERR_ARG, "gemm: the PReLU / second-output epilogue exists on the LDS-DMA kernels only");
+    if (a.prelu || a.C2) {
+        // the PReLU / second-output epilogue exists on the LDS-DMA kernels only: a problem they decline (CB_F32_GLDS=0, C % 4 != 0,
+        // misaligned operands, slices over 2 GiB) runs de-fused — the plain GEMM, then the per-channel passes it replaced
+        CB_CHECK(a.batch == 1 && a.ldc == a.N, CB_ERR_ARG, "gemm: de-fused PReLU / second output needs one dense [M][N] output");
+        GemmArgs b = a;
+        b.prelu = nullptr; b.C2 = nullptr; b.c2_scale = nullptr; b.c2_shift = nullptr;
+        gemm(L, b, ws, ws_bytes);
+        if (a.prelu) k_channel_affine(L, static_cast<float*>(a.C), static_cast<const float*>(a.C), nullptr, nullptr, a.prelu, a.M, a.N);
+        if (a.C2) k_channel_affine(L, static_cast<float*>(a.C2), static_cast<const float*>(a.C), a.c2_scale, a.c2_shift, nullptr, a.M, a.N);
+        return;
+    }
     if (a.a_kind == LD_CONV)
         CB_CHECK(a.g.ks == 1 || a.g.ks == 3, CB_ERR_SHAPE, "conv: ks=%d exists on the LDS-DMA kernel only (16-byte aligned operands, C %% 4 == 0)", a.g.ks);
     Plan pl = make_plan(a, BK, 1.0);

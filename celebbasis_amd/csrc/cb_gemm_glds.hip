@@ -749,7 +749,10 @@ static int f32_glds_mode() {
 }
 static int f32_glds_bk() { return f32_glds_mode() == 2 ? 16 : 32; }
 bool gemm_f32_glds_shape_ok(const GemmArgs& a) {
-    if (!f32_glds_mode() || a.dt != DT_F32 || a.b_kind != LD_ROW) return false;
+    // CB_F32_GLDS=0 (A/B measurements) hands everything the register-staged kernel CAN run to it; the 2x2 / 4x4 kernels (the Upsample
+    // layers' input-gradient conv) exist here only and stay
+    const bool only_here = a.a_kind == LD_CONV && a.g.ks != 1 && a.g.ks != 3;
+    if ((!f32_glds_mode() && !only_here) || a.dt != DT_F32 || a.b_kind != LD_ROW) return false;
     if (a.K % 4 || a.ldb % 4 || a.sBb % 4 || a.sBh % 4) return false;
     const long lim = ((1L << 31) - 64) / 4;
     if ((long)a.N * a.ldb >= lim) return false;

@@ -1250,8 +1250,14 @@ void k_add_rowbcast(const Launch& L, DType dt, void* dst, const void* x, const f
 // faces: [B, S, S, 3*nface] HWC; out: [nface*B, S, S, 3] with face f of sample b at index f*B + b
 // (forward_multi_faces chunks along channels then cats along batch, meta_net.py:336-337).
 // affine_grid(theta, align_corners=True) + grid_sample(bilinear, zeros, align_corners=True).
-__global__ void affine_warp_kernel(float* __restrict__ out, const float* __restrict__ faces, int B, int S, int nface, float t00,
-                                   float t01, float t02, float t10, float t11, float t12) {
+// `grid` (optional, [S][S][2]): the sampling grid as the caller's host evaluated it — the reference builds it with
+// F.affine_grid(trans_matrix, size, align_corners=True) from a CONSTANT matrix and a constant 512x512 size (meta_net.py:131-142,
+// 253-257), i.e. it is a constant table like the beta schedule. With the table the kernel samples at the reference's own fp32
+// coordinates (the fp32 ulp of a 512-pixel coordinate is 6e-5 pixel: re-deriving the grid in another evaluation order moves a
+// sample of a white-noise face by 3e-5, profiles/r04_warp_rounding.json) and follows grid_sample's unnormalise / weight order
+// (GridSampler.h grid_sampler_unnormalize: ((g + 1) / 2) * (S - 1); corner weights (1-wy)(1-wx) ..., summed nw + ne + sw + se).
+__global__ void affine_warp_kernel(float* __restrict__ out, const float* __restrict__ faces, const float* __restrict__ grid, int B,
+                                   int S, int nface, float t00, float t01, float t02, float t10, float t11, float t12) {
     long total = (long)nface * B * S * S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int x = (int)(i % S);
@@ -1259,12 +1265,19 @@ __global__ void affine_warp_kernel(float* __restrict__ out, const float* __restr
         int y = (int)(r % S);
         long fb = r / S;
         int f = (int)(fb / B), b = (int)(fb % B);
-        float xn = (2.f * x) / (S - 1) - 1.f;
-        float yn = (2.f * y) / (S - 1) - 1.f;
-        float gx = t00 * xn + t01 * yn + t02;
-        float gy = t10 * xn + t11 * yn + t12;
-        float ix = (gx + 1.f) * 0.5f * (S - 1);
-        float iy = (gy + 1.f) * 0.5f * (S - 1);
+        float gx, gy;
+        if (grid) {
+            const float2 gg = *reinterpret_cast<const float2*>(grid + ((long)y * S + x) * 2);
+            gx = gg.x; gy = gg.y;
+        } else {
+            float xn = (2.f * x) / (S - 1) - 1.f;
+            float yn = (2.f * y) / (S - 1) - 1.f;
+            gx = t00 * xn + t01 * yn + t02;
+            gy = t10 * xn + t11 * yn + t12;
+        }
+        const float half = 0.5f * (float)(S - 1);
+        float ix = __fmul_rn(__fadd_rn(gx, 1.f), half);
+        float iy = __fmul_rn(__fadd_rn(gy, 1.f), half);
         float fx0 = floorf(ix), fy0 = floorf(iy);
         int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
         float wx1 = ix - fx0, wx0 = 1.f - wx1, wy1 = iy - fy0, wy0 = 1.f - wy1;
@@ -1274,19 +1287,24 @@ __global__ void affine_warp_kernel(float* __restrict__ out, const float* __restr
         bool okx0 = x0 >= 0 && x0 < S, okx1 = x1 >= 0 && x1 < S, oky0 = y0 >= 0 && y0 < S, oky1 = y1 >= 0 && y1 < S;
 #pragma unroll
         for (int c = 0; c < 3; ++c) {
-            float v = 0.f;
-            if (oky0 && okx0) v += base[((long)y0 * S + x0) * pstride + c] * (wy0 * wx0);
-            if (oky0 && okx1) v += base[((long)y0 * S + x1) * pstride + c] * (wy0 * wx1);
-            if (oky1 && okx0) v += base[((long)y1 * S + x0) * pstride + c] * (wy1 * wx0);
-            if (oky1 && okx1) v += base[((long)y1 * S + x1) * pstride + c] * (wy1 * wx1);
+            // torch's CPU grid_sample: nw_val * nw + ne_val * ne + sw_val * sw + se_val * se, compiled to one multiply and three
+            // fused multiply-adds in that order (bit-exact against F.grid_sample on the same grid: tests/test_gpu_ops.py)
+            const float vnw = (oky0 && okx0) ? base[((long)y0 * S + x0) * pstride + c] : 0.f;
+            const float vne = (oky0 && okx1) ? base[((long)y0 * S + x1) * pstride + c] : 0.f;
+            const float vsw = (oky1 && okx0) ? base[((long)y1 * S + x0) * pstride + c] : 0.f;
+            const float vse = (oky1 && okx1) ? base[((long)y1 * S + x1) * pstride + c] : 0.f;
+            float v = __fmul_rn(vnw, __fmul_rn(wy0, wx0));
+            v = __fmaf_rn(vne, __fmul_rn(wy0, wx1), v);
+            v = __fmaf_rn(vsw, __fmul_rn(wy1, wx0), v);
+            v = __fmaf_rn(vse, __fmul_rn(wy1, wx1), v);
             acc[c] = v;
         }
         float* o = out + i * 3;
         o[0] = acc[0]; o[1] = acc[1]; o[2] = acc[2];
     }
 }
-void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* th) {
-    LAUNCH(affine_warp_kernel, grid1d((long)nface * B * S * S), dim3(256), L, out, faces, B, S, nface, th[0], th[1], th[2], th[3],
+void k_affine_warp(const Launch& L, float* out, const float* faces, int B, int S, int nface, const float* th, const float* grid) {
+    LAUNCH(affine_warp_kernel, grid1d((long)nface * B * S * S), dim3(256), L, out, faces, grid, B, S, nface, th[0], th[1], th[2], th[3],
            th[4], th[5]);
 }
 // ------------------------------------------------------------------ feeder augmentations on the device
@@ -1421,14 +1439,21 @@ __global__ void resize_bilinear_ac_kernel(float* __restrict__ out, const float* 
         r /= Wout;
         int y = (int)(r % Hout);
         long n = r / Hout;
-        float fy = sy * y, fx = sx * x;
-        int y0 = (int)fy, x0 = (int)fx;
+        // the source index is a ROUNDED fp32 product in torch (area_pixel_compute_source_index); left to the compiler, `fy - y0` contracts
+        // into fma(sy, y, -y0) on the unrounded product and the weights move by up to an ulp of the index (7e-6 at 96 -> 112)
+        float fy = __fmul_rn(sy, (float)y), fx = __fmul_rn(sx, (float)x);
+        int y0 = min((int)fy, Hin - 1), x0 = min((int)fx, Win - 1);
         int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
-        float ly = fy - y0, lx = fx - x0;
+        float ly = fminf(fmaxf(__fsub_rn(fy, (float)y0), 0.f), 1.f), lx = fminf(fmaxf(__fsub_rn(fx, (float)x0), 0.f), 1.f);
         const float* p = in + n * (long)Hin * Win * C + c;
         float v00 = p[((long)y0 * Win + x0) * C], v01 = p[((long)y0 * Win + x1) * C];
         float v10 = p[((long)y1 * Win + x0) * C], v11 = p[((long)y1 * Win + x1) * C];
-        out[i] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+        // torch's CPU upsample_bilinear2d (UpSampleKernel.cpp Interpolate<2>): out = t0 * w0; out += t1 * w1 per dimension, compiled
+        // as fma(t0, w0, t1 * w1) — bit-exact against F.interpolate(align_corners=True) (tests/test_gpu_ops.py)
+        const float lx0 = 1.f - lx, ly0 = 1.f - ly;
+        const float top = __fmaf_rn(v00, lx0, __fmul_rn(v01, lx));
+        const float bot = __fmaf_rn(v10, lx0, __fmul_rn(v11, lx));
+        out[i] = __fmaf_rn(top, ly0, __fmul_rn(bot, ly));
     }
 }
 void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C) {

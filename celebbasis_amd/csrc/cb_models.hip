@@ -512,7 +512,7 @@ static Ten* first_stage_faces(Graph& G, Trainer* T, const Batch& bt) {
     const TrainerCfg& c = T->cfg;
     const int NF = 2 * bt.B, S_ = c.image_size;
     Ten* warped = G.make(NF, S_, S_, 3, false, DT_F32);
-    k_affine_warp(G.L, warped->pf(), bt.faces, bt.B, S_, 2, kTheta);
+    k_affine_warp(G.L, warped->pf(), bt.faces, bt.B, S_, 2, kTheta, T->ctx->warp_grid_for(S_));
     Ten* small = G.make(NF, c.fr_in, c.fr_in, 3, false, DT_F32);
     k_resize_bilinear_ac(G.L, small->pf(), warped->pf(), NF, S_, S_, c.fr_in, c.fr_in, 3);
     return frnet_forward(G, T->fr, small);

@@ -175,6 +175,7 @@ class EmbeddingManagerId:
         fr = self.meta_id_net.id_model.native(dev)
         f = faces.to(dev).float().contiguous()
         warped = torch.empty(k * B, S, S, 3, device=dev); small = torch.empty(k * B, fr.in_size, fr.in_size, 3, device=dev)
+        ctx.ensure_warp_grid(S)
         _lib.check(L.cb_face_warp_resize(ctx.h, _lib.ptr(f), _lib.ptr(warped), _lib.ptr(small), B, S, k, fr.in_size))
         feat = fr.forward(small)
         Wm, bm = self.meta_id_net.weight.data.to(dev).float().contiguous(), self.meta_id_net.bias.data.to(dev).float().contiguous()

@@ -43,7 +43,7 @@ class CBError(RuntimeError):
 
 
 # ---------------------------------------------------------------- C structs (mirror include/celebbasis_hip.h)
-ABI_VERSION = 300        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
+ABI_VERSION = 301        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
 
 
 class _Sized(C.Structure):
@@ -110,7 +110,7 @@ ABI_SYMBOLS = [
     "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm", "cb_debug_glds_safe",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
-    "cb_q_sample", "cb_mse_loss", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
+    "cb_q_sample", "cb_mse_loss", "cb_ctx_set_warp_grid", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
     "cb_nhwc_to_nchw", "cb_unet_create", "cb_unet_destroy", "cb_unet_forward", "cb_unet_backward_context", "cb_vae_create",
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
@@ -138,7 +138,7 @@ _ARGTYPES = {
     "cb_timestep_embedding": [_P, _P, _P, _I, _I],
     "cb_q_sample": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I],
     "cb_mse_loss": [_P, _P, _P, _P, _P, _I, _I, _I],
-    "cb_face_warp_resize": [_P, _P, _P, _P, _I, _I, _I, _I],
+    "cb_face_warp_resize": [_P, _P, _P, _P, _I, _I, _I, _I], "cb_ctx_set_warp_grid": [_P, _P, _I],
     "cb_row_surgery": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _L],
     "cb_adamw_step": [_P, _P, _P, _P, _P, _L, _P, _F, _F, _F, _F, _F],
     "cb_nchw_to_nhwc": [_P, _P, _P, _I, _I, _I, _I], "cb_nhwc_to_nchw": [_P, _P, _P, _I, _I, _I, _I],
@@ -205,6 +205,10 @@ def ptr(t, dtype=torch.float32):
     return C.c_void_p(t.data_ptr())
 
 
+# meta_net.py:131-142 `trans_matrix` (the '/512' is the reference's own): FFHQ-aligned crop -> ArcFace-aligned crop
+WARP_TRANS_MATRIX = [[1.07695457, -0.03625215, -1.56352194 / 512], [0.03625215, 1.07695457, -5.32134629 / 512]]
+
+
 class Context:
     """cb_ctx wrapper. device=None -> current torch device + current stream; device=-1 -> dry context (no GPU).
     dtype: 'f32' (BASELINE config 2, the reference's arithmetic) or 'bf16' (config 3: bf16 storage + bf16 MFMA for the frozen
@@ -229,6 +233,21 @@ class Context:
 
     def sync(self):
         check(load().cb_ctx_sync(self.h))
+
+    def ensure_warp_grid(self, S):
+        """Hand the library the face warp's sampling grid as a constant table (cb_ctx_set_warp_grid). The reference evaluates
+        F.affine_grid(trans_matrix.repeat(B,1,1), size, align_corners=True) on every step (meta_net.py:253-257) — from a constant
+        matrix (:131-142) at a constant size, so it is a table like the beta schedule: built here ONCE, on the host, by the very
+        call the reference makes, and uploaded. The kernel then samples at the reference's own fp32 coordinates instead of
+        re-deriving them in another evaluation order (two ulps of a 512-pixel coordinate = 3e-5 on a white-noise face)."""
+        S = int(S)
+        if getattr(self, "_warp_S", None) == S:
+            return
+        M = torch.tensor([WARP_TRANS_MATRIX], dtype=torch.float32)
+        grid = torch.nn.functional.affine_grid(M, size=[1, 3, S, S], align_corners=True)[0].contiguous()     # [S, S, 2], host fp32
+        check(load().cb_ctx_set_warp_grid(self.h, C.c_void_p(grid.data_ptr()), C.c_int(S)))
+        self._warp_S = S
+        self.warp_grid_host = grid
 
     def aux_stream(self):
         """the library's side stream as a torch stream (for Tensor.record_stream); None on a dry context"""
@@ -544,6 +563,7 @@ class Trainer(_Handle):
         self.cfg.dtype = ctx.dtype          # the frozen networks follow the context's element type
         self.h = C.c_void_p()
         check(load().cb_trainer_create(ctx.h, wtab.h, C.byref(self.cfg), C.byref(self.h)))
+        ctx.ensure_warp_grid(self.cfg.image_size)
 
     def step(self, image, faces, ids, tokens, t, noise, post_noise, lr):
         b = Batch()

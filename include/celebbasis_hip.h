@@ -58,7 +58,7 @@ const char* cb_last_error(void);
  * a binding compares the two at load time (celebbasis_amd/lib.py does). Every descriptor struct that has grown since 100 starts with
  * `struct_size` = sizeof(the struct as the CALLER compiled it); the library rejects any other size with CB_ERR_ARG instead of
  * reading fields the caller never wrote. */
-#define CB_ABI_VERSION 300
+#define CB_ABI_VERSION 301
 int cb_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -75,6 +75,12 @@ int cb_ctx_sync(cb_ctx* ctx);
  * peak step-arena bytes, bytes held by the persistent pool (weights + packs + optimiser state) */
 int cb_ctx_stats(cb_ctx* ctx, double* gemm_flops, int64_t* launches, int64_t* arena_peak_bytes, int64_t* pool_bytes);
 int cb_ctx_reset_stats(cb_ctx* ctx);
+/* The face warp's sampling grid as a constant table (meta_net.py:131-142, 253-257: F.affine_grid of a constant matrix at a constant
+ * S x S size). host_grid = [S][S][2] fp32 (x, y) normalised coordinates exactly as the caller's host evaluates them; copied to the
+ * device, kept by the context and consumed by every later warp at that S (cb_face_warp_resize, cb_trainer_step / _prefetch). Without
+ * it (or at another S) the kernel derives the grid analytically from the same matrix — equal up to two fp32 ulps of a coordinate.
+ * host_grid = NULL drops the table. */
+int cb_ctx_set_warp_grid(cb_ctx* ctx, const float* host_grid, int S);
 /* debug taps: named intermediates of the last graph-level call (valid until the next call) */
 int cb_ctx_set_debug_taps(cb_ctx* ctx, int enable);
 int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems, int64_t* numel);

@@ -9,6 +9,7 @@ instead of on the CPU oracle:
     python oracle/gen_horizon.py fp32pert -> horizon_sd14_b1_pert.pt  `fp32` with every step's MLP gradient perturbed by 4e-5 relative noise
     python oracle/gen_horizon.py fp32long -> horizon_sd14_b1_800.pt   `fp32` continued to 800 steps (config 2's own length; 3.5 h)
     python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 800 steps of the same stream with low-pass ("photo-like") face crops (2.5 h)
+    python oracle/gen_horizon.py fp32photo2 / fp32photo3 -> horizon_sd14_b1_photo{2,3}.pt  the same with other frozen weights and another batch stream
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
@@ -41,6 +42,12 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # the fp32 stream with LOW-PASS ("photo-like") face crops: the HIP path's 4e-5 step-coefficient difference on the default stream is
             # the fp32 rounding of the warp's sampling coordinate on WHITE-NOISE faces; on smooth faces it is 5e-6 (probe_warp_rounding.py)
             fp32photo=dict(B=1, steps=800, lr=5e-3, seed=8, out="horizon_sd14_b1_photo.pt", grad_steps=(), slim=True, photo=True, coef_steps=200),
+            # two more draws of the 800-step claim (round-4 verdict: one stream, one seed is one sample of a random event): other frozen
+            # weights AND another batch stream; slim fixtures (loss per step, learned rows every 4th step: 0.9 MB each)
+            fp32photo2=dict(B=1, steps=800, lr=5e-3, seed=9, batch_seed0=3000, out="horizon_sd14_b1_photo2.pt", grad_steps=(), slim=True, photo=True,
+                            coef_steps=0, id_coef_stride=4),
+            fp32photo3=dict(B=1, steps=800, lr=5e-3, seed=10, batch_seed0=5000, out="horizon_sd14_b1_photo3.pt", grad_steps=(), slim=True, photo=True,
+                            coef_steps=0, id_coef_stride=4),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 
@@ -64,13 +71,14 @@ def main(which, steps=None):
     W = O.init_weights(shapes, seed=r["seed"])
     st = O.TrainState(W)
     ids = sorted({1 + (b % (m["max_ids"] - 1)) for b in range(r["B"])})
-    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=100, row_stride=ROW_STRIDE, ids=ids, photo=bool(r.get("photo")),
+    seed0 = int(r.get("batch_seed0", 100))
+    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=seed0, id_coef_stride=int(r.get("id_coef_stride", 1)), row_stride=ROW_STRIDE, ids=ids, photo=bool(r.get("photo")),
                         torch=torch.__version__, threads=torch.get_num_threads()),
                loss=[], coef=[], id_coef=[], id_emb_norm=[], gW_rows={}, gb={})
     W0 = st.Wm.clone()
     t0 = time.time()
     for s in range(r["steps"]):
-        batch = make_batch(r["B"], 512, 64, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"], photo=bool(r.get("photo")))
+        batch = make_batch(r["B"], 512, 64, m["clip"]["vocab"], m["placeholder"], seed0 + s, m["max_ids"], photo=bool(r.get("photo")))
         loss, aux = O.train_step(W, st, batch, r["lr"], m["unet"], m["vae"], m["clip"], m["fr"], es=2, inner=512,
                                  placeholder=m["placeholder"], return_aux=True)
         rec["loss"].append(float(loss))
@@ -89,7 +97,7 @@ def main(which, steps=None):
                 # coef_steps: the per-step coefficients are what the kink-crossing analysis reads (the first crossings); beyond that
                 # horizon only the learned (EMA dictionary) rows and the losses are kept — 5 MB instead of 10 for the 800-step run
                 out = dict(cfg=out["cfg"], steps=out["steps"], loss=out["loss"], coef=out["coef"][:r.get("coef_steps", out["steps"])].clone(),
-                           id_coef=out["id_coef"])
+                           id_coef=out["id_coef"][r.get("id_coef_stride", 1) - 1::r.get("id_coef_stride", 1)].clone())   # rows = steps k, 2k, ...
             path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", r["out"])
             torch.save(out, path + ".tmp")
             os.replace(path + ".tmp", path)

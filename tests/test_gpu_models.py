@@ -85,6 +85,36 @@ def test_frnet_mini_vs_reference_golden(cb, golden_dir):
     close("frnet_mini.features", out, fx["out"], 1e-4)
 
 
+def test_frnet_mini_without_the_lds_dma_kernels(golden_dir):
+    """CB_F32_GLDS=0 (the documented A/B switch, read once per process) sends every conv the register-staged kernel can run to it; that
+    kernel has no PReLU / second-output epilogue, so the FR backbone's fused epilogues must run DE-FUSED there (plain conv + the
+    per-channel passes) instead of failing — and give the same features as the golden (round-4 advisor finding). Own process: the
+    switch is latched at first use."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "from celebbasis_amd import lib\n"
+        "from oracle import cb_oracle as O\n"
+        "fx = torch.load(%r, weights_only=False); c = fx['cfg']\n"
+        "W = O.init_weights(O.frnet_param_shapes(c), seed=fx['weight_seed'])\n"
+        "ctx = lib.Context(); ctx.reset_stats()\n"
+        "f = lib.FrNet(ctx, lib.WeightTable(W), layers=c['layers'], width=c['width'], in_size=c['in_size'], feat=c['feat'])\n"
+        "out = f.forward(fx['x'].permute(0, 2, 3, 1).contiguous().cuda()); ctx.sync()\n"
+        "err = (out.cpu() - fx['out']).abs().max().item() / fx['out'].abs().max().item()\n"
+        "print('FRNET_NOGLDS', err, ctx.stats()['launches'])\n" % (root, os.path.join(golden_dir, "frnet_mini.pt")))
+    outs = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, cwd=root, env=dict(os.environ, CB_F32_GLDS=mode))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        line = [l for l in r.stdout.splitlines() if l.startswith("FRNET_NOGLDS")][-1].split()
+        outs[mode] = (float(line[1]), int(line[2]))
+        assert outs[mode][0] <= 1e-4, (mode, outs)
+    assert outs["0"][1] > outs["1"][1], f"CB_F32_GLDS=0 did not change the launch count: the switch is not exercised ({outs})"
+    REPORT["frnet_mini.without_lds_dma"] = dict(rel_err=outs["0"][0], launches=outs["0"][1], launches_fused=outs["1"][1])
+
+
 def test_clip_mini_vs_hf_golden_and_backward(cb, golden_dir):
     from oracle import cb_oracle as O
     lib, ctx = cb

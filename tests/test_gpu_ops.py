@@ -413,8 +413,24 @@ def test_glue_ops_vs_oracle(cb, golden_dir):
     wref, sref = O.face_warp_resize(cat, 112)
     warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
     lib.check(L.cb_face_warp_resize(ctx.h, HOLD(faces), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
-    close("face.warp", warped.permute(0, 3, 1, 2), wref, 1e-4)   # 4-tap bilinear, different association than ATen
+    close("face.warp", warped.permute(0, 3, 1, 2), wref, 1e-4)   # analytic grid: coordinates within two fp32 ulps of torch's
     close("face.resize", small.permute(0, 3, 1, 2), sref, 1e-4)
+    # with the reference's own sampling grid as a constant table (cb_ctx_set_warp_grid; meta_net.py:253-257) the warp samples at
+    # torch's coordinates and follows grid_sample's / interpolate's operation order: BIT-EXACT, at the real 512 x 512 size too
+    import hashlib
+    for S in (96, 512):
+        faces = torch.rand(Bf, S, S, 6, generator=torch.Generator().manual_seed(5)) * 2 - 1
+        wref, sref = O.face_warp_resize(torch.cat(faces.chunk(2, -1), 0), 112)
+        ctx.ensure_warp_grid(S)
+        warped = torch.empty(2 * Bf, S, S, 3, device=_dev()); small = torch.empty(2 * Bf, 112, 112, 3, device=_dev())
+        lib.check(L.cb_face_warp_resize(ctx.h, HOLD(faces), lib.ptr(warped), lib.ptr(small), Bf, S, 2, 112))
+        ctx.sync()
+        dw = (warped.permute(0, 3, 1, 2).cpu() - wref).abs().max().item(); ds = (small.permute(0, 3, 1, 2).cpu() - sref).abs().max().item()
+        print(f"[warp grid table] S={S}: warp max diff {dw:.3g}, resize max diff {ds:.3g}; host grid sha1 "
+              f"{hashlib.sha1(ctx.warp_grid_host.numpy().tobytes()).hexdigest()[:12]} (cpu capability {torch.backends.cpu.get_cpu_capability()})")
+        assert torch.equal(warped.permute(0, 3, 1, 2).cpu(), wref), f"warp with the reference's grid table is not bit-exact at S={S} ({dw:.3g})"
+        assert torch.equal(small.permute(0, 3, 1, 2).cpu(), sref), f"resize after the table warp is not bit-exact at S={S} ({ds:.3g})"
+    L.cb_ctx_set_warp_grid(ctx.h, None, 0); ctx._warp_S = None
     # row surgery: bit-exact against the reference golden cases (copies only)
     for i, case in enumerate(torch.load(os.path.join(golden_dir, "shift_rows.pt"), weights_only=False)):
         toks = case["tokens"][None].contiguous().to(_dev())
