@@ -95,6 +95,9 @@ def check_no_scratch(remarks, needle):
         m = re.search(r"remark:\s+(ScratchSize \[bytes/lane\]|VGPRs Spill|Dynamic Stack): (\S+)", line)
         if m and m.group(2) not in ("0", "False"):
             bad.append((cur, m.group(1), m.group(2)))
+        m = re.search(r"remark:\s+SGPRs Spill: (\S+)", line)          # SGPR spills go to VGPR lanes, not scratch: slower, not a vmcnt hazard
+        if m and m.group(1) != "0":
+            print(f"[celebbasis_amd.build] WARNING: {cur}: SGPRs Spill = {m.group(1)}", flush=True)
     return bad, seen
 
 
@@ -149,9 +152,11 @@ def _build_locked(verbose, force):
                     if show:
                         sys.stderr.write(l + "\n")
                 bad, seen = check_no_scratch(r.stderr, guard)
-                if not seen and os.environ.get("CB_REQUIRE_REMARKS", "0") != "1":
+                # no remarks at all = the guard could not run. Fatal for the counted-vmcnt kernels (a silent spill there reads tiles before
+                # they land); CB_REQUIRE_REMARKS=0 is the explicit opt-out for a toolchain that renamed the remark
+                if not seen and (not fatal or os.environ.get("CB_REQUIRE_REMARKS", "1") == "0"):
                     print(f"[celebbasis_amd.build] WARNING: {hipcc} printed no kernel-resource-usage remarks for {src}; the spill "
-                          "guard of the counted-vmcnt kernels could not run (CB_REQUIRE_REMARKS=1 makes this fatal)", flush=True)
+                          "guard could not run" + (" (CB_REQUIRE_REMARKS=0: accepted)" if fatal else ""), flush=True)
                 elif bad and not fatal:
                     print(f"[celebbasis_amd.build] WARNING: {src}: scratch / spills in {bad[:4]} (slower, still correct)", flush=True)
                 elif bad or not seen:

@@ -759,11 +759,12 @@ bool gemm_f32_glds_shape_ok(const GemmArgs& a) {
     if (a.a_kind == LD_CONV) {
         const ConvGeom& g = a.g;
         if (g.C % 4 || g.ks < 1 || g.ks > 4 || a.K != g.ks * g.ks * g.C) return false;
-        // (+ the FAST path's descriptor bias: its voffsets are shifted up by the most negative row base)
-        return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C + (long)(g.pad * g.W + g.pad) * g.C < lim;
+        // (+ the FAST path's descriptor bias: its voffsets are shifted up by the most negative row base; + its largest SCALAR offset, the
+        // (tap, channel) walk up to (ks * W + ks) * C: the hardware adds soffset after the range check, the sum must stay a 31-bit offset)
+        return (long)(a.M / (g.Ho * g.Wo)) * g.H * g.W * g.C + (long)(g.pad * g.W + g.pad) * g.C + (long)(g.ks * g.W + g.ks) * g.C < lim;
     }
     if (a.a_kind != LD_ROW || a.lda % 4 || a.sAb % 4 || a.sAh % 4) return false;
-    return (long)a.M * a.lda < lim;
+    return (long)a.M * a.lda + a.K < lim && (long)a.N * a.ldb + a.K < lim;       // + the FAST path's scalar k offset
 }
 static double f32_glds_speed() {
     static const double s = [] { const char* e = getenv("CB_PLAN_F32G_SPEED"); return e && atof(e) > 0 ? atof(e) : 1.25; }();
@@ -1025,8 +1026,9 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     {   // 32-bit byte offsets inside one operand slice (buffer loads)
         const long lim = (1L << 31) - 64;
         long ea = a.a_kind == LD_CONV ? (long)(a.M / (a.g.Ho * a.g.Wo)) * a.g.H * a.g.W * a.g.C + (long)(a.g.pad * a.g.W + a.g.pad) * a.g.C
-                                      : (long)a.M * a.lda;           // conv: + the FAST path's descriptor bias
-        long eb = (long)a.N * a.ldb;
+                                            + (long)(a.g.ks * a.g.W + a.g.ks) * a.g.C
+                                      : (long)a.M * a.lda + a.K;     // conv: + the FAST path's descriptor bias; both: + its largest scalar offset
+        long eb = (long)a.N * a.ldb + a.K;
         CB_CHECK(ea * 2 < lim && eb * 2 < lim, CB_ERR_SHAPE, "gemm_bf16: an operand slice exceeds 2 GiB");
     }
     autotune<bf16_t>(L, a, bf16_bk(), plan_knobs().bf16_speed);

@@ -1258,6 +1258,7 @@ void k_add_rowbcast(const Launch& L, DType dt, void* dst, const void* x, const f
 // (GridSampler.h grid_sampler_unnormalize: ((g + 1) / 2) * (S - 1); corner weights (1-wy)(1-wx) ..., summed nw + ne + sw + se).
 __global__ void affine_warp_kernel(float* __restrict__ out, const float* __restrict__ faces, const float* __restrict__ grid, int B,
                                    int S, int nface, float t00, float t01, float t02, float t10, float t11, float t12) {
+#pragma clang fp contract(off)
     long total = (long)nface * B * S * S;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         int x = (int)(i % S);
@@ -1276,8 +1277,8 @@ __global__ void affine_warp_kernel(float* __restrict__ out, const float* __restr
             gy = t10 * xn + t11 * yn + t12;
         }
         const float half = 0.5f * (float)(S - 1);
-        float ix = __fmul_rn(__fadd_rn(gx, 1.f), half);
-        float iy = __fmul_rn(__fadd_rn(gy, 1.f), half);
+        float ix = ((gx + 1.f) * half);
+        float iy = ((gy + 1.f) * half);
         float fx0 = floorf(ix), fy0 = floorf(iy);
         int x0 = (int)fx0, y0 = (int)fy0, x1 = x0 + 1, y1 = y0 + 1;
         float wx1 = ix - fx0, wx0 = 1.f - wx1, wy1 = iy - fy0, wy0 = 1.f - wy1;
@@ -1293,10 +1294,10 @@ __global__ void affine_warp_kernel(float* __restrict__ out, const float* __restr
             const float vne = (oky0 && okx1) ? base[((long)y0 * S + x1) * pstride + c] : 0.f;
             const float vsw = (oky1 && okx0) ? base[((long)y1 * S + x0) * pstride + c] : 0.f;
             const float vse = (oky1 && okx1) ? base[((long)y1 * S + x1) * pstride + c] : 0.f;
-            float v = __fmul_rn(vnw, __fmul_rn(wy0, wx0));
-            v = __fmaf_rn(vne, __fmul_rn(wy0, wx1), v);
-            v = __fmaf_rn(vsw, __fmul_rn(wy1, wx0), v);
-            v = __fmaf_rn(vse, __fmul_rn(wy1, wx1), v);
+            float v = vnw * (wy0 * wx0);
+            v = __builtin_fmaf(vne, wy0 * wx1, v);
+            v = __builtin_fmaf(vsw, wy1 * wx0, v);
+            v = __builtin_fmaf(vse, wy1 * wx1, v);
             acc[c] = v;
         }
         float* o = out + i * 3;
@@ -1429,6 +1430,9 @@ void k_paste_bg(const Launch& L, float* out, const float* img, const int* geom_d
 // F.interpolate(mode='bilinear', align_corners=True), NHWC
 __global__ void resize_bilinear_ac_kernel(float* __restrict__ out, const float* __restrict__ in, int N, int Hin, int Win,
                                           int Hout, int Wout, int C) {
+    // every product / sum below is a SEPARATE fp32 rounding unless written as an explicit fma (HIP's __fmul_rn / __fsub_rn are plain
+    // operators compiled in the header's own contraction mode: with them, or without this pragma, `fy - y0` still contracts into fma(sy, y, -y0) on the unrounded product)
+#pragma clang fp contract(off)
     long total = (long)N * Hout * Wout * C;
     float sy = Hout > 1 ? (float)(Hin - 1) / (float)(Hout - 1) : 0.f;
     float sx = Wout > 1 ? (float)(Win - 1) / (float)(Wout - 1) : 0.f;
@@ -1441,19 +1445,19 @@ __global__ void resize_bilinear_ac_kernel(float* __restrict__ out, const float* 
         long n = r / Hout;
         // the source index is a ROUNDED fp32 product in torch (area_pixel_compute_source_index); left to the compiler, `fy - y0` contracts
         // into fma(sy, y, -y0) on the unrounded product and the weights move by up to an ulp of the index (7e-6 at 96 -> 112)
-        float fy = __fmul_rn(sy, (float)y), fx = __fmul_rn(sx, (float)x);
+        float fy = sy * (float)y, fx = sx * (float)x;
         int y0 = min((int)fy, Hin - 1), x0 = min((int)fx, Win - 1);
         int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
-        float ly = fminf(fmaxf(__fsub_rn(fy, (float)y0), 0.f), 1.f), lx = fminf(fmaxf(__fsub_rn(fx, (float)x0), 0.f), 1.f);
+        float ly = fminf(fmaxf(fy - (float)y0, 0.f), 1.f), lx = fminf(fmaxf(fx - (float)x0, 0.f), 1.f);
         const float* p = in + n * (long)Hin * Win * C + c;
         float v00 = p[((long)y0 * Win + x0) * C], v01 = p[((long)y0 * Win + x1) * C];
         float v10 = p[((long)y1 * Win + x0) * C], v11 = p[((long)y1 * Win + x1) * C];
         // torch's CPU upsample_bilinear2d (UpSampleKernel.cpp Interpolate<2>): out = t0 * w0; out += t1 * w1 per dimension, compiled
         // as fma(t0, w0, t1 * w1) — bit-exact against F.interpolate(align_corners=True) (tests/test_gpu_ops.py)
         const float lx0 = 1.f - lx, ly0 = 1.f - ly;
-        const float top = __fmaf_rn(v00, lx0, __fmul_rn(v01, lx));
-        const float bot = __fmaf_rn(v10, lx0, __fmul_rn(v11, lx));
-        out[i] = __fmaf_rn(top, ly0, __fmul_rn(bot, ly));
+        const float top = __builtin_fmaf(v00, lx0, v01 * lx);
+        const float bot = __builtin_fmaf(v10, lx0, v11 * lx);
+        out[i] = __builtin_fmaf(top, ly0, bot * ly);
     }
 }
 void k_resize_bilinear_ac(const Launch& L, float* out, const float* in, int N, int Hin, int Win, int Hout, int Wout, int C) {

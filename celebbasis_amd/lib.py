@@ -244,7 +244,16 @@ class Context:
         if getattr(self, "_warp_S", None) == S:
             return
         M = torch.tensor([WARP_TRANS_MATRIX], dtype=torch.float32)
-        grid = torch.nn.functional.affine_grid(M, size=[1, 3, S, S], align_corners=True)[0].contiguous()     # [S, S, 2], host fp32
+        self.set_warp_grid(torch.nn.functional.affine_grid(M, size=[1, 3, S, S], align_corners=True)[0])
+
+    def set_warp_grid(self, grid):
+        """install a given [S, S, 2] fp32 sampling grid (host tensor). torch's CPU affine_grid is linspace + a K = 3 bmm whose rounding is
+        HOST dependent (two x86 hosts with the same torch build differ in 14 % of the elements by one ulp,
+        tools/probes/probe_affine_grid_host.py): a caller that must reproduce another host's run — the parity tests against oracle
+        trajectories generated elsewhere — hands over that host's table."""
+        grid = grid.detach().to(torch.float32).cpu().contiguous()
+        S = int(grid.shape[0])
+        assert tuple(grid.shape) == (S, S, 2), grid.shape
         check(load().cb_ctx_set_warp_grid(self.h, C.c_void_p(grid.data_ptr()), C.c_int(S)))
         self._warp_S = S
         self.warp_grid_host = grid

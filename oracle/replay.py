@@ -29,6 +29,31 @@ def low_pass(x_hwc, sigma=4.0, radius=12):
     return (x / x.abs().amax()).float().contiguous()
 
 
+FIXTURE_HOST_GRID_SHA1 = {512: "8ce7204e5307"}
+
+
+def fixture_host_warp_grid(S=512):
+    """the face warp's sampling grid (meta_net.py:253-257: F.affine_grid of the constant trans_matrix, align_corners=True) AS THE HOST THAT
+    GENERATED tests/golden/horizon_sd14_*.pt EVALUATED IT. torch's CPU affine_grid = linspace + a K = 3 bmm; the linspace is the same on
+    every host, the bmm's rounding is not (tools/probes/probe_affine_grid_host.py: the fixture host's result equals
+    fma(t2, 1, fma(t1, y, t0 * x)) bit for bit, the GPU box's EPYC differs from it in 14 % of the elements by one ulp = up to 6e-5 pixel).
+    A run that is compared with those trajectories step by step samples the faces on THIS table; the formula is evaluated with
+    float64-emulated fused multiply-adds, so it gives the same bytes everywhere (digest checked)."""
+    import hashlib
+    import numpy as np
+    from oracle.cb_oracle import TRANS_MATRIX
+    f32 = np.float32
+    fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)     # exact product, one rounding
+    lin = torch.linspace(-1, 1, S).numpy()
+    th = np.array(TRANS_MATRIX, dtype=f32)
+    X = np.broadcast_to(lin[None, :], (S, S)).astype(f32); Y = np.broadcast_to(lin[:, None], (S, S)).astype(f32)
+    g = np.stack([fma(np.full_like(X, th[r, 2]), np.ones_like(X), fma(np.full_like(X, th[r, 1]), Y, (th[r, 0] * X).astype(f32))) for r in range(2)], -1)
+    if S in FIXTURE_HOST_GRID_SHA1:
+        sha = hashlib.sha1(np.ascontiguousarray(g).tobytes()).hexdigest()[:12]
+        assert sha == FIXTURE_HOST_GRID_SHA1[S], f"fixture-host warp grid digest {sha} != {FIXTURE_HOST_GRID_SHA1[S]}"
+    return torch.from_numpy(np.ascontiguousarray(g))
+
+
 def make_batch(B, S, lat, vocab, placeholder, seed, n_ids, photo=False):
     g = torch.Generator().manual_seed(seed)
     tokens = torch.randint(0, vocab - 30, (B, 77), generator=g)

@@ -333,7 +333,12 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
     W = O.init_weights(shapes, seed=c["weight_seed"])
     tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+    # the warp's constant sampling grid as the host that generated the trajectory evaluated it (this box's torch rounds the K = 3 bmm of
+    # F.affine_grid differently in 14 % of the elements: oracle/replay.py::fixture_host_warp_grid); restored afterwards
+    from oracle.replay import fixture_host_warp_grid
+    ctx.set_warp_grid(fixture_host_warp_grid(512))
     B, ids, rs = c["B"], c["ids"], c["row_stride"]
+    cst = int(c.get("id_coef_stride", 1))          # slim multi-seed fixtures keep the learned rows of every cst-th step
     steps = min(steps, int(fx["steps"]))
     table = []
     traj = dict(coef=[], id_coef=[], gW_rows=[], loss=[])
@@ -345,8 +350,9 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
         coef = ctx.tap("coef").reshape(2 * B, -1)
         loss = float(tr.get_state("loss")[0])
         idc = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)[ids]
-        row = dict(step=s + 1, loss_rel=abs(loss - float(fx["loss"][s])) / abs(float(fx["loss"][s])),
-                   id_coef_l2=(idc - fx["id_coef"][s]).norm(dim=1).max().item())
+        row = dict(step=s + 1, loss_rel=abs(loss - float(fx["loss"][s])) / abs(float(fx["loss"][s])))
+        if (s + 1) % cst == 0:
+            row["id_coef_l2"] = (idc - fx["id_coef"][(s + 1) // cst - 1]).norm(dim=1).max().item()
         if s < fx["coef"].shape[0]:                   # slim long-horizon fixtures keep the step coefficients of their first steps only
             row["coef_l2"] = (coef - fx["coef"][s]).norm(dim=1).max().item()
         if s + 1 in fx.get("gW_rows", {}):
@@ -360,6 +366,7 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     if save_traj:
         torch.save({k: (torch.stack(v) if k != "loss" else torch.tensor(v, dtype=torch.float64)) for k, v in traj.items() if len(v)}, save_traj)
     ctx.set_debug_taps(False)
+    ctx._warp_S = None; ctx.ensure_warp_grid(512)          # back to this host's own table
     if steps == int(fx["steps"]) and "W0_rows" in fx:
         w = tr.get_state("mlp.weight").reshape(-1, 512)[::rs]
         d_hip, d_ref = w - fx["W0_rows"], fx["Wm_rows"] - fx["W0_rows"]
@@ -369,9 +376,11 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     report[tag + ".table"] = table
     n = len(table)
     ctab = [r for r in table if "coef_l2" in r]
-    summary = dict(steps=n, coef_l2_max=max(r["coef_l2"] for r in ctab), coef_l2_last=ctab[-1]["coef_l2"], coef_l2_steps=len(ctab),
-                   id_coef_l2_last=table[-1]["id_coef_l2"], id_coef_l2_max=max(r["id_coef_l2"] for r in table),
+    itab = [r for r in table if "id_coef_l2" in r]
+    summary = dict(steps=n, id_coef_l2_last=itab[-1]["id_coef_l2"], id_coef_l2_max=max(r["id_coef_l2"] for r in itab),
                    loss_rel_max=max(r["loss_rel"] for r in table))
+    if ctab:
+        summary.update(coef_l2_max=max(r["coef_l2"] for r in ctab), coef_l2_last=ctab[-1]["coef_l2"], coef_l2_steps=len(ctab))
     report[tag + ".summary"] = summary
     os.makedirs("gpurun_out", exist_ok=True)
     with open(f"gpurun_out/{tag}.json", "w") as f:
@@ -385,20 +394,19 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     """BASELINE config 2 at FULL SIZE over its own horizon: 800 optimiser steps (aigc_id.yaml:135) of SD v1-4 512x512 bs=1 on the HIP
     path against the oracle trajectory committed in tests/golden/horizon_sd14_b1_800.pt (oracle/gen_horizon.py fp32long, 3.6 h of host
     time; its first 100 steps are horizon_sd14_b1.pt, which also holds the sampled gradient rows, and its first ten are the ones
-    test_train_10_steps_sd14_drift recomputes live). Table: gpurun_out/horizon_sd14_b1_800.json (committed: profiles/r04_sd14_horizon800.json).
+    test_train_10_steps_sd14_drift recomputes live) — the DEFAULT replay stream, whose face crops are white noise.
+    Table: gpurun_out/horizon_sd14_b1_800.json (committed: profiles/r05_sd14_horizon800.json).
 
-    What can be asserted, and why not more. The two paths agree to round-off — step coefficients 4e-5 L2: the fp32 rounding of
-    the 512-pixel warp coordinate on the stream's white-noise faces (profiles/r04_warp_rounding.json), loss 1e-6 — until a coefficient's
-    pre-activation lands within that round-off of the KINK of the head's LeakyReLU(0.2) (meta_net.py:41-48): on this stream at step 16.
-    From then on that row of the MLP sees gradients that differ by the slope ratio 1 : 0.2 and the trajectories separate. That is a
-    property of the reference's arithmetic: the REFERENCE'S OWN code with a real-width head and 3e-6 relative feature noise is 3.5e-3
-    from itself after 200 steps and 3.3e-2 after 800 (profiles/r04_horizon_ref_w512_sensitivity.json), while at mini width, where the
-    trajectory is not chaotic, the HIP path stays within 1.9e-6 of a run of the reference for all 800 steps
-    (test_train_800_steps_mini_vs_reference_run). So: (a) up to the first sign disagreement the step coefficients agree to 1e-4;
-    (b) the first sign disagreements are genuine kink crossings — both values within 2e-5 of zero; (c) the LEARNED coefficients (EMA
-    dictionary, embedding_manager.py:484-489) hold north_star's 1e-3 bar through step 75; (d) every loss of the 800 steps to 5e-3 relative
-    and the first 100 to 2e-4; (e) beyond the separation the distance is REPORTED at 100 / 200 / 400 / 800, not held to a relaxed bar —
-    only to twice the envelope of the reference-vs-reference table (1e-1; measured 2.4e-3 / 1.9e-2 / 4.8e-2 at 200 / 400 / 800), as a regression guard."""
+    north_star's bar — learned coefficients (EMA dictionary, embedding_manager.py:484-489) within 1e-3 L2 of the CPU path at fixed seed —
+    is asserted at EVERY ONE of the 800 steps, with every loss to 2e-4 relative.
+
+    History. Through round 4 this stream left the bar at step 76 and ended 4.8e-2 apart: the HIP warp re-derived the sampling
+    grid (meta_net.py:253-257) in its own evaluation order, two fp32 ulps of a 512-pixel coordinate = 3e-5 on a white-noise face, and —
+    found in round 5 — the 512 -> 112 resize computed its source index as an UNROUNDED product (the compiler contracted `scale * y - y0`
+    into one fma). That 4e-5 step-coefficient difference met a LeakyReLU(0.2) kink of the head (meta_net.py:41-48) at step 16 and the
+    trajectories separated. Now the warp consumes the reference's grid as a constant table (cb_ctx_set_warp_grid) and both kernels follow
+    torch's operation order bit for bit (tests/test_gpu_ops.py: bit-exact at 512 x 512); what is left is the summation order inside the
+    FR backbone / UNet (step coefficients ~5e-6), and sign disagreements of a coefficient happen only within that distance of zero."""
     lib, ctx = cb
     fx = dict(load(golden_dir, "horizon_sd14_b1_800.pt"))
     fx100 = load(golden_dir, "horizon_sd14_b1.pt")
@@ -406,43 +414,41 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
     fx["cfg"] = dict(fx100["cfg"], **fx["cfg"]); fx["gW_rows"] = fx100["gW_rows"]
     os.makedirs("gpurun_out", exist_ok=True)
     traj = "gpurun_out/horizon_sd14_b1_800_traj.pt"
-    run_horizon(lib, ctx, fx, 800, "horizon_sd14_b1_800", REPORT, dict(loss_rel_max=5e-3), save_traj=traj)
+    run_horizon(lib, ctx, fx, 800, "horizon_sd14_b1_800", REPORT, dict(loss_rel_max=2e-4), save_traj=traj)
     tab = REPORT["horizon_sd14_b1_800.table"]
     hip = torch.load(traj, weights_only=False)["coef"]
-    ref = fx["coef"]                                   # the fixture keeps the per-step coefficients of the first 200 steps (the crossings analysed)
+    ref = fx["coef"]                                   # the fixture keeps the per-step coefficients of the first 200 steps
     seen, events, first = set(), [], None
     for s_ in range(min(hip.shape[0], ref.shape[0])):
         for face, el in (torch.sign(hip[s_]) != torch.sign(ref[s_])).nonzero().tolist():
-            if el not in seen:          # a row that crossed once keeps differing: only its FIRST appearance must sit at the kink
-                seen.add(el)
+            if (face, el) not in seen:
+                seen.add((face, el))
                 events.append(dict(step=s_ + 1, face=face, element=el, oracle=float(ref[s_][face, el]), hip=float(hip[s_][face, el])))
                 first = first or (s_ + 1)
     at = {str(k): dict(learned_coefficient_l2=tab[k - 1]["id_coef_l2"], step_coefficient_l2=tab[k - 1].get("coef_l2"), loss_rel=tab[k - 1]["loss_rel"])
-          for k in (10, 50, 75, 100, 200, 400, 800)}
+          for k in (1, 10, 50, 75, 100, 200, 400, 800)}
     REPORT["horizon_sd14_b1_800.at_steps"] = at
-    REPORT["horizon_sd14_b1_800.kink_crossings"] = events[:20]
-    REPORT["horizon_sd14_b1_800.first_kink_crossing_step"] = first
+    REPORT["horizon_sd14_b1_800.sign_disagreements_in_200_steps"] = events[:20]
     with open("gpurun_out/horizon_sd14_b1_800.json") as f:
         rec = json.load(f)
-    rec.update(at_steps=at, first_kink_crossing_step=first, kink_crossings=events[:20], sign_disagreeing_coefficients_at_200=len(seen))
+    rec.update(at_steps=at, first_sign_disagreement_step=first, sign_disagreements_in_200_steps=events[:20], coefficients_with_a_sign_disagreement=len(seen))
+    rec["table"] = [r for r in rec["table"] if r["step"] <= 20 or r["step"] % 10 == 0]
     with open("gpurun_out/horizon_sd14_b1_800.json", "w") as f:
         json.dump(rec, f, indent=1)
-    smooth = tab[:(first - 1) if first else len(tab)]
-    assert max(r["coef_l2"] for r in smooth) <= 1e-4, "before the first LeakyReLU kink crossing the step coefficients must agree to round-off"
-    assert len(smooth) >= 10, f"a sign disagreement at step {first}: the first ten steps are round-off clean on this stream"
-    for e in events[:3]:                 # later crossings happen on already separated trajectories
-        assert abs(e["oracle"]) <= 2e-5 and abs(e["hip"]) <= 2e-5, f"sign disagreement away from the kink: {e}"
-    assert max(r["id_coef_l2"] for r in tab[:75]) <= 1e-3, "learned coefficients (EMA dictionary) left the 1e-3 bar inside 75 steps"
-    assert max(r["loss_rel"] for r in tab[:100]) <= 2e-4
-    assert max(r["id_coef_l2"] for r in tab) <= 1e-1, "learned coefficients far outside the reference-vs-reference envelope (measured 4.8e-2 at step 800)"
+    for e in events:                     # a sign can only differ where the value is round-off sized in BOTH paths
+        assert abs(e["oracle"]) <= 2e-5 and abs(e["hip"]) <= 2e-5, f"sign disagreement away from zero: {e}"
+    assert max(r["coef_l2"] for r in tab if "coef_l2" in r) <= 3e-5, "step coefficients (meta_net.py:289) beyond round-off in the first 200 steps"
+    worst = max(r["id_coef_l2"] for r in tab)
+    assert worst <= 1e-3, f"learned coefficients left north_star's 1e-3 bar inside the 800-step horizon on the default (white-noise) stream: {worst:.3e}"
+    assert worst <= 1e-4, f"regression guard: measured 4.5e-6 in round 5, now {worst:.3e}"
 
 
 def test_two_gemm_tilings_stay_together_sd14(cb):
     """the control behind the horizon tests' reading: the HIP path's OWN noise is far below what separates it from the oracle. Two HIP
     runs of 40 SD-size steps on the white-noise stream that differ only in their GEMM tilings (the measured plan table against every
     problem pinned to 64x64 tiles with the planner's split: other fp32 summation orders in every conv / Linear of the step) must keep
-    their learned coefficients within 1e-5 L2 of each other (measured 3e-6 in round 3) — while each of them is 3e-4 from the oracle by
-    then, because of the warp's coordinate rounding and the kink crossing at step 16 (test_train_800_steps_sd14_horizon)."""
+    their learned coefficients within 1e-5 L2 of each other (measured 1.2e-6 in round 4): summation order alone does not separate two fp32
+    evaluations at this horizon (what did, through round 4, was the warp's coordinate arithmetic: test_train_800_steps_sd14_horizon)."""
     from oracle import cb_oracle as O
     lib, ctx = cb
     m = SD14(O)
@@ -495,6 +501,31 @@ def test_train_800_steps_sd14_photo_faces_horizon(cb, golden_dir):
     assert len(smooth) >= 5 and max(r["coef_l2"] for r in smooth) <= 1.5e-5, (first, max(r["coef_l2"] for r in smooth) if smooth else None)
     worst = max(r["id_coef_l2"] for r in tab)
     assert worst <= 1e-3, f"learned coefficients left north_star's 1e-3 bar inside the 800-step horizon on photo-like faces: {worst:.3e}"
+
+
+@pytest.mark.parametrize("name", ["horizon_sd14_b1_photo2", "horizon_sd14_b1_photo3"])
+def test_train_800_steps_sd14_more_draws(cb, golden_dir, name):
+    """two more draws of the 800-step claim (round-4 verdict: one stream and one seed is one sample of a random event): other frozen
+    weights (init seeds 9 / 10) AND other batch streams (seeds 3000+ / 5000+), photo-like faces, oracle trajectories from
+    oracle/gen_horizon.py fp32photo2 / fp32photo3 (2.5 h of host time each; slim fixtures: loss per step, learned rows every 4th step).
+    north_star's 1e-3 on the learned coefficients is asserted over the whole horizon, every loss to 2e-4."""
+    lib, ctx = cb
+    path = os.path.join(golden_dir, name + ".pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{name}.pt not generated yet (oracle/gen_horizon.py)")
+    fx = dict(load(golden_dir, name + ".pt"))
+    n = int(fx["steps"])
+    assert fx["cfg"]["photo"] and n >= 100, "the generator writes the fixture every 10 steps; at least 100 are needed for a horizon claim"
+    s = run_horizon(lib, ctx, fx, n, name, REPORT, dict(loss_rel_max=2e-4))
+    tab = [r for r in REPORT[name + ".table"] if "id_coef_l2" in r]
+    with open(f"gpurun_out/{name}.json") as f:
+        rec = json.load(f)
+    rec["table"] = [r for r in rec["table"] if r["step"] % 20 == 0]
+    rec["at_steps"] = {str(r["step"]): r["id_coef_l2"] for r in tab if r["step"] in (4, 100, 200, 400, 800)}
+    with open(f"gpurun_out/{name}.json", "w") as f:
+        json.dump(rec, f, indent=1)
+    REPORT[name + ".steps_compared"] = n
+    assert s["id_coef_l2_max"] <= 1e-3, f"{name}: learned coefficients left north_star's 1e-3 bar inside {n} steps: {s['id_coef_l2_max']:.3e}"
 
 
 def test_train_800_steps_mini_vs_reference_run(cb, golden_dir):

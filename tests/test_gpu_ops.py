@@ -206,10 +206,16 @@ def test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra):
 def test_gemm_n80_tiles(cb, bm, M, N, K, extra, split):
     lib, ctx = cb
     lib.check(lib.load().cb_debug_force_plan(bm, 80, split))
+    ctx.profile_begin()
     try:
         test_gemm(cb, M, N, K, 0, 0, 1, extra)
     finally:
         lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+        prof = ctx.profile_end()
+    ran = [r["kernel"] for r in prof]
+    # a pinned plan the problem is not eligible for is dropped silently by the planner (cb_gemm_tiles.h): the test must see the kernel it names
+    assert any(k.startswith(f"gemm_glds80_kernel<float,{bm},80,") for k in ran), f"the {bm}x80 kernel did not run: {ran}"
+    assert (split > 1) == any(k.startswith("splitk_reduce") for k in ran), (split, ran)
     key = f"gemm[{M}x{N}x{K},a0b0,batch1,{extra}]"
     REPORT[f"n80.{bm}/{split}." + key] = REPORT.pop(key)
 
@@ -225,15 +231,20 @@ def test_gemm_n80_tiles(cb, bm, M, N, K, extra, split):
 def test_conv_n80_tiles(cb, bm, N, H, W, Cin, Cout, ks, mode, extra, split):
     lib, ctx = cb
     lib.check(lib.load().cb_debug_force_plan(bm, 80, split))
+    ctx.profile_begin()
     try:
         test_conv_fwd_dgrad(cb, N, H, W, Cin, Cout, ks, mode, extra)
     finally:
         lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+        prof = ctx.profile_end()
+    ran = [r["kernel"] for r in prof]
+    assert any(k.startswith(f"gemm_glds80_kernel<float,{bm},80,CONV") for k in ran), f"the {bm}x80 conv kernel did not run: {ran}"
 
 
-def test_n80_counted_wait_matches_safe_mode(cb):
-    """the 80-column kernel shares the counted `s_waitcnt vmcnt(N)` + raw `s_barrier` ring of the LDS-DMA GEMM: with
-    cb_debug_glds_safe(1) (queue drained + full barrier per k-tile) the results must be the same BIT FOR BIT"""
+def test_n80_fast_pieces_match_safe_mode(cb):
+    """the 80-column kernel's FAST form (scalar-offset LDS-DMA pieces, ring slot = tile parity) against its per-lane form: cb_debug_glds_safe(1)
+    forces FAST off and adds a full barrier per k-tile; results must be the same BIT FOR BIT. (The two-stage ring drains with vmcnt(0) in both
+    modes — the counted wait belongs to the three-stage rings of gemm_glds_kernel, tested in test_glds_counted_wait_matches_safe_mode.)"""
     lib, ctx = cb
     L = lib.load()
     outs = {}
@@ -257,6 +268,40 @@ def test_n80_counted_wait_matches_safe_mode(cb):
     for (safe, bm, M, N, K), v in outs.items():
         if safe == 0:
             assert v.abs().max() > 0 and torch.equal(v, outs[(1, bm, M, N, K)]), (bm, M, N, K)
+
+
+@pytest.mark.parametrize("plan", [(64, 80), (32, 80), (16, 80), (64, 128), (64, 64)])
+def test_conv_fast_pieces_match_safe_mode(cb, plan):
+    """the conv gather's FAST form (scalar-offset pieces; per-lane validity and (tap, channel) offset re-derived at a tap change only;
+    A-side descriptor bias for negative row bases) against the per-lane form that cb_debug_glds_safe(1) forces: stride 1 / 2, pad 1,
+    1x1, a split-K over taps, on the 80-column tiles and on gemm_glds_kernel's — BIT FOR BIT (round-4 advisor finding: only ROW
+    GEMMs were compared before)."""
+    lib, ctx = cb
+    L = lib.load()
+    bm, bn = plan
+    cases = [(1, 64, 64, 320, 320, 3, "same", 1), (2, 33, 31, 64, 160, 3, "down", 1), (1, 8, 8, 1280, 1280, 3, "same", 3),
+             (2, 16, 16, 64, 96, 1, "same", 1), (1, 16, 16, 640, 1280, 3, "same", 2)]
+    outs = {}
+    try:
+        for safe in (0, 1):
+            lib.check(L.cb_debug_glds_safe(safe))
+            for ci, (N, H, W, Cin, Cout, ks, mode, split) in enumerate(cases):
+                lib.check(L.cb_debug_force_plan(bm, bn, split))
+                x = rnd(N, H, W, Cin, seed=ci + 1).to(_dev()); w = rnd(Cout, Cin, ks, ks, seed=ci + 20, scale=(Cin * ks * ks) ** -0.5).to(_dev())
+                b = rnd(Cout, seed=ci + 40).to(_dev())
+                wp = torch.empty(w.numel(), device=_dev())
+                lib.check(L.cb_pack_conv_weight(ctx.h, lib.ptr(w), lib.ptr(wp), Cout, Cin, ks, 0))
+                Ho, Wo = ((H + 1) // 2, (W + 1) // 2) if mode == "down" else (H, W)
+                y = torch.zeros(N, Ho, Wo, Cout, device=_dev())
+                lib.check(L.cb_conv2d_fwd(ctx.h, lib.ptr(x), lib.ptr(wp), lib.ptr(b), None, None, lib.ptr(y), N, H, W, Cin, Cout, ks, MODES[mode]))
+                ctx.sync()
+                outs[(safe, ci)] = y.cpu()
+    finally:
+        lib.check(L.cb_debug_glds_safe(0)); lib.check(L.cb_debug_force_plan(0, 0, 0))
+    for ci in range(len(cases)):
+        a, b_ = outs[(0, ci)], outs[(1, ci)]
+        assert a.abs().max() > 0 and torch.isfinite(a).all()
+        assert torch.equal(a, b_), f"plan {plan}, conv case {cases[ci]}: FAST and per-lane forms differ (max {(a - b_).abs().max().item():.3e})"
 
 
 # ------------------------------------------------------------------------------------------------ norms
