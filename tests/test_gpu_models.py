@@ -437,10 +437,10 @@ def test_train_800_steps_sd14_horizon(cb, golden_dir):
         json.dump(rec, f, indent=1)
     for e in events:                     # a sign can only differ where the value is round-off sized in BOTH paths
         assert abs(e["oracle"]) <= 2e-5 and abs(e["hip"]) <= 2e-5, f"sign disagreement away from zero: {e}"
-    assert max(r["coef_l2"] for r in tab if "coef_l2" in r) <= 3e-5, "step coefficients (meta_net.py:289) beyond round-off in the first 200 steps"
+    assert max(r["coef_l2"] for r in tab if "coef_l2" in r) <= 2e-5, "step coefficients (meta_net.py:289) beyond round-off in the first 200 steps (measured 4.7e-6)"
     worst = max(r["id_coef_l2"] for r in tab)
     assert worst <= 1e-3, f"learned coefficients left north_star's 1e-3 bar inside the 800-step horizon on the default (white-noise) stream: {worst:.3e}"
-    assert worst <= 1e-4, f"regression guard: measured 4.5e-6 in round 5, now {worst:.3e}"
+    assert worst <= 5e-5, f"regression guard: measured 2.0e-6 in round 5 (step coefficients 4.7e-6), now {worst:.3e}"
 
 
 def test_two_gemm_tilings_stay_together_sd14(cb):
