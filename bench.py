@@ -162,11 +162,21 @@ def timed_loop(run, steps, warmup, world, dist, dev, dry):
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
+    PER_RANK.clear()
     if world > 1:
+        # every rank's own clock next to the MAX the contract asks for (a slow GPU / a late rank shows up in the line itself), plus its HBM use
+        free, total = (0, 0) if dry else torch.cuda.mem_get_info()
+        mine = torch.tensor([elapsed, float(total - free) / 2 ** 30], device=dev, dtype=torch.float64)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        PER_RANK.extend(dict(rank=r, elapsed_s=round(float(t[0]), 4), hbm_used_gib=round(float(t[1]), 2)) for r, t in enumerate(every))
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     return elapsed
+
+
+PER_RANK = []
 
 
 def profile_step(ctx, run, peak_tflops, bf16=False):
@@ -354,6 +364,20 @@ def main():
     elapsed = 1.0 if only3 else timed_loop(run, args.steps, args.warmup, world, dist, dev, dry)
     loss = None if (dry or only3) else float(tr.get_state("loss")[0])
 
+    # ---- secondary measurement (rank 0, N == 1): the same K steps with the whole-step HIP-graph replay switched off (eager launches).
+    # `value` is measured on the library's default, which replays the captured graph (cb_trainer_set_graph_replay; bitwise identical).
+    graph_stats, eager = (None if dry else tr.graph_stats()), None
+    if rank == 0 and world == 1 and not dry and not only3 and graph_stats and graph_stats["replays"] > 0:
+        tr.set_graph_replay(False)
+        for i in range(2):
+            run(i)
+        torch.cuda.synchronize(); te = time.perf_counter()
+        for i in range(args.steps):
+            run(2 + i)
+        torch.cuda.synchronize(); el = time.perf_counter() - te
+        tr.set_graph_replay(True)
+        eager = dict(steps_per_s=round(args.steps / el, 4), ms_per_step=round(el / args.steps * 1e3, 3), note="graph replay off: ~1 650 launches enqueued one by one")
+
     # ---- secondary measurement (rank 0, not the headline `value`): the same K steps with the first stage of batch i+1
     # (VAE encode + FR backbone, no gradients) prefetched on its own stream under the UNet of batch i (cb_trainer_prefetch).
     # Every timed iteration still executes one VAE encode, one FR pass and one full step; results are bitwise identical.
@@ -410,8 +434,10 @@ def main():
             "step_tflops_per_gpu": round(st["gemm_flops"] / 1e12 / (ms_per_step * 1e-3), 2),
             "loss": loss,
             "phase_ms": phases,
+            "graph_replay": dict(graph_stats, eager=eager) if graph_stats else None,
             "pipelined": pipelined,
             "merged_identities": merged_identities,
+            "per_rank": list(PER_RANK) or None,
             "build": tree_stamp(),
             "roofline": roofline,
         }

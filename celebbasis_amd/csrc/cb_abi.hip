@@ -864,6 +864,19 @@ int cb_trainer_step(cb_trainer* t, const cb_batch* b, float lr) {
     CB_END
 }
 
+int cb_trainer_set_graph_replay(cb_trainer* t, int enable) {
+    CB_TRY
+    require(t, "trainer");
+    trainer_set_graph_replay(&t->T, enable != 0);
+    CB_END
+}
+int cb_trainer_graph_stats(cb_trainer* t, int64_t* captures, int64_t* replays) {
+    CB_TRY
+    require(t, "trainer");
+    if (captures) *captures = t->T.graph.captures;
+    if (replays) *replays = t->T.graph.replays;
+    CB_END
+}
 int cb_trainer_prefetch(cb_trainer* t, const cb_batch* b) {
     CB_TRY
     require(t, "trainer"); require(b, "batch");

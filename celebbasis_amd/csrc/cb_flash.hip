@@ -113,13 +113,10 @@ __device__ __forceinline__ void fl_load_rowregs(float (&reg)[FlCfg<DT>::KS], con
 }
 
 // ---------------------------------------------------------------------------------------------- forward
-// NB = number of LDS tile pairs. NB = 1: store -> barrier -> compute -> barrier per streamed tile. NB = 2 (round 5): tile i+1 is written
-// into the other pair while tile i is computed on — ONE barrier per tile, the global prefetch runs two tiles ahead.
-template <int DT, int NB>
+template <int DT>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PAIR = 2 * C::TK * C::S2;
     float* Ks = lds;                         // [TK][S2]
     float* Vs = lds + C::TK * C::S2;         // [TK][S2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
@@ -149,40 +146,14 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
     fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
     fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
-    if constexpr (NB == 2) {
-        if (kbeg < kend) {
-            fl_store<DT>(Ks, pk, st);
-            fl_store<DT>(Vs, pv, st);
-            if (kbeg + C::TK < kend) {
-                fl_prefetch<DT>(pk, srdK, st, kbeg + C::TK, a.Nk, a.ldk);
-                fl_prefetch<DT>(pv, srdV, st, kbeg + C::TK, a.Nk, a.ldk);
-            }
-        }
-        __syncthreads();
-    }
-    int par = 0;
     for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
-        if constexpr (NB == 2) {
-            // pair `par` holds tile k0 (written before the last barrier); the registers hold tile k0 + TK: into the other pair, which
-            // every wave finished reading before that barrier; then fetch tile k0 + 2 TK
-            if (k0 + C::TK < kend) {
-                fl_store<DT>(lds + (par ^ 1) * PAIR, pk, st);
-                fl_store<DT>(lds + (par ^ 1) * PAIR + C::TK * C::S2, pv, st);
-                if (k0 + 2 * C::TK < kend) {
-                    fl_prefetch<DT>(pk, srdK, st, k0 + 2 * C::TK, a.Nk, a.ldk);
-                    fl_prefetch<DT>(pv, srdV, st, k0 + 2 * C::TK, a.Nk, a.ldk);
-                }
-            }
-            Ks = lds + par * PAIR; Vs = Ks + C::TK * C::S2;
-        } else {
-            __syncthreads();
-            fl_store<DT>(Ks, pk, st);
-            fl_store<DT>(Vs, pv, st);
-            __syncthreads();
-            if (k0 + C::TK < kend) {
-                fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
-                fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
-            }
+        __syncthreads();
+        fl_store<DT>(Ks, pk, st);
+        fl_store<DT>(Vs, pv, st);
+        __syncthreads();
+        if (k0 + C::TK < kend) {
+            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
         }
         f32x4 s[C::NT];
 #pragma unroll
@@ -237,7 +208,6 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
                     float av = Vs[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
                     o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[kt][r], o[t], 0, 0, 0);
                 }
-        if constexpr (NB == 2) { __syncthreads(); par ^= 1; }
     }
     if (a.ksplit > 1) {                                // partial: unnormalised O relative to the running max m, and (m, l)
         if (qrow < a.Nq) {
@@ -284,11 +254,10 @@ __global__ __launch_bounds__(256) void flash_dvec_kernel(const FlashArgs a, int 
 }
 
 // ---------------------------------------------------------------------------------------------- backward: dQ
-template <int DT, int NB>
+template <int DT>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PAIR = 2 * C::TK * C::S2;
     float* Ks = lds;
     float* Vs = lds + C::TK * C::S2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
@@ -331,38 +300,14 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
     fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
     fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
-    if constexpr (NB == 2) {
-        if (kbeg < kend) {
-            fl_store<DT>(Ks, pk, st);
-            fl_store<DT>(Vs, pv, st);
-            if (kbeg + C::TK < kend) {
-                fl_prefetch<DT>(pk, srdK, st, kbeg + C::TK, a.Nk, a.ldk);
-                fl_prefetch<DT>(pv, srdV, st, kbeg + C::TK, a.Nk, a.ldk);
-            }
-        }
-        __syncthreads();
-    }
-    int par = 0;
     for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
-        if constexpr (NB == 2) {
-            if (k0 + C::TK < kend) {
-                fl_store<DT>(lds + (par ^ 1) * PAIR, pk, st);
-                fl_store<DT>(lds + (par ^ 1) * PAIR + C::TK * C::S2, pv, st);
-                if (k0 + 2 * C::TK < kend) {
-                    fl_prefetch<DT>(pk, srdK, st, k0 + 2 * C::TK, a.Nk, a.ldk);
-                    fl_prefetch<DT>(pv, srdV, st, k0 + 2 * C::TK, a.Nk, a.ldk);
-                }
-            }
-            Ks = lds + par * PAIR; Vs = Ks + C::TK * C::S2;
-        } else {
-            __syncthreads();
-            fl_store<DT>(Ks, pk, st);
-            fl_store<DT>(Vs, pv, st);
-            __syncthreads();
-            if (k0 + C::TK < kend) {
-                fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
-                fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
-            }
+        __syncthreads();
+        fl_store<DT>(Ks, pk, st);
+        fl_store<DT>(Vs, pv, st);
+        __syncthreads();
+        if (k0 + C::TK < kend) {
+            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
         }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
@@ -399,7 +344,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
                     float ak = Ks[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
                     g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, s[kt][r], g[t], 0, 0, 0);
                 }
-        if constexpr (NB == 2) { __syncthreads(); par ^= 1; }
     }
     if (a.ksplit > 1) {
         if (qrow < a.Nq) {
@@ -432,11 +376,10 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
 //   dP[q][key]   = dO V^T        A = dO tile (K-style), B = V^T regs
 //   dV^T[d][key] += dO^T P       A = dO tile (V-style), B = P regs
 //   dK^T[d][key] += Q^T dS       A = Q tile (V-style),  B = dS regs
-template <int DT, int NB>
+template <int DT>
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int PAIR = 2 * C::TK * C::S2 + 2 * C::TK;     // Q tile, dO tile, lse[TK], D[TK]
     float* Qs = lds;                              // [TK][S2]
     float* Ds = lds + C::TK * C::S2;              // dO tile [TK][S2]
     float* Ls = lds + 2 * C::TK * C::S2;          // lse[TK], D[TK]
@@ -467,58 +410,19 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     float4 pq[FlTile<DT>::N], pd[FlTile<DT>::N];
     fl_prefetch<DT>(pq, srdQ, stq, qbeg, a.Nq, a.ldq);
     fl_prefetch<DT>(pd, srdD, sto, qbeg, a.Nq, a.ldo);
-    // the per-query scalars of a tile (lse, D) ride along: threads < TK hold the NEXT tile's pair in registers
-    float nl = 0.f, nd = 0.f;
-    auto load_ld = [&](int q0) {
+    for (int q0 = qbeg; q0 < qlim; q0 += C::TK) {
+        __syncthreads();
+        fl_store<DT>(Qs, pq, stq);
+        fl_store<DT>(Ds, pd, sto);
         if (threadIdx.x < C::TK) {
-            const int qi = q0 + threadIdx.x;
-            nl = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
-            nd = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
-        }
-    };
-    if constexpr (NB == 2) {
-        if (qbeg < qlim) {
-            fl_store<DT>(Qs, pq, stq);
-            fl_store<DT>(Ds, pd, sto);
-            load_ld(qbeg);
-            if (threadIdx.x < C::TK) { Ls[threadIdx.x] = nl; Ls[C::TK + threadIdx.x] = nd; }
-            if (qbeg + C::TK < qlim) {
-                fl_prefetch<DT>(pq, srdQ, stq, qbeg + C::TK, a.Nq, a.ldq);
-                fl_prefetch<DT>(pd, srdD, sto, qbeg + C::TK, a.Nq, a.ldo);
-                load_ld(qbeg + C::TK);
-            }
+            int qi = q0 + threadIdx.x;
+            Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
+            Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
         }
         __syncthreads();
-    }
-    int par = 0;
-    for (int q0 = qbeg; q0 < qlim; q0 += C::TK) {
-        if constexpr (NB == 2) {
-            if (q0 + C::TK < qlim) {
-                float* nx = lds + (par ^ 1) * PAIR;
-                fl_store<DT>(nx, pq, stq);
-                fl_store<DT>(nx + C::TK * C::S2, pd, sto);
-                if (threadIdx.x < C::TK) { nx[2 * C::TK * C::S2 + threadIdx.x] = nl; nx[2 * C::TK * C::S2 + C::TK + threadIdx.x] = nd; }
-                if (q0 + 2 * C::TK < qlim) {
-                    fl_prefetch<DT>(pq, srdQ, stq, q0 + 2 * C::TK, a.Nq, a.ldq);
-                    fl_prefetch<DT>(pd, srdD, sto, q0 + 2 * C::TK, a.Nq, a.ldo);
-                    load_ld(q0 + 2 * C::TK);
-                }
-            }
-            Qs = lds + par * PAIR; Ds = Qs + C::TK * C::S2; Ls = Qs + 2 * C::TK * C::S2;
-        } else {
-            __syncthreads();
-            fl_store<DT>(Qs, pq, stq);
-            fl_store<DT>(Ds, pd, sto);
-            if (threadIdx.x < C::TK) {
-                int qi = q0 + threadIdx.x;
-                Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
-                Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
-            }
-            __syncthreads();
-            if (q0 + C::TK < qlim) {
-                fl_prefetch<DT>(pq, srdQ, stq, q0 + C::TK, a.Nq, a.ldq);
-                fl_prefetch<DT>(pd, srdD, sto, q0 + C::TK, a.Nq, a.ldo);
-            }
+        if (q0 + C::TK < qlim) {
+            fl_prefetch<DT>(pq, srdQ, stq, q0 + C::TK, a.Nq, a.ldq);
+            fl_prefetch<DT>(pd, srdD, sto, q0 + C::TK, a.Nq, a.ldo);
         }
         f32x4 s[C::NT], dp[C::NT];
 #pragma unroll
@@ -559,7 +463,6 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
                     gv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s[qt][r], gv[t], 0, 0, 0);
                     gk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dp[qt][r], gk[t], 0, 0, 0);
                 }
-        if constexpr (NB == 2) { __syncthreads(); par ^= 1; }
     }
     if (a.nsplit > 1) {
         if (krow < a.Nk) {
@@ -720,29 +623,16 @@ template <int DT> static size_t fl_lds_bytes(bool dkv) {
     using C = FlCfg<DT>;
     return (size_t)(2 * C::TK * C::S2 + (dkv ? 2 * C::TK : 0)) * sizeof(float);
 }
-// LDS tile pairs per block: 2 = one barrier per streamed tile (round 5; CB_FLASH_NB=1 restores the two-barrier form for A/B runs)
-static int fl_nb() {
-    static const int nb = [] { const char* e = getenv("CB_FLASH_NB"); return (e && e[0] == '1') ? 1 : 2; }();
-    return nb;
-}
 
-#define FL_LAUNCH(KERNEL, DTV, NBV, GRID, LDSB, ...)                                                                  \
-    {                                                                                                                \
-        const size_t lb_ = LDSB(DTV) * NBV;                                                                          \
-        set_dyn_lds(reinterpret_cast<const void*>(&KERNEL<DTV, NBV>), (int)lb_);                                     \
-        hipLaunchKernelGGL((KERNEL<DTV, NBV>), GRID, dim3(256), lb_, L.stream, __VA_ARGS__);                         \
-    }
-#define FL_DISPATCH_NB(NBV, DTV, KERNEL, GRID, LDSB, ...)                                                             \
-    switch (DTV) {                                                                                                   \
-        case 1: FL_LAUNCH(KERNEL, 1, NBV, GRID, LDSB, __VA_ARGS__) break;                                            \
-        case 2: FL_LAUNCH(KERNEL, 2, NBV, GRID, LDSB, __VA_ARGS__) break;                                            \
-        case 3: FL_LAUNCH(KERNEL, 3, NBV, GRID, LDSB, __VA_ARGS__) break;                                            \
-        case 4: FL_LAUNCH(KERNEL, 4, NBV, GRID, LDSB, __VA_ARGS__) break;                                            \
-        case 5: FL_LAUNCH(KERNEL, 5, NBV, GRID, LDSB, __VA_ARGS__) break;                                            \
-        default: FL_LAUNCH(KERNEL, 10, NBV, GRID, LDSB, __VA_ARGS__) break;                                          \
-    }
 #define FL_DISPATCH(DTV, KERNEL, GRID, LDSB, ...)                                                                     \
-    if (fl_nb() == 2) { FL_DISPATCH_NB(2, DTV, KERNEL, GRID, LDSB, __VA_ARGS__) } else { FL_DISPATCH_NB(1, DTV, KERNEL, GRID, LDSB, __VA_ARGS__) }
+    switch (DTV) {                                                                                                   \
+        case 1: hipLaunchKernelGGL(KERNEL<1>, GRID, dim3(256), LDSB(1), L.stream, __VA_ARGS__); break;               \
+        case 2: hipLaunchKernelGGL(KERNEL<2>, GRID, dim3(256), LDSB(2), L.stream, __VA_ARGS__); break;               \
+        case 3: hipLaunchKernelGGL(KERNEL<3>, GRID, dim3(256), LDSB(3), L.stream, __VA_ARGS__); break;               \
+        case 4: hipLaunchKernelGGL(KERNEL<4>, GRID, dim3(256), LDSB(4), L.stream, __VA_ARGS__); break;               \
+        case 5: hipLaunchKernelGGL(KERNEL<5>, GRID, dim3(256), LDSB(5), L.stream, __VA_ARGS__); break;               \
+        default: hipLaunchKernelGGL(KERNEL<10>, GRID, dim3(256), LDSB(10), L.stream, __VA_ARGS__); break;            \
+    }
 
 static int fl_dt(int d) { int dt = (d + 15) / 16; if (dt == 3 && d > 40) dt = 4; return dt <= 5 ? dt : 10; }
 

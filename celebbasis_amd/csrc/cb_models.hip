@@ -457,6 +457,7 @@ Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
 // ================================================================= training step
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     T->ctx = ctx; T->cfg = cfg;
+    { const char* e = getenv("CB_STEP_GRAPH"); T->graph.enabled = !(e && e[0] == '0'); }
     unet_load(ctx, wt, "model.diffusion_model.", cfg.unet, &T->unet);
     vae_load(ctx, wt, "first_stage_model.", cfg.vae, &T->vae);
     clip_load(ctx, wt, "cond_stage_model.transformer.text_model.", cfg.clip, &T->clip);
@@ -719,9 +720,78 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     k_adamw(L, T->b, T->mb, T->vb, T->gb, (long)O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
 }
 
+void trainer_set_graph_replay(Trainer* T, bool on) { T->graph.enabled = on; }
+
+// stage the batch, then replay (or first capture) the step's graph
+static void step_graph(Trainer* T, const Batch& bt, float lr) {
+    Ctx* ctx = T->ctx;
+    const TrainerCfg& c = T->cfg;
+    Trainer::StepGraph& g = T->graph;
+    constexpr int kMaxGraphs = 8;
+    const int B = bt.B, S_ = c.image_size, lat = S_ >> (c.vae.n_mult - 1), zc = c.vae.z_channels, T77 = c.clip.ctx_len;
+    if (!g.image) {
+        g.image = ctx->pool.allocf((size_t)kMaxBatch * S_ * S_ * 3);
+        g.faces = ctx->pool.allocf((size_t)kMaxBatch * S_ * S_ * 6);
+        g.noise = ctx->pool.allocf((size_t)kMaxBatch * zc * lat * lat);
+        g.post_noise = ctx->pool.allocf((size_t)kMaxBatch * zc * lat * lat);
+        g.ids = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * 2 * sizeof(int64_t)));
+        g.tokens = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * T77 * sizeof(int64_t)));
+        g.t = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * sizeof(int64_t)));
+    }
+    hipStream_t s = ctx->stream;
+    auto stage = [&](void* dst, const void* src, size_t bytes) { CB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); };
+    stage(g.image, bt.image, (size_t)B * S_ * S_ * 3 * sizeof(float));
+    stage(g.faces, bt.faces, (size_t)B * S_ * S_ * 6 * sizeof(float));
+    stage(g.noise, bt.noise, (size_t)B * zc * lat * lat * sizeof(float));
+    stage(g.post_noise, bt.post_noise, (size_t)B * zc * lat * lat * sizeof(float));
+    stage(g.ids, bt.ids, (size_t)B * 2 * sizeof(int64_t));
+    stage(g.tokens, bt.tokens, (size_t)B * T77 * sizeof(int64_t));
+    stage(g.t, bt.t, (size_t)B * sizeof(int64_t));
+    Trainer::StepGraph::Entry* e = nullptr;
+    for (auto& x : g.cache) if (x.B == B && x.lr == lr) e = &x;
+    if (!e) {
+        Batch sb;
+        sb.image = g.image; sb.faces = g.faces; sb.ids = g.ids; sb.tokens = g.tokens; sb.t = g.t; sb.noise = g.noise; sb.post_noise = g.post_noise;
+        sb.B = B;
+        hipGraph_t graph = nullptr;
+        ctx->arena.reset();
+        CB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        try { step_impl(T, sb, lr); }
+        catch (...) { (void)hipStreamEndCapture(s, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        CB_HIP(hipStreamEndCapture(s, &graph));
+        hipGraphExec_t exec = nullptr;
+        hipError_t rc = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        CB_HIP(rc);
+        if ((int)g.cache.size() >= kMaxGraphs) {
+            size_t lru = 0;
+            for (size_t i = 1; i < g.cache.size(); ++i) if (g.cache[i].used < g.cache[lru].used) lru = i;
+            CB_HIP(hipStreamSynchronize(s));                 // the evicted graph may still be in flight
+            (void)hipGraphExecDestroy(g.cache[lru].exec);
+            g.cache.erase(g.cache.begin() + lru);
+        }
+        Trainer::StepGraph::Entry ne; ne.B = B; ne.lr = lr; ne.exec = exec;
+        g.cache.push_back(ne);
+        e = &g.cache.back();
+        g.captures++;
+    }
+    e->used = ++g.tick;
+    CB_HIP(hipGraphLaunch(e->exec, s));
+    g.replays++;
+}
+
 void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only) {
     Ctx* ctx = T->ctx;
     CB_CHECK(bt.B >= 1 && bt.B <= kMaxBatch, CB_ERR_ARG, "trainer: batch %d unsupported (1..%d)", bt.B, kMaxBatch);
+    // graph replay from the second step at a batch size on (the first one runs eagerly: it sizes the arena and latches the per-kernel
+    // dynamic-LDS attributes); not while the live profiler is recording (its event pairs are host calls) or debug taps are collected (they are
+    // registered by the host code of an eager step), and not for a batch whose first stage was prefetched (that path waits on a prefetch event the captured graph does not know)
+    if (T->graph.enabled && !ctx->dry && !dry_only && T->arena_B == bt.B && !ctx->prof.on && !ctx->debug_taps) {
+        bool prefetched = false;
+        for (auto& sl : T->pf.slot)
+            if (sl.valid && sl.image == bt.image && sl.faces == bt.faces && sl.post_noise == bt.post_noise && sl.B == bt.B) prefetched = true;
+        if (!prefetched) { step_graph(T, bt, lr); return; }
+    }
     if (ctx->dry || dry_only || T->arena_B != bt.B) {
         bool was_dry = ctx->dry;
         Stats saved = ctx->stats;

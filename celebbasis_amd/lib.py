@@ -43,7 +43,7 @@ class CBError(RuntimeError):
 
 
 # ---------------------------------------------------------------- C structs (mirror include/celebbasis_hip.h)
-ABI_VERSION = 301        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
+ABI_VERSION = 302        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
 
 
 class _Sized(C.Structure):
@@ -115,7 +115,7 @@ ABI_SYMBOLS = [
     "cb_vae_destroy", "cb_vae_encode", "cb_clip_create", "cb_clip_destroy", "cb_clip_embed_tokens", "cb_clip_forward",
     "cb_clip_backward_embeds", "cb_frnet_create", "cb_frnet_destroy", "cb_frnet_forward", "cb_trainer_cfg_default",
     "cb_trainer_create", "cb_trainer_destroy", "cb_trainer_step", "cb_trainer_get_state", "cb_trainer_set_state",
-    "cb_debug_force_plan", "cb_trainer_prefetch", "cb_trainer_prefetch_stream", "cb_trainer_set_prefetch_stream", "cb_trainer_loss_to", "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
+    "cb_debug_force_plan", "cb_trainer_prefetch", "cb_trainer_set_graph_replay", "cb_trainer_graph_stats", "cb_trainer_prefetch_stream", "cb_trainer_set_prefetch_stream", "cb_trainer_loss_to", "cb_celeb_head_forward", "cb_face_augment", "cb_paste_on_canvas", "cb_row_surgery_multi", "cb_trainer_share_unet", "cb_trainer_share_clip", "cb_unet_ddim_sample", "cb_ddim_update", "cb_vae_decoder_create", "cb_vae_decoder_destroy", "cb_vae_decode",
 ]
 
 
@@ -151,7 +151,7 @@ _ARGTYPES = {
     "cb_clip_backward_embeds": [_P, _P, _P],
     "cb_frnet_create": [_P, _P, C.c_char_p, _P, _I, _I, _P], "cb_frnet_destroy": [_P], "cb_frnet_forward": [_P, _P, _I, _P],
     "cb_trainer_cfg_default": [_P], "cb_trainer_create": [_P, _P, _P, _P], "cb_trainer_destroy": [_P],
-    "cb_trainer_step": [_P, _P, _F], "cb_trainer_prefetch": [_P, _P], "cb_trainer_prefetch_stream": [_P, _P], "cb_debug_force_plan": [_I, _I, _I], "cb_trainer_set_prefetch_stream": [_P, _P], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
+    "cb_trainer_step": [_P, _P, _F], "cb_trainer_set_graph_replay": [_P, _I], "cb_trainer_graph_stats": [_P, _P, _P], "cb_trainer_prefetch": [_P, _P], "cb_trainer_prefetch_stream": [_P, _P], "cb_debug_force_plan": [_I, _I, _I], "cb_trainer_set_prefetch_stream": [_P, _P], "cb_trainer_get_state": [_P, C.c_char_p, _P, _L, _P],
     "cb_trainer_set_state": [_P, C.c_char_p, _P, _L], "cb_trainer_loss_to": [_P, _P],
     "cb_row_surgery_multi": [_P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _I],
     "cb_celeb_head_forward": [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _P, _P],
@@ -582,6 +582,15 @@ class Trainer(_Handle):
             b.ids, b.tokens, b.t = ptr(ids, torch.int64), ptr(tokens, torch.int64), ptr(t, torch.int64)
             b.noise, b.post_noise = ptr(noise), ptr(post_noise)
         check(load().cb_trainer_step(self.h, C.byref(b), C.c_float(lr)))
+
+    def set_graph_replay(self, on=True):
+        """whole-step HIP-graph replay (cb_trainer_set_graph_replay); on by default"""
+        check(load().cb_trainer_set_graph_replay(self.h, C.c_int(1 if on else 0)))
+
+    def graph_stats(self):
+        c, r = C.c_int64(), C.c_int64()
+        check(load().cb_trainer_graph_stats(self.h, C.byref(c), C.byref(r)))
+        return dict(captures=c.value, replays=r.value)
 
     def loss_tensor(self, device):
         """the last step's loss as a 0-dim DEVICE tensor, copied in stream order (no host sync)"""

@@ -58,7 +58,7 @@ const char* cb_last_error(void);
  * a binding compares the two at load time (celebbasis_amd/lib.py does). Every descriptor struct that has grown since 100 starts with
  * `struct_size` = sizeof(the struct as the CALLER compiled it); the library rejects any other size with CB_ERR_ARG instead of
  * reading fields the caller never wrote. */
-#define CB_ABI_VERSION 301
+#define CB_ABI_VERSION 302
 int cb_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -295,6 +295,13 @@ typedef struct {
     int B;
 } cb_batch;
 int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
+/* Whole-step HIP-graph replay. From the second step at a batch size on, cb_trainer_step copies the batch into
+ * trainer-owned staging buffers and replays ONE captured graph of the step's ~1 650 launches (both streams) instead of enqueuing them
+ * one by one; a graph is captured per (B, lr) and kept (8 most recent). Same kernels in the same order on the same addresses: results
+ * are bitwise those of the eager path. On by default (environment CB_STEP_GRAPH=0 turns it off); the eager path still serves the first
+ * step at a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from cb_trainer_prefetch. */
+int cb_trainer_set_graph_replay(cb_trainer* t, int enable);
+int cb_trainer_graph_stats(cb_trainer* t, int64_t* captures, int64_t* replays);
 /* Optional software pipelining across steps: enqueue the gradient-free first stage of the NEXT batch (VAE encode -> latent,
  * FR backbone -> face features; only image / faces / post_noise / B of `next` are read) on a library-owned stream so that it
  * overlaps the UNet of the step that is enqueued afterwards. A later cb_trainer_step on the same buffers consumes the result

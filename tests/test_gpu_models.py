@@ -285,6 +285,58 @@ def test_train_step_sd14_vs_oracle(cb):
     run_steps(lib, ctx, full, B=1, steps=1, lr=5e-3, seed=5, check_aux=True)
 
 
+def _graph_vs_eager(lib, ctx, m, seed, script):
+    """run `script` = [(B, lr), ...] twice on fresh trainers — eager launches / HIP-graph replay — and return both end states + the graph counters"""
+    from oracle import cb_oracle as O
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = O.init_weights(shapes, seed=seed)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    out = {}
+    for graph in (False, True):
+        tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+        tr.set_graph_replay(graph)
+        losses = []
+        for s, (B, lr) in enumerate(script):
+            dev = {k: dv(v) for k, v in make_batch(B, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 100 + s, m["max_ids"]).items()}
+            tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], lr)
+            del dev                              # the batch may be freed right after the call: the graph reads its staging copy
+            losses.append(float(tr.get_state("loss")[0]))
+        out[graph] = dict(W=tr.get_state("mlp.weight").clone(), b=tr.get_state("mlp.bias").clone(), idc=tr.get_state("id_coefficients").clone(),
+                          ide=tr.get_state("id_embeddings").clone(), gW=tr.get_state("mlp.grad_weight").clone(), losses=losses, stats=tr.graph_stats())
+        tr.close()
+    return out
+
+
+def test_graph_replay_is_bitwise_the_eager_step_mini(cb):
+    """SURVEY §8 B3 `cb_train_step (whole step, HIP-graph replay)`: the captured graph holds the same kernels in the same order on the same
+    arena addresses, so a run that replays it must end in BITWISE the state of the eager run — across a change of batch size (first step
+    at a size runs eagerly, the second captures) and of learning rate (one graph per (B, lr))."""
+    lib, ctx = cb
+    script = [(1, 5e-3)] * 6 + [(2, 1e-2)] * 4 + [(1, 5e-3)] * 2 + [(1, 2.5e-3)] * 3
+    out = _graph_vs_eager(lib, ctx, MINI, 3, script)
+    e, g = out[False], out[True]
+    assert e["stats"] == dict(captures=0, replays=0), e["stats"]
+    # eager steps: the first at B=1 and the first at B=2; captures: (1, 5e-3), (2, 1e-2), (1, 2.5e-3); every other step is a replay
+    assert g["stats"]["captures"] == 3 and g["stats"]["replays"] == len(script) - 2, g["stats"]
+    assert g["losses"] == e["losses"], (g["losses"], e["losses"])
+    for k in ("W", "b", "idc", "ide", "gW"):
+        assert torch.equal(g[k], e[k]), f"graph replay changed {k}: max diff {(g[k] - e[k]).abs().max().item():.3e}"
+    REPORT["graph_replay.mini"] = g["stats"]
+
+
+def test_graph_replay_is_bitwise_the_eager_step_sd14(cb):
+    """the same at SD v1-4 size, bs=1: 1 eager + 1 capture + 4 replays of the ~1 650-launch, two-stream step"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    out = _graph_vs_eager(lib, ctx, SD14(O), 8, [(1, 5e-3)] * 6)
+    e, g = out[False], out[True]
+    assert g["stats"] == dict(captures=1, replays=5), g["stats"]
+    assert g["losses"] == e["losses"], (g["losses"], e["losses"])
+    for k in ("W", "b", "idc", "ide", "gW"):
+        assert torch.equal(g[k], e[k]), f"graph replay changed {k}: max diff {(g[k] - e[k]).abs().max().item():.3e}"
+    REPORT["graph_replay.sd14"] = g["stats"]
+
+
 SD14 = lambda O: dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
                       placeholder=O.PLACEHOLDER_SKS)
 

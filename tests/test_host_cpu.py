@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(built_lib):
     missing = [s for s in sorted(declared) if not hasattr(built_lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(lib.ABI_SYMBOLS), declared ^ set(lib.ABI_SYMBOLS)
-    assert built_lib.cb_version() == 301          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
+    assert built_lib.cb_version() == 302          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
 
 
 def test_integration_stub_matches_the_library(built_lib):
@@ -36,7 +36,7 @@ def test_integration_stub_matches_the_library(built_lib):
     block = re.search(r"```python\n(# ldm/models/diffusion/native_step.py.*?)```", text, re.S).group(1)
     block = block.replace('C.CDLL("libcelebbasis_hip.so")', f"C.CDLL({built_lib._name!r})")
     ns = {}
-    exec(compile(block, "INTEGRATION.md:native_step", "exec"), ns)          # runs the stub's own `assert lib.cb_version() == 301`
+    exec(compile(block, "INTEGRATION.md:native_step", "exec"), ns)          # runs the stub's own `assert lib.cb_version() == 302`
     so = ns["lib"]
     for name in set(re.findall(r"lib\.(cb_[a-z0-9_]+)", block)):
         assert hasattr(so, name), name
@@ -468,6 +468,30 @@ def test_run_config5_launches_its_own_ranks_and_checks_the_merge():
     r = subprocess.run([sys.executable, script, "--gpus", "2", "--identities", "2", "--dry"], capture_output=True, text=True, timeout=300,
                        env=env, cwd=str(ROOT))
     assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)
+
+
+def test_eight_rank_launch_of_bench_and_config5_dry():
+    """the two 8-GPU forms of BASELINE.json (config 4: 8 identities, one per GPU; config 5: 32 identities, 4 per GPU back to back) as the
+    driver would launch them, on dry contexts with gloo: `python bench.py --gpus 8 --dry` and `python tools/run_config5.py --gpus 8
+    --identities 32 --dry` start their own eight ranks, shard `i -> rank i mod 8`, run the one all_gather of the job and check the merge on
+    rank 0; the bench line carries every rank's own clock (`per_rank`). No 8-GPU node is available to the builder: this is the launcher,
+    sharding, merge and JSON contract at the real world size."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["merged_identities"] == 8 and d["scaling"] == "weak" and d["config"]["global_batch"] == 8
+    assert [p["rank"] for p in d["per_rank"]] == list(range(8)) and all(p["elapsed_s"] > 0 for p in d["per_rank"])
+    assert abs(d["value"] - 8 * d["steps"] / max(p["elapsed_s"] for p in d["per_rank"])) <= 0.02 * d["value"]      # value = whole job / MAX over ranks
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "run_config5.py"), "--gpus", "8", "--identities", "32", "--train-steps", "1", "--dry"],
+                       capture_output=True, text=True, timeout=900, env=env, cwd=str(ROOT))
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 8 and d["merged_identities"] == 32 and d["identities_per_rank"] == [4] * 8 and d["dry"] is True
 
 
 def test_build_guard_flags_scratch_in_counted_wait_kernels():
