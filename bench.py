@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=64, help="host threads for the CPU baseline (reported as `cores`)")
     ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
+    ap.add_argument("--no-graph", action="store_true", help="skip the secondary HIP-graph replay measurement")
     ap.add_argument("--dry", action="store_true", help="no GPU: dry contexts + gloo (launcher / sharding / merge / JSON contract only)")
     args = ap.parse_args()
     maybe_self_launch(args)
@@ -364,19 +365,27 @@ def main():
     elapsed = 1.0 if only3 else timed_loop(run, args.steps, args.warmup, world, dist, dev, dry)
     loss = None if (dry or only3) else float(tr.get_state("loss")[0])
 
-    # ---- secondary measurement (rank 0, N == 1): the same K steps with the whole-step HIP-graph replay switched off (eager launches).
-    # `value` is measured on the library's default, which replays the captured graph (cb_trainer_set_graph_replay; bitwise identical).
-    graph_stats, eager = (None if dry else tr.graph_stats()), None
-    if rank == 0 and world == 1 and not dry and not only3 and graph_stats and graph_stats["replays"] > 0:
+    # ---- secondary measurement (rank 0, N == 1; never `value`): the same K steps through the opt-in whole-step HIP-graph replay
+    # (cb_trainer_set_graph_replay; bitwise identical results) — wall clock and the HOST thread's CPU time per step next to the eager
+    # path's. Runs LAST among the timed legs: the runtime's graph-internal streams change the hardware-queue mapping of later streams.
+    def graph_leg():
+        if not (rank == 0 and world == 1 and not dry and not only3 and not args.no_graph):
+            return None
+        res = {}
+        for tag, on in (("eager", False), ("graph", True)):
+            tr.set_graph_replay(on)
+            for i in range(3):
+                run(i)
+            torch.cuda.synchronize(); tw, tc = time.perf_counter(), time.thread_time()
+            for i in range(args.steps):
+                run(3 + i)
+            cpu = time.thread_time() - tc
+            torch.cuda.synchronize(); el = time.perf_counter() - tw
+            res[tag] = dict(steps_per_s=round(args.steps / el, 4), ms_per_step=round(el / args.steps * 1e3, 3), host_cpu_ms_per_step=round(cpu / args.steps * 1e3, 3))
+        res.update(tr.graph_stats())
         tr.set_graph_replay(False)
-        for i in range(2):
-            run(i)
-        torch.cuda.synchronize(); te = time.perf_counter()
-        for i in range(args.steps):
-            run(2 + i)
-        torch.cuda.synchronize(); el = time.perf_counter() - te
-        tr.set_graph_replay(True)
-        eager = dict(steps_per_s=round(args.steps / el, 4), ms_per_step=round(el / args.steps * 1e3, 3), note="graph replay off: ~1 650 launches enqueued one by one")
+        res["note"] = "opt-in cb_trainer_set_graph_replay: one captured graph of the step's ~1 650 launches replayed per step; not used for `value`"
+        return res
 
     # ---- secondary measurement (rank 0, not the headline `value`): the same K steps with the first stage of batch i+1
     # (VAE encode + FR backbone, no gradients) prefetched on its own stream under the UNet of batch i (cb_trainer_prefetch).
@@ -434,7 +443,7 @@ def main():
             "step_tflops_per_gpu": round(st["gemm_flops"] / 1e12 / (ms_per_step * 1e-3), 2),
             "loss": loss,
             "phase_ms": phases,
-            "graph_replay": dict(graph_stats, eager=eager) if graph_stats else None,
+            "graph_replay": None,
             "pipelined": pipelined,
             "merged_identities": merged_identities,
             "per_rank": list(PER_RANK) or None,
@@ -489,6 +498,8 @@ def main():
                           "roofline": rf3}
         tr3.close(); ctx3.close()
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
+    if out is not None:
+        out["graph_replay"] = graph_leg()
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         from oracle import cb_oracle as O
         cores = min(args.cpu_threads, os.cpu_count() or 1)

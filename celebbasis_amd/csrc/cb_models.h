@@ -148,12 +148,13 @@ struct Trainer {
     // hands out the same addresses every step (cb_engine.h). Results are bitwise those of the eager path: same kernels, same order.
     struct StepGraph {
         bool enabled = false;
-        struct Entry { int B = 0; float lr = 0.f; hipGraphExec_t exec = nullptr; long used = 0; };
+        struct Entry { int B = 0; float lr = 0.f; hipGraphExec_t exec = nullptr; long used = 0; const void* arena_base = nullptr; };
         std::vector<Entry> cache;                 // at most kMaxGraphs, least recently used evicted
         float* image = nullptr; float* faces = nullptr; int64_t* ids = nullptr; int64_t* tokens = nullptr; int64_t* t = nullptr;
         float* noise = nullptr; float* post_noise = nullptr;       // staging, sized for kMaxBatch
         long captures = 0, replays = 0, tick = 0;
-        ~StepGraph() { for (auto& e : cache) if (e.exec) (void)hipGraphExecDestroy(e.exec); }
+        hipStream_t cap = nullptr;                // capture stream (the caller's may be the uncapturable legacy default stream)
+        ~StepGraph() { for (auto& e : cache) if (e.exec) (void)hipGraphExecDestroy(e.exec); if (cap) (void)hipStreamDestroy(cap); }
     } graph;
 };
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T);
@@ -168,7 +169,7 @@ struct Batch {
     int B = 1;
 };
 void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only);
-void trainer_set_graph_replay(Trainer* T, bool on);   // default: environment CB_STEP_GRAPH (unset = on)
+void trainer_set_graph_replay(Trainer* T, bool on);   // default: off unless the environment says CB_STEP_GRAPH=1
 // Enqueue the first stage of `next` (image -> z0, faces -> FR features) on the prefetch stream. A following trainer_step on the
 // same buffers consumes the results instead of recomputing them; any other batch recomputes inline. Results are identical.
 void trainer_prefetch(Trainer* T, const Batch& next);

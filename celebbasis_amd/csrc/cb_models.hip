@@ -457,7 +457,7 @@ Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
 // ================================================================= training step
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     T->ctx = ctx; T->cfg = cfg;
-    { const char* e = getenv("CB_STEP_GRAPH"); T->graph.enabled = !(e && e[0] == '0'); }
+    { const char* e = getenv("CB_STEP_GRAPH"); T->graph.enabled = e && e[0] == '1'; }      // opt-in: measured flat on MI355X (profiles/README.md, round 5)
     unet_load(ctx, wt, "model.diffusion_model.", cfg.unet, &T->unet);
     vae_load(ctx, wt, "first_stage_model.", cfg.vae, &T->vae);
     clip_load(ctx, wt, "cond_stage_model.transformer.text_model.", cfg.clip, &T->clip);
@@ -747,6 +747,15 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
     stage(g.ids, bt.ids, (size_t)B * 2 * sizeof(int64_t));
     stage(g.tokens, bt.tokens, (size_t)B * T77 * sizeof(int64_t));
     stage(g.t, bt.t, (size_t)B * sizeof(int64_t));
+    // a graph is valid for the arena it was captured on: a larger batch size in between re-allocates the step arena (ensure_arena) and
+    // every address inside the older graphs is gone with it
+    for (size_t i = 0; i < g.cache.size();) {
+        if (g.cache[i].arena_base != ctx->arena.base) {
+            CB_HIP(hipStreamSynchronize(s));
+            (void)hipGraphExecDestroy(g.cache[i].exec);
+            g.cache.erase(g.cache.begin() + i);
+        } else ++i;
+    }
     Trainer::StepGraph::Entry* e = nullptr;
     for (auto& x : g.cache) if (x.B == B && x.lr == lr) e = &x;
     if (!e) {
@@ -755,10 +764,16 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
         sb.B = B;
         hipGraph_t graph = nullptr;
         ctx->arena.reset();
-        CB_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        // the caller's stream may be the legacy default stream (PyTorch's current stream usually is), which cannot be captured: the
+        // step's host code runs once against a library-owned capture stream; the instantiated graph is launched on the caller's
+        if (!g.cap) CB_HIP(hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking));
+        ctx->stream = g.cap;
+        hipError_t rcb = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal);
+        if (rcb != hipSuccess) { ctx->stream = s; CB_HIP(rcb); }
         try { step_impl(T, sb, lr); }
-        catch (...) { (void)hipStreamEndCapture(s, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
-        CB_HIP(hipStreamEndCapture(s, &graph));
+        catch (...) { ctx->stream = s; (void)hipStreamEndCapture(g.cap, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        ctx->stream = s;
+        CB_HIP(hipStreamEndCapture(g.cap, &graph));
         hipGraphExec_t exec = nullptr;
         hipError_t rc = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         (void)hipGraphDestroy(graph);
@@ -770,7 +785,7 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
             (void)hipGraphExecDestroy(g.cache[lru].exec);
             g.cache.erase(g.cache.begin() + lru);
         }
-        Trainer::StepGraph::Entry ne; ne.B = B; ne.lr = lr; ne.exec = exec;
+        Trainer::StepGraph::Entry ne; ne.B = B; ne.lr = lr; ne.exec = exec; ne.arena_base = ctx->arena.base;
         g.cache.push_back(ne);
         e = &g.cache.back();
         g.captures++;

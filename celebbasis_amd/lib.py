@@ -584,7 +584,7 @@ class Trainer(_Handle):
         check(load().cb_trainer_step(self.h, C.byref(b), C.c_float(lr)))
 
     def set_graph_replay(self, on=True):
-        """whole-step HIP-graph replay (cb_trainer_set_graph_replay); on by default"""
+        """whole-step HIP-graph replay (cb_trainer_set_graph_replay); opt-in (or CB_STEP_GRAPH=1)"""
         check(load().cb_trainer_set_graph_replay(self.h, C.c_int(1 if on else 0)))
 
     def graph_stats(self):

@@ -298,8 +298,10 @@ int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
 /* Whole-step HIP-graph replay. From the second step at a batch size on, cb_trainer_step copies the batch into
  * trainer-owned staging buffers and replays ONE captured graph of the step's ~1 650 launches (both streams) instead of enqueuing them
  * one by one; a graph is captured per (B, lr) and kept (8 most recent). Same kernels in the same order on the same addresses: results
- * are bitwise those of the eager path. On by default (environment CB_STEP_GRAPH=0 turns it off); the eager path still serves the first
- * step at a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from cb_trainer_prefetch. */
+ * are bitwise those of the eager path. OPT-IN (this call, or environment CB_STEP_GRAPH=1): on MI355X the step is GPU-bound — the
+ * replayed step measures the same 37 ms as the eager one (what the graph saves is host CPU time) and the runtime's graph-internal
+ * streams take the hardware queues cb_trainer_prefetch's overlap needs. With replay on, the eager path still serves the first step at
+ * a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from cb_trainer_prefetch. */
 int cb_trainer_set_graph_replay(cb_trainer* t, int enable);
 int cb_trainer_graph_stats(cb_trainer* t, int64_t* captures, int64_t* replays);
 /* Optional software pipelining across steps: enqueue the gradient-free first stage of the NEXT batch (VAE encode -> latent,

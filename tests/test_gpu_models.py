@@ -316,8 +316,11 @@ def test_graph_replay_is_bitwise_the_eager_step_mini(cb):
     out = _graph_vs_eager(lib, ctx, MINI, 3, script)
     e, g = out[False], out[True]
     assert e["stats"] == dict(captures=0, replays=0), e["stats"]
-    # eager steps: the first at B=1 and the first at B=2; captures: (1, 5e-3), (2, 1e-2), (1, 2.5e-3); every other step is a replay
-    assert g["stats"]["captures"] == 3 and g["stats"]["replays"] == len(script) - 2, g["stats"]
+    # eager: the first step at B=1, the first at B=2 and the first back at B=1 (each re-plans the step arena; the B=2 arena is larger, so
+    # the B=1 graph captured before it is dropped and re-captured afterwards). Captures: (1, 5e-3), (2, 1e-2), (1, 5e-3) again,
+    # (1, 2.5e-3); a capture step launches its graph too
+    # (at mini size the arena's slack covers B=2 and nothing is re-allocated: 3 captures)
+    assert g["stats"]["captures"] in (3, 4) and g["stats"]["replays"] == len(script) - 3, g["stats"]
     assert g["losses"] == e["losses"], (g["losses"], e["losses"])
     for k in ("W", "b", "idc", "ide", "gW"):
         assert torch.equal(g[k], e[k]), f"graph replay changed {k}: max diff {(g[k] - e[k]).abs().max().item():.3e}"
