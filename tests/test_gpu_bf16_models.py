@@ -8,16 +8,16 @@ accumulates ~sqrt(L) * 2^-9 relative noise. Stated per check as max|hip - ref| <
   * the MLP gradient dW (what config 3 keeps in fp32 downstream of the bf16 networks): relative L2 error <= 6e-2 and cosine
     similarity >= 0.995 — it passes through the whole UNet + CLIP backward in bf16;
   * learned coefficients: north_star states its 1e-3 L2 bar for config 2 (fp32, "match reference coeffs"); for config 3 the
-    bar at MINI width is COEF_BAR_BF16 = 8e-3 over 40 optimiser steps, and the drift is also reported relative to the distance the
+    bar at MINI width is COEF_BAR_BF16 = 4e-3 over 40 optimiser steps, and the drift is also reported relative to the distance the
     coefficients travelled (<= 2 %); at the REAL width the bars are the measured envelope of
-    test_train_20_steps_sd14_bf16_bs4_horizon (learned coefficients 3e-3 .. 4e-3 after 20 steps at lr 2e-2). north_star's 1e-3 is
-    REPORTED per sample by test_train_40_steps_mini_bf16_summation_order_samples (no expected-failure marker). Why not 1e-3: AdamW divides by sqrt(v), so an element's update is ~lr whatever the
-    gradient's size, and the bf16 rounding noise of dW (relative L2 1.5e-2, cosine 0.9999 at SD size) moves each of the 1024
-    coefficients by a few 1e-5 per step; measured 1.9e-3 .. 2.3e-3 after 40 steps with the UNet + VAE in bf16 and CLIP, the
-    FR-net, the head, the gradient and the optimiser in fp32 (4.3e-3 with CLIP in bf16 as well, which is why CLIP stays fp32).
-    The 40-step distance is a random variable of the summation order, not a constant: round 4's 80-column tiles change nothing but the
-    fp32 summation order of the CLIP / head GEMMs (bit-exact fp32 products, CB_N80=0 restores the old order) and the same run measures
-    4.8e-3 instead of 2.3e-3 (profiles/README.md, round 4) — so the mini bar is 8e-3, like the real-width one: twice the largest sample."""
+    test_train_20_steps_sd14_bf16_bs4_horizon (learned coefficients 2.8e-3 .. 3.9e-3 after 20 steps at lr 2e-2). north_star's 1e-3 is
+    REPORTED per sample by test_train_40_steps_mini_bf16_summation_order_samples (no expected-failure marker). Why not 1e-3: AdamW
+    divides by sqrt(v), so an element's update is ~lr whatever the gradient's size, and the bf16 rounding noise of dW (relative L2
+    1.5e-2, cosine 0.9999 at SD size) moves each of the 1024 coefficients by a few 1e-5 per step.
+    The 40-step distance is a random variable of the summation order, not a constant: SEVEN samples (every GEMM / conv of the step pinned
+    to another tiling, profiles/r05_bf16_mini40_summation_order_samples.json) measure 1.9e-3 .. 2.9e-3, mean 2.25e-3, none within 1e-3.
+    The bar is 4e-3 again (round 4 had raised it to 8e-3 on a 4.8e-3 sample; that sample's excess came from the fp32 identity branch —
+    the warp / resize arithmetic fixed in round 5 — not from bf16: the same plan now measures 2.2e-3)."""
 import json
 import os
 
@@ -29,7 +29,7 @@ from test_gpu_models import MINI, close, dv, load, make_batch, run_horizon, trai
 pytestmark = pytest.mark.gpu
 REPORT = {}
 DEV = "cuda:0"
-COEF_BAR_BF16 = 8e-3
+COEF_BAR_BF16 = 4e-3
 
 
 @pytest.fixture(scope="module")
@@ -196,12 +196,12 @@ def test_train_20_steps_sd14_bf16_bs4_horizon(cbf, golden_dir):
     Measured (two runs, with and without the fp32 K/V-projection lever CB_BF16_KV_F32): dW of a step is within 0.7 - 2 % relative L2 of
     the oracle's; the FIRST AdamW step already turns that into a 7e-3 coefficient difference (every weight moves by lr * sign(g): the
     ~0.5 % of elements whose sign differs move the other way), the step coefficients are 2.4e-2 .. 4.5e-2 apart after 20 steps and
-    the learned (EMA dictionary) coefficients 3.0e-3 .. 3.9e-3; losses agree to 5e-4. north_star's 1e-3 bar is therefore NOT met by
+    the learned (EMA dictionary) coefficients 2.8e-3 .. 3.9e-3 (bar 5e-3); losses agree to 5e-4. north_star's 1e-3 bar is therefore NOT met by
     the bf16 path at real width (REPORT key below; the mini-width samples are in test_train_40_steps_mini_bf16_summation_order_samples);
     this test holds the path to its measured envelope with 2x margin so that a regression of the bf16 kernels is caught."""
     lib, ctx = cbf
     fx = load(golden_dir, "horizon_sd14_b4.pt")
-    s = run_horizon(lib, ctx, fx, 20, "horizon_sd14_b4_bf16", REPORT, dict(coef_l2_max=9e-2, id_coef_l2_last=8e-3, loss_rel_max=5e-3))
+    s = run_horizon(lib, ctx, fx, 20, "horizon_sd14_b4_bf16", REPORT, dict(coef_l2_max=9e-2, id_coef_l2_last=5e-3, loss_rel_max=5e-3))
     REPORT["bf16.sd14.learned_coefficients_within_north_star_1e-3"] = s["id_coef_l2_last"] <= 1e-3
     tab = REPORT["horizon_sd14_b4_bf16.table"]
     g1 = tab[0]["grad_weight_rel_l2_sampled_rows"]

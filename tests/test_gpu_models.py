@@ -292,6 +292,7 @@ def _graph_vs_eager(lib, ctx, m, seed, script):
     W = O.init_weights(shapes, seed=seed)
     lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
     out = {}
+    ctx.set_debug_taps(False)                    # an earlier test of the module may have left them on: a step that collects taps runs eagerly
     for graph in (False, True):
         tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
         tr.set_graph_replay(graph)
