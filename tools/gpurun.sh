@@ -39,7 +39,7 @@ case "$what" in
     tag=$1; shift
     STEPS=6
     cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/trace_$tag -o bench -- \
-      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --no-config3 "$@" > $REPO/gpurun_out/trace_$tag.log 2>&1
+      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --no-config3 --no-graph "$@" > $REPO/gpurun_out/trace_$tag.log 2>&1
     cd $REPO
     db=$(find gpurun_out/trace_$tag -name "*.db" | head -1)
     # every measurement leg of bench.py runs warmup + steps + 1 profiled step of its own kernels
@@ -49,7 +49,7 @@ case "$what" in
     tag=$1; shift
     STEPS=6
     cd /tmp && rocprofv3 --kernel-trace --stats -d $REPO/gpurun_out/trace3_$tag -o bench -- \
-      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --trace-leg config3 "$@" > $REPO/gpurun_out/trace3_$tag.log 2>&1
+      python $REPO/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-pipelined --no-graph --trace-leg config3 "$@" > $REPO/gpurun_out/trace3_$tag.log 2>&1
     cd $REPO
     db=$(find gpurun_out/trace3_$tag -name "*.db" | head -1)
     python tools/prof_stats.py "$db" gpurun_out/${tag}_config3_kernel_stats.csv $((STEPS + 3)) | head -40
@@ -60,7 +60,7 @@ case "$what" in
     cd /tmp
     for c in FETCH_SIZE WRITE_SIZE; do
       rocprofv3 --kernel-trace --pmc $c -d $REPO/gpurun_out/pmc${sfx}_${tag}_$c -o p --output-format csv -- \
-        python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined $leg "$@" > $REPO/gpurun_out/pmc${sfx}_${tag}_$c.log 2>&1
+        python $REPO/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-pipelined --no-graph $leg "$@" > $REPO/gpurun_out/pmc${sfx}_${tag}_$c.log 2>&1
     done
     cd $REPO
     python tools/pmc_traffic.py gpurun_out/pmc${sfx}_${tag}_FETCH_SIZE gpurun_out/pmc${sfx}_${tag}_WRITE_SIZE gpurun_out/${tag}_pmc_hbm_traffic${sfx}.json
