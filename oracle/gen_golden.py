@@ -743,6 +743,9 @@ def main():
                                           "(aigc_id.yaml:135); slim: losses, step coefficients, EMA dictionary rows")
     manifest["horizon_sd14_b1_photo.pt"] = ("oracle/gen_horizon.py fp32photo: 800 steps of the fp32 run on the replay stream with low-pass (photo-like) face crops "
                                             "(oracle/replay.py::low_pass); slim")
+    for tag, ws, bs in (("photo2", 9, 3000), ("photo3", 10, 5000)):
+        manifest[f"horizon_sd14_b1_{tag}.pt"] = (f"oracle/gen_horizon.py fp32{tag}: another draw of the 800-step photo-like run — frozen weights init_weights({ws}), batch stream "
+                                                 f"seeds {bs}+; slim: loss per step, EMA dictionary rows of every 4th step")
     manifest["horizon_mini_ref800.pt"] = ("oracle/gen_horizon_ref.py: 800 optimiser steps of the REFERENCE's composed step (the gen_step harness: ddpm.py "
                                           "LatentDiffusion.forward / p_losses / q_sample / get_loss, UNetModel, Encoder, EmbeddingManagerId + MetaIdNet, AdamW) at "
                                           "mini size — per-step loss + EMA dictionary rows; the same with seeded FR-feature noise (3e-6 / 2.5e-5 / 2e-4); "

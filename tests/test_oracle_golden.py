@@ -369,3 +369,24 @@ def test_oracle_tracks_the_reference_for_800_steps(golden_dir):
     assert float(((fx["oracle"]["loss"] - ref["loss"]).abs() / ref["loss"].abs()).max()) <= 2e-5
     for tag, bar in (("ref_fr3e-6", 1e-5), ("ref_fr2.5e-5", 5e-5), ("ref_fr2e-4", 5e-4)):
         assert float(learned_l2(fx[tag]["id_coef"], ref["id_coef"]).max()) <= bar, tag
+
+
+def test_fixture_host_warp_grid_digest_and_distance_to_this_host():
+    """the SD-size oracle trajectories were generated on a host whose torch evaluates F.affine_grid(trans_matrix, 512 x 512) to the table
+    oracle/replay.py::fixture_host_warp_grid restates (digest-pinned; the `-m gpu` horizon tests hand the library THAT table through
+    cb_ctx_set_warp_grid). On any host it must be within one fp32 ulp of the host's own affine_grid — torch's K = 3 bmm rounds host
+    dependently (tools/probes/probe_affine_grid_host.py) — and the oracle's face_warp_resize must use the reference's call."""
+    import hashlib
+    import torch.nn.functional as F
+    from oracle import cb_oracle as O
+    from oracle.replay import FIXTURE_HOST_GRID_SHA1, fixture_host_warp_grid
+    g = fixture_host_warp_grid(512)
+    assert g.shape == (512, 512, 2) and g.dtype == torch.float32
+    assert hashlib.sha1(g.numpy().tobytes()).hexdigest()[:12] == FIXTURE_HOST_GRID_SHA1[512]
+    here = F.affine_grid(torch.tensor([O.TRANS_MATRIX], dtype=torch.float32), size=[1, 3, 512, 512], align_corners=True)[0]
+    assert (g - here).abs().max().item() <= 1.2e-7 + 1e-12, "the fixture host's grid is more than one ulp from this host's"
+    # the corners: align_corners=True maps the output corners through the matrix exactly (up to rounding)
+    t = torch.tensor(O.TRANS_MATRIX)
+    for (y, x, u, v) in ((0, 0, -1.0, -1.0), (511, 511, 1.0, 1.0), (0, 511, 1.0, -1.0)):
+        want = t @ torch.tensor([u, v, 1.0])
+        assert torch.allclose(g[y, x], want, atol=3e-7), (y, x, g[y, x], want)
