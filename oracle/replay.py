@@ -45,6 +45,12 @@ def fixture_host_warp_grid(S=512):
     f32 = np.float32
     fma = lambda a, b, c: (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(f32)     # exact product, one rounding
     lin = torch.linspace(-1, 1, S).numpy()
+    if S == 512 and hashlib.sha1(lin.tobytes()).hexdigest()[:12] != "0aa2f976c8dd":
+        # a host whose torch rounds linspace differently (another vector width): the fixture host's 512 values are kept as data
+        import json
+        import os
+        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", "warp_linspace_512.json")) as f:
+            lin = np.array([float.fromhex(v) for v in json.load(f)["values"]], dtype=f32)
     th = np.array(TRANS_MATRIX, dtype=f32)
     X = np.broadcast_to(lin[None, :], (S, S)).astype(f32); Y = np.broadcast_to(lin[:, None], (S, S)).astype(f32)
     g = np.stack([fma(np.full_like(X, th[r, 2]), np.ones_like(X), fma(np.full_like(X, th[r, 1]), Y, (th[r, 0] * X).astype(f32))) for r in range(2)], -1)
