@@ -746,6 +746,8 @@ def main():
     for tag, ws, bs in (("photo2", 9, 3000), ("photo3", 10, 5000)):
         manifest[f"horizon_sd14_b1_{tag}.pt"] = (f"oracle/gen_horizon.py fp32{tag}: another draw of the 800-step photo-like run — frozen weights init_weights({ws}), batch stream "
                                                  f"seeds {bs}+; slim: loss per step, EMA dictionary rows of every 4th step")
+    manifest["horizon_sd14_b1_noise2.pt"] = ("oracle/gen_horizon.py fp32noise2: another draw of the DEFAULT (white-noise) 800-step run — frozen weights init_weights(11), "
+                                             "batch stream seeds 7000+; slim: loss per step, EMA dictionary rows of every 4th step")
     manifest["warp_linspace_512.json"] = ("torch.linspace(-1, 1, 512) (the x / y base grid of F.affine_grid, meta_net.py:253-257) as float32 hex on the fixture host; "
                                           "fallback data of oracle/replay.py::fixture_host_warp_grid")
     manifest["horizon_mini_ref800.pt"] = ("oracle/gen_horizon_ref.py: 800 optimiser steps of the REFERENCE's composed step (the gen_step harness: ddpm.py "

@@ -10,6 +10,7 @@ instead of on the CPU oracle:
     python oracle/gen_horizon.py fp32long -> horizon_sd14_b1_800.pt   `fp32` continued to 800 steps (config 2's own length; 3.5 h)
     python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 800 steps of the same stream with low-pass ("photo-like") face crops (2.5 h)
     python oracle/gen_horizon.py fp32photo2 / fp32photo3 -> horizon_sd14_b1_photo{2,3}.pt  the same with other frozen weights and another batch stream
+    python oracle/gen_horizon.py fp32noise2 -> horizon_sd14_b1_noise2.pt  the default (white-noise) stream with other frozen weights and another batch stream
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
@@ -47,6 +48,9 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             fp32photo2=dict(B=1, steps=800, lr=5e-3, seed=9, batch_seed0=3000, out="horizon_sd14_b1_photo2.pt", grad_steps=(), slim=True, photo=True,
                             coef_steps=0, id_coef_stride=4),
             fp32photo3=dict(B=1, steps=800, lr=5e-3, seed=10, batch_seed0=5000, out="horizon_sd14_b1_photo3.pt", grad_steps=(), slim=True, photo=True,
+                            coef_steps=0, id_coef_stride=4),
+            # the DEFAULT (white-noise) stream drawn again: other frozen weights, another batch stream
+            fp32noise2=dict(B=1, steps=800, lr=5e-3, seed=11, batch_seed0=7000, out="horizon_sd14_b1_noise2.pt", grad_steps=(), slim=True,
                             coef_steps=0, id_coef_stride=4),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
