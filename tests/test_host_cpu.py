@@ -568,23 +568,23 @@ def test_bench_uses_committed_profiles_only_when_their_stamp_is_this_tree(tmp_pa
     body = "name,calls,total_ms,ms_per_step,avg_us,min_us,max_us,pct\n" \
            '"gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>",378,79.8,8.867,211.1,72.2,736.1,20.8\n"splitk_reduce_kernel<float>",3924,22.5,2.509,5.75,2.8,14.6,5.9\n'
     good = f"# stamp src_sha={st['src_sha']} plan_table_sha={st['plan_table_sha']} nsteps=9\n# rocprofv3\n" + body
-    (tmp_path / "profiles" / "r04z_bench_kernel_stats.csv").write_text(good)
+    (tmp_path / "profiles" / "r05z_bench_kernel_stats.csv").write_text(good)
     src, stale, per, base = bench.rocprof_trace(False)
-    assert src == "r04z_bench_kernel_stats.csv" and stale is False and abs(base["splitk_reduce_kernel"] - 2.509) < 1e-9
+    assert src == "r05z_bench_kernel_stats.csv" and stale is False and abs(base["splitk_reduce_kernel"] - 2.509) < 1e-9
     assert per["gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>"][0] == 42.0           # launches per step from calls / nsteps
     # one profiler label = the scalar-offset (FAST) and the per-lane form of the kernel; the 80-column tiles: <BM, A kind, stages, FAST>
     assert bench.trace_symbols("gemm_glds_kernel<float,128,128,CONVF>") == ["gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>",
                                                                             "gemm_glds_kernel<float, 128, 128, 2, 128, 2, false>"]
     assert bench.trace_symbols("gemm_glds80_kernel<float,32,80,ROW>")[0] == "gemm_glds80_kernel<32, 0, 2, true>"
-    (tmp_path / "profiles" / "r04z_bench_kernel_stats.csv").write_text(good.replace(st["src_sha"], "0" * 16))
+    (tmp_path / "profiles" / "r05z_bench_kernel_stats.csv").write_text(good.replace(st["src_sha"], "0" * 16))
     src, stale, per, base = bench.rocprof_trace(False)
     assert stale is True and per == {} and base == {}
     pmc = {"stamp": st, "per_symbol": {"gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>": {"launches": 210, "fetch_bytes_per_launch": 90e6, "write_bytes_per_launch": 24e6}}}
-    (tmp_path / "profiles" / "r04z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    (tmp_path / "profiles" / "r05z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
     t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
     assert t == 204000000 and det["stale"] is False and det["fetch_size_bytes_per_launch_raw"] == 90000000      # 2 x FETCH_SIZE + WRITE_SIZE
     pmc["stamp"] = {"src_sha": "x", "plan_table_sha": "y"}
-    (tmp_path / "profiles" / "r04z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    (tmp_path / "profiles" / "r05z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
     t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
     assert t is None and det["stale"] is True
 
