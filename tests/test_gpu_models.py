@@ -572,7 +572,8 @@ def test_train_800_steps_sd14_more_draws(cb, golden_dir, name):
         pytest.skip(f"{name}.pt not generated yet (oracle/gen_horizon.py)")
     fx = dict(load(golden_dir, name + ".pt"))
     n = int(fx["steps"])
-    assert n >= 100, "the generator writes the fixture every 10 steps; at least 100 are needed for a horizon claim"
+    if n < 100:
+        pytest.skip(f"{name}.pt holds {n} steps so far (the generator writes it every 10 steps; at least 100 are needed for a horizon claim)")
     s = run_horizon(lib, ctx, fx, n, name, REPORT, dict(loss_rel_max=2e-4))
     tab = [r for r in REPORT[name + ".table"] if "id_coef_l2" in r]
     with open(f"gpurun_out/{name}.json") as f:
@@ -582,6 +583,13 @@ def test_train_800_steps_sd14_more_draws(cb, golden_dir, name):
     with open(f"gpurun_out/{name}.json", "w") as f:
         json.dump(rec, f, indent=1)
     REPORT[name + ".steps_compared"] = n
+    # a draw whose trajectories meet a LeakyReLU kink inside the horizon shows it as a jump of 1 - 2 decades between two table rows:
+    # recorded (photo2: round-off agreement 2.4e-6 through step 680, 3.5e-5 at 700, 4.8e-4 at 760, 4.3e-4 at 800), and still held to the bar
+    jumps = [b["step"] for a, b in zip(tab, tab[1:]) if b["id_coef_l2"] > 5 * max(a["id_coef_l2"], 1e-6)]
+    rec["first_jump_step"] = jumps[0] if jumps else None
+    with open(f"gpurun_out/{name}.json", "w") as f:
+        json.dump(rec, f, indent=1)
+    REPORT[name + ".first_jump_step"] = rec["first_jump_step"]
     assert s["id_coef_l2_max"] <= 1e-3, f"{name}: learned coefficients left north_star's 1e-3 bar inside {n} steps: {s['id_coef_l2_max']:.3e}"
 
 
