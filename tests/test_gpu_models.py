@@ -45,6 +45,22 @@ def load(golden_dir, name):
     return torch.load(os.path.join(golden_dir, name), weights_only=False)
 
 
+_W_CACHE = {}
+
+
+def cached_weights(O, shapes, seed):
+    """O.init_weights(shapes, seed) — 40 s of host time for the 1.08e9 SD-size parameters — kept for the two most recent (size, seed) pairs:
+    several SD-size tests share seed 8. The tensors are read-only for every user (the trainers copy them to the device)."""
+    key = (len(shapes), sum(int(torch.Size(v).numel()) for v in shapes.values()), seed)
+    if key not in _W_CACHE:
+        while len(_W_CACHE) >= 2:
+            _W_CACHE.pop(next(iter(_W_CACHE)))
+        _W_CACHE[key] = O.init_weights(shapes, seed=seed)
+    else:
+        _W_CACHE[key] = _W_CACHE.pop(key)          # most recently used last
+    return _W_CACHE[key]
+
+
 def test_unet_mini_vs_reference_golden(cb, golden_dir):
     from oracle import cb_oracle as O
     lib, ctx = cb
@@ -162,7 +178,7 @@ def trainer_cfg(lib, m):
 def run_steps(lib, ctx, m, B, steps, lr, seed, check_aux, per_step=True, drift=None):
     from oracle import cb_oracle as O
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
-    W = O.init_weights(shapes, seed=seed)
+    W = cached_weights(O, shapes, seed)
     tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
     st = O.TrainState(W)
     lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
@@ -289,7 +305,7 @@ def _graph_vs_eager(lib, ctx, m, seed, script):
     """run `script` = [(B, lr), ...] twice on fresh trainers — eager launches / HIP-graph replay — and return both end states + the graph counters"""
     from oracle import cb_oracle as O
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
-    W = O.init_weights(shapes, seed=seed)
+    W = cached_weights(O, shapes, seed)
     lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
     out = {}
     ctx.set_debug_taps(False)                    # an earlier test of the module may have left them on: a step that collects taps runs eagerly
@@ -387,7 +403,7 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     c = fx["cfg"]
     m = SD14(O)
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
-    W = O.init_weights(shapes, seed=c["weight_seed"])
+    W = cached_weights(O, shapes, c["weight_seed"])
     tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
     # the warp's constant sampling grid as the host that generated the trajectory evaluated it (this box's torch rounds the K = 3 bmm of
     # F.affine_grid differently in 14 % of the elements: oracle/replay.py::fixture_host_warp_grid); restored afterwards
@@ -399,8 +415,20 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     table = []
     traj = dict(coef=[], id_coef=[], gW_rows=[], loss=[])
     ctx.set_debug_taps(True)
+    # the replay stream is generated on host cores (the photo-like faces: two float64 512^3 products per channel and step): a few worker
+    # threads build the batches ahead of the GPU, same bytes in the same order
+    from concurrent.futures import ThreadPoolExecutor
+    gen = lambda s_: make_batch(B, 512, 64, m["clip"]["vocab"], m["placeholder"], c["batch_seed0"] + s_, m["max_ids"], photo=bool(c.get("photo")))
+    first = gen(0)                                   # fills the low-pass operator cache before the threads start
+    pool = ThreadPoolExecutor(max_workers=8)
+    ahead = {0: None}
+    for s_ in range(1, min(steps, 24)):
+        ahead[s_] = pool.submit(gen, s_)
     for s in range(steps):
-        batch = make_batch(B, 512, 64, m["clip"]["vocab"], m["placeholder"], c["batch_seed0"] + s, m["max_ids"], photo=bool(c.get("photo")))
+        fut = ahead.pop(s)
+        batch = first if s == 0 else fut.result()
+        if s + 24 < steps:
+            ahead[s + 24] = pool.submit(gen, s + 24)
         dev = {k: dv(v) for k, v in batch.items()}
         tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], c["lr"])
         coef = ctx.tap("coef").reshape(2 * B, -1)
@@ -421,6 +449,7 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
             traj["coef"].append(coef.clone()); traj["id_coef"].append(idc.clone()); traj["loss"].append(loss)
     if save_traj:
         torch.save({k: (torch.stack(v) if k != "loss" else torch.tensor(v, dtype=torch.float64)) for k, v in traj.items() if len(v)}, save_traj)
+    pool.shutdown(wait=True)
     ctx.set_debug_taps(False)
     ctx._warp_S = None; ctx.ensure_warp_grid(512)          # back to this host's own table
     if steps == int(fx["steps"]) and "W0_rows" in fx:
@@ -509,7 +538,7 @@ def test_two_gemm_tilings_stay_together_sd14(cb):
     lib, ctx = cb
     m = SD14(O)
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
-    W = O.init_weights(shapes, seed=8)
+    W = cached_weights(O, shapes, 8)
     out = []
     try:
         for plan in ((0, 0, 0), (64, 64, 0)):
