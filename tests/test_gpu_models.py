@@ -614,11 +614,11 @@ def test_train_800_steps_sd14_more_draws(cb, golden_dir, name):
     REPORT[name + ".steps_compared"] = n
     # a draw whose trajectories meet a LeakyReLU kink inside the horizon shows it as a jump of 1 - 2 decades between two table rows:
     # recorded (photo2: round-off agreement 2.4e-6 through step 680, 3.5e-5 at 700, 4.8e-4 at 760, 4.3e-4 at 800), and still held to the bar
-    jumps = [b["step"] for a, b in zip(tab, tab[1:]) if b["id_coef_l2"] > 5 * max(a["id_coef_l2"], 1e-6)]
-    rec["first_jump_step"] = jumps[0] if jumps else None
+    jumps = [r["step"] for r in tab if r["id_coef_l2"] > 1e-5]              # round-off agreement is 2 - 3e-6 on every draw
+    rec["first_step_beyond_1e-5"] = jumps[0] if jumps else None
     with open(f"gpurun_out/{name}.json", "w") as f:
         json.dump(rec, f, indent=1)
-    REPORT[name + ".first_jump_step"] = rec["first_jump_step"]
+    REPORT[name + ".first_step_beyond_1e-5"] = rec["first_step_beyond_1e-5"]
     assert s["id_coef_l2_max"] <= 1e-3, f"{name}: learned coefficients left north_star's 1e-3 bar inside {n} steps: {s['id_coef_l2_max']:.3e}"
 
 
