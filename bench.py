@@ -309,7 +309,10 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=64, help="host threads for the CPU baseline (reported as `cores`)")
     ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
-    ap.add_argument("--no-graph", action="store_true", help="skip the secondary HIP-graph replay measurement")
+    ap.add_argument("--graph", action="store_true", help="also measure the opt-in whole-step HIP-graph replay as a secondary leg (eager vs replay; "
+                    "profiles/BENCH_r05_run*.json were taken with it). Off by default: the runtime's graph path is erratic once other streams / "
+                    "contexts exist (DESIGN §2) and a secondary leg must not be able to endanger the line")
+    ap.add_argument("--no-graph", action="store_true", help="(default; kept for the profile targets of tools/gpurun.sh)")
     ap.add_argument("--dry", action="store_true", help="no GPU: dry contexts + gloo (launcher / sharding / merge / JSON contract only)")
     args = ap.parse_args()
     maybe_self_launch(args)
@@ -369,7 +372,7 @@ def main():
     # (cb_trainer_set_graph_replay; bitwise identical results) — wall clock and the HOST thread's CPU time per step next to the eager
     # path's. Runs LAST among the timed legs: the runtime's graph-internal streams change the hardware-queue mapping of later streams.
     def graph_leg():
-        if not (rank == 0 and world == 1 and not dry and not only3 and not args.no_graph):
+        if not (rank == 0 and world == 1 and not dry and not only3 and args.graph and not args.no_graph):
             return None
         res = {}
         for tag, on in (("eager", False), ("graph", True)):
@@ -499,7 +502,14 @@ def main():
         tr3.close(); ctx3.close()
     # ---- CPU baseline (rank 0, N == 1 only): the oracle on this box's host cores, bounded sample
     if out is not None:
-        out["graph_replay"] = graph_leg()
+        try:                                   # a secondary leg must never take the line down with it
+            out["graph_replay"] = graph_leg()
+        except Exception as e:                 # noqa: BLE001
+            out["graph_replay"] = {"error": f"{type(e).__name__}: {e}"[:300]}
+            try:
+                tr.set_graph_replay(False)
+            except Exception:                  # noqa: BLE001
+                pass
     if rank == 0 and world == 1 and not args.no_cpu_baseline and not dry:
         from oracle import cb_oracle as O
         cores = min(args.cpu_threads, os.cpu_count() or 1)
