@@ -810,3 +810,36 @@ def test_upsample_conv_gradient_identity():
     w4 = comb(comb(w, 2), 3)                                          # [Co, C, 4, 4]
     dx = F.conv2d(dy, w4.transpose(0, 1), stride=2, padding=1)
     assert dx.shape == dx_ref.shape and (dx - dx_ref).abs().max().item() < 1e-12
+
+
+def test_warp_grid_and_graph_replay_entries_on_a_dry_context(built_lib):
+    """round-5 ABI entries without a GPU: cb_ctx_set_warp_grid validates its table (size, finite normalised coordinates), accepts the
+    reference's own affine_grid through lib.Context.ensure_warp_grid / set_warp_grid and drops it on NULL; cb_trainer_set_graph_replay /
+    cb_trainer_graph_stats are callable on a dry trainer, whose steps never capture anything (a dry context computes nothing)."""
+    import ctypes as C
+    import torch
+    from celebbasis_amd import lib, synthetic
+    L = built_lib
+    ctx = lib.Context(device=-1)
+    g = torch.zeros(8, 8, 2)
+    assert L.cb_ctx_set_warp_grid(ctx.h, C.c_void_p(g.data_ptr()), 1) != 0 and b"S = 1" in L.cb_last_error()
+    bad = g.clone(); bad[0, 0, 0] = float("nan")
+    assert L.cb_ctx_set_warp_grid(ctx.h, C.c_void_p(bad.data_ptr()), 8) != 0 and b"normalised coordinate" in L.cb_last_error()
+    far = g.clone(); far[0, 0, 0] = 100.0
+    assert L.cb_ctx_set_warp_grid(ctx.h, C.c_void_p(far.data_ptr()), 8) != 0
+    ctx.ensure_warp_grid(64)
+    want = torch.nn.functional.affine_grid(torch.tensor([lib.WARP_TRANS_MATRIX], dtype=torch.float32), size=[1, 3, 64, 64], align_corners=True)[0]
+    assert ctx._warp_S == 64 and torch.equal(ctx.warp_grid_host, want)
+    ctx.ensure_warp_grid(64)                                     # cached: same object
+    assert ctx.warp_grid_host.data_ptr() == ctx.warp_grid_host.data_ptr()
+    ctx.set_warp_grid(want + 0.0)
+    assert L.cb_ctx_set_warp_grid(ctx.h, None, 0) == 0           # NULL drops the table
+    with pytest.raises(AssertionError):
+        ctx.set_warp_grid(torch.zeros(8, 4, 2))                  # not square
+    tr = lib.Trainer(ctx, lib.WeightTable(synthetic.trainer_shapes()))
+    assert ctx._warp_S == 512                                    # the trainer installs the table of its image size
+    tr.set_graph_replay(True)
+    for _ in range(3):
+        tr.step(1, None, None, None, None, None, None, 5e-3)
+    assert tr.graph_stats() == dict(captures=0, replays=0)
+    tr.set_graph_replay(False)
