@@ -54,7 +54,7 @@ int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
     c.dtype = c.load_dt = (DType)dtype;
     c.device = device;
     c.dry = device < 0;
-    c.arena.dry = c.dry; c.pool.dry = c.dry;
+    c.arena.dry = c.dry; c.arena.cnt.dry = c.dry; c.pool.dry = c.dry;
     if (!c.dry) {
         int n = 0;
         CB_HIP(hipGetDeviceCount(&n));
@@ -70,6 +70,8 @@ int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
         CB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
         CB_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         CB_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
+        CB_HIP(hipEventCreateWithFlags(&c.ev_tail, hipEventDisableTiming));
+        CB_HIP(hipEventCreateWithFlags(&c.ev_tail_fork, hipEventDisableTiming));
     }
     *out = h.release();
     CB_END
@@ -82,6 +84,7 @@ int cb_ctx_destroy(cb_ctx* ctx) {
 int cb_ctx_sync(cb_ctx* ctx) {
     CB_TRY
     require(ctx, "ctx");
+    ctx->c.join_tail();          // a training step's deferred tail (side stream) is part of "everything enqueued on this context"
     if (!ctx->c.dry) CB_HIP(hipStreamSynchronize(ctx->c.stream));
     CB_END
 }
@@ -106,7 +109,8 @@ int cb_ctx_set_warp_grid(cb_ctx* ctx, const float* host_grid, int S) {
     require(ctx, "ctx");
     Ctx& c = ctx->c;
     if (!host_grid) {
-        if (c.warp_grid && !c.dry) { CB_HIP(hipStreamSynchronize(c.stream)); CB_HIP(hipFree(c.warp_grid)); }
+        // the prefetch stream and a replaying step graph read the table too and the context does not know them: wait for the device
+        if (c.warp_grid && !c.dry) { c.join_tail(); CB_HIP(hipDeviceSynchronize()); CB_HIP(hipFree(c.warp_grid)); }
         c.warp_grid = nullptr; c.warp_S = 0;
     } else {
         CB_CHECK(S > 1 && S <= 4096, CB_ERR_ARG, "warp grid: S = %d", S);
@@ -118,8 +122,8 @@ int cb_ctx_set_warp_grid(cb_ctx* ctx, const float* host_grid, int S) {
         if (c.dry) {
             c.warp_grid = reinterpret_cast<float*>(0x200000); c.warp_S = S;
         } else {
-            CB_HIP(hipStreamSynchronize(c.stream));
-            if (c.aux) CB_HIP(hipStreamSynchronize(c.aux));
+            c.join_tail();
+            CB_HIP(hipDeviceSynchronize());            // rare configuration call: every stream that may be sampling the old table
             if (c.warp_grid && c.warp_S != S) { CB_HIP(hipFree(c.warp_grid)); c.warp_grid = nullptr; }
             if (!c.warp_grid) CB_HIP(hipMalloc(&c.warp_grid, n * sizeof(float)));
             CB_HIP(hipMemcpy(c.warp_grid, host_grid, n * sizeof(float), hipMemcpyHostToDevice));
@@ -143,6 +147,7 @@ int cb_ctx_tap(cb_ctx* ctx, const char* name, float* host_dst, int64_t max_elems
     if (numel) *numel = it->second.n;
     if (host_dst && !ctx->c.dry) {
         int64_t n = std::min<int64_t>(max_elems, it->second.n);
+        ctx->c.join_tail();
         CB_HIP(hipStreamSynchronize(ctx->c.stream));
         if (it->second.dt == DT_BF16) {        // taps are always handed out as fp32
             std::vector<uint16_t> tmp((size_t)n);
@@ -159,6 +164,7 @@ int cb_ctx_profile_begin(cb_ctx* ctx) {
     CB_TRY
     require(ctx, "ctx");
     CB_CHECK(!ctx->c.dry, CB_ERR_STATE, "profiling needs a real device context");
+    ctx->c.join_tail();
     for (auto& r : ctx->c.prof.recs) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     ctx->c.prof.recs.clear();
     ctx->c.prof.on = true;
@@ -169,6 +175,7 @@ int cb_ctx_profile_end(cb_ctx* ctx, char* json, int64_t cap) {
     require(ctx, "ctx"); require(json, "json");
     Profiler& P = ctx->c.prof;
     P.on = false;
+    ctx->c.join_tail();
     CB_HIP(hipStreamSynchronize(ctx->c.stream));
     std::vector<double> ms(P.names.size(), 0.0), fl(P.names.size(), 0.0), by(P.names.size(), 0.0);
     std::vector<long> cnt(P.names.size(), 0);
@@ -229,6 +236,12 @@ int cb_debug_force_plan(int BM, int BN, int split) {
 int cb_debug_glds_safe(int on) {
     CB_TRY
     plan_force().glds_safe = on ? 1 : 0;
+    CB_END
+}
+
+int cb_debug_splitk_inlaunch(int on) {
+    CB_TRY
+    plan_force().splitk_inlaunch = on ? 1 : 0;
     CB_END
 }
 
@@ -846,6 +859,7 @@ int cb_trainer_share_clip(cb_trainer* t, cb_clip** out) {
 }
 int cb_trainer_destroy(cb_trainer* t) {
     CB_TRY
+    if (t && t->ctx && !t->ctx->dry) { t->ctx->join_tail(); (void)hipStreamSynchronize(t->ctx->stream); }
     delete t;
     CB_END
 }
@@ -868,6 +882,13 @@ int cb_trainer_set_graph_replay(cb_trainer* t, int enable) {
     CB_TRY
     require(t, "trainer");
     trainer_set_graph_replay(&t->T, enable != 0);
+    CB_END
+}
+int cb_trainer_set_tail_overlap(cb_trainer* t, int enable) {
+    CB_TRY
+    require(t, "trainer");
+    t->ctx->join_tail();
+    t->T.tail_overlap = enable != 0;
     CB_END
 }
 int cb_trainer_graph_stats(cb_trainer* t, int64_t* captures, int64_t* replays) {
@@ -904,7 +925,8 @@ int cb_trainer_loss_to(cb_trainer* t, float* loss_dev) {
     CB_TRY
     require(t, "trainer");
     if (!t->ctx->dry) require(loss_dev, "loss_dev");
-    k_axpby(t->ctx->launch(), loss_dev, t->T.loss, 1, 1.f, 0.f);
+    // (the loss is written on the context stream during the UNet phase: no need to join a deferred tail for it)
+    k_axpby(t->ctx->launch_nojoin(), loss_dev, t->T.loss, 1, 1.f, 0.f);
     CB_END
 }
 
@@ -942,6 +964,7 @@ int cb_trainer_get_state(cb_trainer* t, const char* name, float* host_dst, int64
     if (numel) *numel = r.n;
     if (host_dst && !t->ctx->dry) {
         CB_CHECK(max_elems >= r.n, CB_ERR_ARG, "get_state '%s': buffer too small (%ld < %ld)", name, (long)max_elems, r.n);
+        t->ctx->join_tail();
         CB_HIP(hipStreamSynchronize(t->ctx->stream));
         if (r.is_int) {
             int v = 0;
@@ -959,6 +982,7 @@ int cb_trainer_set_state(cb_trainer* t, const char* name, const float* host_src,
     StateRef r = find_state(t, name);
     CB_CHECK(numel == r.n, CB_ERR_SHAPE, "set_state '%s': %ld elements given, %ld expected", name, (long)numel, r.n);
     if (!t->ctx->dry) {
+        t->ctx->join_tail();
         CB_HIP(hipStreamSynchronize(t->ctx->stream));
         if (r.is_int) {
             int v = (int)host_src[0];

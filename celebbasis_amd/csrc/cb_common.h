@@ -70,11 +70,25 @@ struct Profiler {
         return (int)names.size() - 1;
     }
 };
+// Arrival counters of the in-launch split-K reduction (cb_gemm_glds.hip): device ints that are ZERO between launches (zeroed once
+// when the pool is created; the last-arriving block of a tile puts its counter back to zero). A launch takes a fresh range, the
+// ranges are rewound together with the step arena (same ranges every step: replay-stable like the arena's addresses).
+struct CounterPool {
+    int* base = nullptr; size_t cap = 0, off = 0;
+    bool dry = false;            // dry context: a placeholder address (nothing is launched), so that launch accounting matches a real one
+    int* take(size_t n) {
+        if (dry) return reinterpret_cast<int*>(0x300000);
+        n = (n + 31) / 32 * 32;
+        if (!base || off + n > cap) return nullptr;      // exhausted: the caller falls back to the separate reduce launch
+        int* p = base + off; off += n; return p;
+    }
+};
 struct Launch {
     hipStream_t stream = nullptr;
     bool dry = false;
     Stats* stats = nullptr;
     Profiler* prof = nullptr;
+    CounterPool* cnt = nullptr;
     void count(long n = 1) const { if (stats) stats->launches += n; }
 };
 

@@ -21,6 +21,7 @@ struct Arena {
     char* base = nullptr;
     size_t cap = 0, off = 0, peak = 0;
     bool dry = false;
+    CounterPool cnt;             // split-K arrival counters, rewound with the arena
     void* alloc(size_t bytes) {
         off = (size_t)rup((long)off, 256);
         if (!dry) CB_CHECK(off + bytes <= cap, CB_ERR_OOM, "step arena exhausted: need %zu, cap %zu", off + bytes, cap);
@@ -30,7 +31,7 @@ struct Arena {
         return p;
     }
     float* allocf(size_t n) { return static_cast<float*>(alloc(n * sizeof(float))); }
-    void reset() { off = 0; }
+    void reset() { off = 0; cnt.off = 0; }
 };
 
 // Persistent pool (weights, packed weights, optimiser state): grows in hipMalloc'ed slabs.
@@ -61,6 +62,17 @@ struct Ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;           // library-owned side stream: independent branches of the step (FR-net || VAE encode)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // Deferred tail of a training step (cb_models.hip, step_impl): the CLIP input-gradient chain, the coefficient head's backward and
+    // AdamW of step i are enqueued on `aux` and recorded in ev_tail instead of being joined into `stream` — step i+1's VAE encode
+    // (main stream, independent of the trainable tensors) then runs beside them. EVERY other consumer of this context joins first:
+    // launch() (all op- and graph-level entries), ensure_arena, the state / tap / sync entries (join_tail is one hipStreamWaitEvent).
+    hipEvent_t ev_tail = nullptr, ev_tail_fork = nullptr;
+    bool tail_pending = false; const void* tail_owner = nullptr;
+    void join_tail() {
+        if (!tail_pending) return;
+        tail_pending = false;
+        if (!dry && ev_tail) CB_HIP(hipStreamWaitEvent(stream, ev_tail, 0));
+    }
     bool dry = true;
     Arena arena;                 // per-step activations
     Pool pool;                   // persistent
@@ -76,7 +88,8 @@ struct Ctx {
     // the face warp's constant sampling grid [S][S][2] as the caller's host evaluated it (cb_ctx_set_warp_grid); nullptr = analytic
     float* warp_grid = nullptr; int warp_S = 0;
     const float* warp_grid_for(int S) const { return (warp_grid && warp_S == S) ? warp_grid : nullptr; }
-    Launch launch() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; return L; }
+    Launch launch() { join_tail(); return launch_nojoin(); }
+    Launch launch_nojoin() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; L.cnt = &arena.cnt; return L; }   // the trainer's own steps only
     void ensure_arena(size_t bytes);
     // upload a table entry to the device (raw fp32 copy); dims are checked against `expect` (-1 = any)
     float* upload(const WTab& wt, const std::string& name, std::initializer_list<int64_t> expect);
@@ -119,14 +132,15 @@ struct Graph {
     Launch L;
     std::deque<Ten> tens;
     std::vector<std::function<void()>> tape;
-    explicit Graph(Ctx* c) : ctx(c), L(c->launch()) {}
+    explicit Graph(Ctx* c, bool join_tail = true) : ctx(c), L(join_tail ? c->launch() : c->launch_nojoin()) {}
 
     Ten* make(int n, int h, int w, int c, bool rg, DType dt);
     Ten* wrap(const void* p, int n, int h, int w, int c, bool rg, DType dt);   // external buffer
     void* grad(Ten* t, float* beta);       // grad buffer for a writer; *beta = 0 on first write, 1 afterwards
     Ten* cast(Ten* x, DType dt);           // element-type change (differentiable); returns x itself when the type already matches
     void tap(const std::string& name, const Ten* t);
-    void backward();
+    void backward();                       // run (and drop) the whole tape, newest closure first
+    void backward_until(size_t mark);      // ... only the closures pushed at or after index `mark`
 
     // ops (forward now, backward pushed on the tape when an input requires grad)
     // epi (no-grad fp32 layers: the frozen FR backbone): PReLU on the output and / or a second output tensor c2 = scale[c] * y + shift[c]

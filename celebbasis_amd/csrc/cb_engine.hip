@@ -26,9 +26,17 @@ void Pool::release() {
     slabs.clear(); cur = nullptr; left = 0; total = 0;
 }
 
+constexpr size_t kArenaCounters = (size_t)1 << 20;      // 4 MB of split-K arrival counters per arena (a step takes ~1e5)
 void Ctx::ensure_arena(size_t bytes) {
-    if (dry) { arena.dry = true; return; }
+    if (dry) { arena.dry = true; arena.cnt.dry = true; return; }
+    if (!arena.cnt.base) {
+        void* c = nullptr;
+        CB_HIP(hipMalloc(&c, kArenaCounters * sizeof(int)));
+        CB_HIP(hipMemset(c, 0, kArenaCounters * sizeof(int)));
+        arena.cnt.base = static_cast<int*>(c); arena.cnt.cap = kArenaCounters; arena.cnt.off = 0;
+    }
     if (arena.cap >= bytes) return;
+    join_tail();                                       // a deferred step tail still reads the arena that is about to be freed
     CB_HIP(hipStreamSynchronize(stream));
     if (arena.base) CB_HIP(hipFree(arena.base));
     arena.base = nullptr; arena.cap = 0;
@@ -45,7 +53,10 @@ Ctx::~Ctx() {
         if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
+        if (ev_tail) (void)hipEventDestroy(ev_tail);
+        if (ev_tail_fork) (void)hipEventDestroy(ev_tail_fork);
         if (arena.base) (void)hipFree(arena.base);
+        if (arena.cnt.base) (void)hipFree(arena.cnt.base);
         if (warp_grid) (void)hipFree(warp_grid);
         pool.release();
     }
@@ -216,9 +227,13 @@ void* Graph::grad(Ten* t, float* beta) {
 void Graph::tap(const std::string& name, const Ten* t) {
     if (ctx->debug_taps) ctx->taps[name] = Ctx::Tap{t->p, t->numel(), t->dt};
 }
-void Graph::backward() {
-    for (auto it = tape.rbegin(); it != tape.rend(); ++it) (*it)();
-    tape.clear();
+void Graph::backward() { backward_until(0); }
+void Graph::backward_until(size_t mark) {
+    while (tape.size() > mark) {
+        std::function<void()> fn = std::move(tape.back());
+        tape.pop_back();
+        fn();
+    }
 }
 // fp32 <-> bf16 at the edges of a bf16 graph (the public tensors of the step, the coefficient head and the FR-net are fp32)
 Ten* Graph::cast(Ten* x, DType dt) {

@@ -222,7 +222,8 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
     const T* __restrict__ rowbias = static_cast<const T*>(a.rowbias);
     const long ldrb = a.ld_rowbias ? a.ld_rowbias : a.N;
     if (p.splitk > 1) {
-        float* W = p.ws + ((long)split * a.batch + z) * (long)a.M * a.N;
+        const long MN = (long)a.M * a.N;
+        float* W = p.ws + ((long)split * a.batch + z) * MN;
         const bool v4 = vec && (a.N % 4 == 0);
 #pragma unroll
         for (int ps = 0; ps < WR / RPP; ++ps) {
@@ -235,6 +236,19 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
                 const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
                 for (int e = 0; e < 8 && col + e < a.N; ++e) w[e] = v[e];
             }
+        }
+        if (!p.cnt) return;                               // partials only: splitk_reduce_kernel follows
+        const int tile = (m0 / BM) * p.tiles_n + n0 / BN;
+        if (!splitk_arrive(p.cnt + (long)z * (p.tiles_m * p.tiles_n) + tile, p.splitk, reinterpret_cast<int*>(lds))) return;
+        T* __restrict__ Cq = static_cast<T*>(a.C) + zb * a.sCb + zh * a.sCh;
+        const T* __restrict__ Rq = a.R ? static_cast<const T*>(a.R) + zb * a.sRb + zh * a.sRh : nullptr;
+        const float* W0 = p.ws + (long)z * MN;
+        for (int ps = 0; ps < WR / RPP; ++ps) {
+            const int rl = ps * RPP + rsub, row = m0 + wm * WR + rl;
+            if (row >= a.M || col >= a.N) continue;
+            float v[8];
+            splitk_fold8(v, W0 + (long)row * a.N + col, (long)a.batch * MN, p.splitk, v4, a.N - col);
+            glds_finish_piece<T>(a, v, bcol, Cq, Rq, rowbias, ldrb, row, col, vec);
         }
         return;
     }
@@ -641,6 +655,7 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
     const float* __restrict__ Rp = static_cast<const float*>(a.R);
     const float* __restrict__ rowbias = static_cast<const float*>(a.rowbias);
     const long ldrb = a.ld_rowbias ? a.ld_rowbias : a.N;
+    const long MN = (long)a.M * a.N;
     for (int q = tid; q < BM * 10; q += 256) {
         const int rl = q / 10, cc = (q - rl * 10) * 8;
         const int row = m0 + rl, col = n0 + cc;
@@ -658,7 +673,7 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         }
         const bool vec = (col + 8 <= a.N);
         if (p.splitk > 1) {
-            float* w = p.ws + (long)split * a.M * a.N + (long)row * a.N + col;
+            float* w = p.ws + (long)split * MN + (long)row * a.N + col;
             if (vec && (a.N % 4 == 0)) {
                 *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -667,6 +682,20 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
             continue;
         }
         float bcol[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bcol[e] = (a.bias && col + e < a.N) ? a.bias[col + e] : 0.f;
+        glds_finish_piece<float>(a, v, bcol, Cp, Rp, rowbias, ldrb, row, col, vec);
+    }
+    if (p.splitk <= 1 || !p.cnt) return;                  // (no counters: partials only, splitk_reduce_kernel follows)
+    // in-launch reduction: the tile's last-arriving block folds the splitk slabs in split order (cb_gemm_tiles.h, splitk_arrive)
+    if (!splitk_arrive(p.cnt + tm * p.tiles_n + tn, p.splitk, reinterpret_cast<int*>(lds80))) return;
+    for (int q = tid; q < BM * 10; q += 256) {
+        const int rl = q / 10, cc = (q - rl * 10) * 8;
+        const int row = m0 + rl, col = n0 + cc;
+        if (row >= a.M || col >= a.N) continue;
+        const bool vec = (col + 8 <= a.N);
+        float v[8], bcol[8];
+        splitk_fold8(v, p.ws + (long)row * a.N + col, MN, p.splitk, vec && (a.N % 4 == 0), a.N - col);
 #pragma unroll
         for (int e = 0; e < 8; ++e) bcol[e] = (a.bias && col + e < a.N) ? a.bias[col + e] : 0.f;
         glds_finish_piece<float>(a, v, bcol, Cp, Rp, rowbias, ldrb, row, col, vec);
@@ -812,12 +841,20 @@ static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KAr
     else launch_glds<float, AK, 128, 2>(pl, grid, s, ka);
 }
 
+// In-launch split-K reduction (cb_gemm_tiles.h, splitk_arrive): on unless CB_SPLITK_INLAUNCH=0 / cb_debug_splitk_inlaunch(0) (A/B and the
+// bitwise comparison of tests/test_gpu_ops.py: partials + splitk_reduce_kernel).
+static bool splitk_inlaunch_on() { return plan_force().splitk_inlaunch != 0; }
+static int* splitk_counters(const Launch& L, const Plan& pl, int batch) {
+    if (!splitk_inlaunch_on() || pl.splitk <= 1 || !L.cnt) return nullptr;
+    return L.cnt->take((size_t)pl.tiles_m * pl.tiles_n * batch);
+}
+
 // ---------------------------------------------------------------- offline autotuner (CB_AUTOTUNE=<file>)
 // For every distinct problem that reaches the LDS-DMA kernel on a real context, time all (tile, split-K) candidates on the
 // launch's own operands — outputs and partials go to scratch buffers, so the step itself is undisturbed and keeps running the
 // analytic plan (the arena was sized for it) — and append "<plan_key> <BM> <BN> <split> <us> | <analytic BM BN split us>" to the file.
 // tools/make_plan_table.py turns the file into cb_plan_table.inc. Batched (attention) problems are left to the model.
-template <typename T> static void launch_problem(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk);
+template <typename T> static void launch_problem(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk, int* cnt);
 struct Tuner { FILE* f = nullptr; std::unordered_map<std::string, int> seen; };
 static Tuner* tuner() {
     static Tuner* t = [] {
@@ -845,18 +882,22 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     size_t ws_max = 0;
     for (int sp : splits) if (sp > 1 && ksteps / sp >= 2) ws_max = std::max(ws_max, (size_t)sp * a.M * a.N * sizeof(float));
     ws_max = std::min(ws_max, (size_t)1 << 30);
-    void* ctmp = nullptr; void* wtmp = nullptr;
+    void* ctmp = nullptr; void* wtmp = nullptr; void* cnttmp = nullptr;
     CB_HIP(hipDeviceSynchronize());                      // the other streams' work would disturb the timings
     CB_HIP(hipMalloc(&ctmp, out_elems * sizeof(T)));
     if (ws_max) CB_HIP(hipMalloc(&wtmp, ws_max));
+    if (ws_max && splitk_inlaunch_on()) {       // candidates are timed the way they would run: in-launch reduction
+        const size_t nc = (size_t)cdiv(a.M, 16) * cdiv(a.N, 64) + 64;
+        CB_HIP(hipMalloc(&cnttmp, nc * sizeof(int))); CB_HIP(hipMemset(cnttmp, 0, nc * sizeof(int)));
+    }
     GemmArgs b = a;
     b.C = ctmp; b.beta = 0.f;
     hipEvent_t e0, e1;
     CB_HIP(hipEventCreate(&e0)); CB_HIP(hipEventCreate(&e1));
     auto time_plan = [&](const Plan& pl) {
-        for (int i = 0; i < 2; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk);
+        for (int i = 0; i < 2; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk, static_cast<int*>(cnttmp));
         CB_HIP(hipEventRecord(e0, L.stream));
-        for (int i = 0; i < 5; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk);
+        for (int i = 0; i < 5; ++i) launch_problem<T>(L.stream, b, pl, static_cast<float*>(wtmp), bk, static_cast<int*>(cnttmp));
         CB_HIP(hipEventRecord(e1, L.stream));
         CB_HIP(hipEventSynchronize(e1));
         float ms = 0.f; CB_HIP(hipEventElapsedTime(&ms, e0, e1));
@@ -883,33 +924,33 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     fprintf(t->f, "%s %d %d %d %.2f | %d %d %d %.2f\n", key.c_str(), bp.BM, bp.BN, bp.splitk, best, model.BM, model.BN, model.splitk, t_model);
     fflush(t->f);
     CB_HIP(hipEventDestroy(e0)); CB_HIP(hipEventDestroy(e1));
-    CB_HIP(hipFree(ctmp)); if (wtmp) CB_HIP(hipFree(wtmp));
+    CB_HIP(hipFree(ctmp)); if (wtmp) CB_HIP(hipFree(wtmp)); if (cnttmp) CB_HIP(hipFree(cnttmp));
 }
 
-template <> void launch_problem<bf16_t>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
+template <> void launch_problem<bf16_t>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk, int* cnt) {
     KArgs ka;
     ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe; ka.cnt = pl.splitk > 1 ? cnt : nullptr;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     if (a.a_kind == LD_ROW) launch_tiles_bf16<AK_ROW>(pl, grid, s, ka);
     else if (convf) launch_tiles_bf16<AK_CONVF>(pl, grid, s, ka);
     else launch_tiles_bf16<AK_CONV>(pl, grid, s, ka);
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !ka.cnt) {
         long total = (long)a.M * a.N * a.batch;
         hipLaunchKernelGGL(splitk_reduce_kernel<bf16_t>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, ka);
     }
 }
-template <> void launch_problem<float>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk) {
+template <> void launch_problem<float>(hipStream_t s, const GemmArgs& a, const Plan& pl, float* ws, int bk, int* cnt) {
     KArgs ka;
     ka.a = a; ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n; ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe; ka.cnt = pl.splitk > 1 ? cnt : nullptr;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     if (a.a_kind == LD_ROW) launch_tiles_f32<AK_ROW>(pl, grid, s, ka);
     else if (convf) launch_tiles_f32<AK_CONVF>(pl, grid, s, ka);
     else launch_tiles_f32<AK_CONV>(pl, grid, s, ka);
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !ka.cnt) {
         long total = (long)a.M * a.N * a.batch;
         hipLaunchKernelGGL(splitk_reduce_kernel<float>, dim3((unsigned)std::min<long>((total + 255) / 256, 4096)), dim3(256), 0, s, ka);
     }
@@ -936,7 +977,8 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
     const int bk = f32_glds_bk();
     Plan pl = make_plan(a, bk, f32_glds_speed(), n80_ok(a));
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
-    L.count(pl.splitk > 1 ? 2 : 1);
+    int* const cnt = splitk_counters(L, pl, a.batch);
+    L.count(pl.splitk > 1 && !cnt ? 2 : 1);
     gemm_log(a, pl, bk);
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
@@ -948,7 +990,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
     ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe; ka.cnt = cnt;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bk == 0);
     ProfRec rec; bool prof = L.prof && L.prof->on;
@@ -970,7 +1012,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !cnt) {
         long total = (long)a.M * a.N * a.batch;
         unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
         ProfRec r2;
@@ -1015,7 +1057,8 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_CHECK(a.ldb % 8 == 0 && a.sBb % 8 == 0 && a.sBh % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: B strides must be multiples of 8 elements");
     Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed);
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
-    L.count(pl.splitk > 1 ? 2 : 1);
+    int* const cnt = splitk_counters(L, pl, a.batch);
+    L.count(pl.splitk > 1 && !cnt ? 2 : 1);
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
         CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1036,7 +1079,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     ka.a = a;
     ka.tiles_m = pl.tiles_m; ka.tiles_n = pl.tiles_n;
     ka.splitk = pl.splitk; ka.k_per_split = pl.k_per_split;
-    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe;
+    ka.ws = ws; ka.a_vec = 1; ka.b_vec = 1; ka.safe = plan_force().glds_safe; ka.cnt = cnt;
     dim3 grid(pl.tiles_m * pl.tiles_n, pl.splitk, a.batch);
     const bool convf = a.a_kind == LD_CONV && !a.g.up && !a.g.tr && (a.g.C % bf16_bk() == 0);
     ProfRec rec; bool prof = L.prof && L.prof->on;
@@ -1058,7 +1101,7 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }
-    if (pl.splitk > 1) {
+    if (pl.splitk > 1 && !cnt) {
         long total = (long)a.M * a.N * a.batch;
         unsigned nb = (unsigned)std::min<long>((total + 255) / 256, 4096);
         ProfRec r2;

@@ -126,6 +126,8 @@ struct Trainer {
     float* sqrt_ac = nullptr; float* sqrt_1mac = nullptr;
     float* loss = nullptr;                        // device scalar
     size_t arena_need = 0; int arena_B = 0;
+    bool capturing = false;                       // step_impl runs under hipStreamBeginCapture (no deferred tail)
+    bool tail_overlap = true;                     // cb_trainer_set_tail_overlap / CB_TAIL_OVERLAP=0: the step's tail on the side stream, joined lazily
     // ---- optional first-stage prefetch (trainer_prefetch): the frozen, gradient-free stages of the NEXT batch (VAE encode ->
     // z0, FR backbone -> features) run on their own stream and arena while the current step's UNet is in flight
     struct Prefetch {
@@ -140,6 +142,7 @@ struct Trainer {
             if (ready) (void)hipEventDestroy(ready);
             for (auto& sl : slot) if (sl.done) (void)hipEventDestroy(sl.done);
             if (arena.base) (void)hipFree(arena.base);
+            if (arena.cnt.base) (void)hipFree(arena.cnt.base);
         }
     } pf;
     // ---- whole-step HIP-graph replay (SURVEY §8 B3 `cb_train_step`): the fixed-shape step — ~1 650 launches on two streams — is captured

@@ -457,7 +457,8 @@ Ten* frnet_forward(Graph& G, const FrNet& F, Ten* img) {
 // ================================================================= training step
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     T->ctx = ctx; T->cfg = cfg;
-    { const char* e = getenv("CB_STEP_GRAPH"); T->graph.enabled = e && e[0] == '1'; }      // opt-in: measured flat on MI355X (profiles/README.md, round 5)
+    { const char* e = getenv("CB_STEP_GRAPH"); T->graph.enabled = e && e[0] == '1'; }
+    { const char* e = getenv("CB_TAIL_OVERLAP"); T->tail_overlap = !(e && e[0] == '0'); }          // default on; cb_trainer_set_tail_overlap      // opt-in: measured flat on MI355X (profiles/README.md, round 5)
     unet_load(ctx, wt, "model.diffusion_model.", cfg.unet, &T->unet);
     vae_load(ctx, wt, "first_stage_model.", cfg.vae, &T->vae);
     clip_load(ctx, wt, "cond_stage_model.transformer.text_model.", cfg.clip, &T->clip);
@@ -530,7 +531,7 @@ static Ten* first_stage_latent(Graph& G, Trainer* T, const Batch& bt) {
 
 static void prefetch_impl(Trainer* T, const Batch& bt, Trainer::Prefetch::Slot& sl) {
     Ctx* ctx = T->ctx;
-    Graph G(ctx);
+    Graph G(ctx, /*join_tail=*/false);          // own stream, own arena, frozen weights only: a deferred step tail is no business of the prefetch
     G.L.stream = T->pf.stream;
     if (!T->cfg.use_rm_mlp) {
         Ten* feat = first_stage_faces(G, T, bt);
@@ -602,7 +603,9 @@ void trainer_prefetch(Trainer* T, const Batch& bt) {
 static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ctx* ctx = T->ctx;
     const TrainerCfg& c = T->cfg;
-    Graph G(ctx);
+    // no join of the previous step's deferred tail here: it runs on the side stream, this step's side branch queues behind it and the
+    // VAE encode on the context stream touches neither its arena regions nor the trainable tensors (see the end of this function)
+    Graph G(ctx, /*join_tail=*/false);
     const Launch& L = G.L;
     const int B = bt.B, S_ = c.image_size, w = c.clip.width, es = c.es, K = c.inner_dim, T77 = c.clip.ctx_len;
     const int zc = c.vae.z_channels;
@@ -665,6 +668,8 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ten* cond32 = clip_encode(G, T->clip, emb1);
     Ten* cond = G.cast(cond32, T->unet.dt);
     ph_clip.reset();
+    const size_t tape_mark = G.tape.size();          // closures below this index: conditioning -> CLIP -> pseudo-word rows (the step's tail)
+    const size_t id_region_end = ctx->arena.off;     // arena [0, id_region_end): identity branch + CLIP activations (what the tail reads)
 
     if (fork) { CB_HIP(hipEventRecord(ctx->ev_join, ctx->aux)); G.L.stream = main_stream; }
 
@@ -676,7 +681,10 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         G.tap("z0", z0);
     }
 
-    if (fork) CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));   // join: the UNet needs the conditioning
+    const size_t vae_region_end = ctx->arena.off;    // arena [id_region_end, vae_region_end): the first stage (context stream, before the join)
+    // join: the UNet needs the conditioning. ev_join was recorded on the side stream BEHIND the previous step's deferred tail, so this
+    // wait also orders that tail before everything below
+    if (fork) { CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0)); ctx->tail_pending = false; }
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
     std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));
@@ -689,10 +697,30 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     ph_uf.reset();
 
     // (7) backward: UNet dgrad -> context -> CLIP dgrad -> rows p, p+1 -> basis^T -> norm -> LeakyReLU -> dW, db
+    // The tail — everything after d context: ~190 launches of 77-row problems, the head's backward, AdamW — reads only the identity /
+    // CLIP region of the arena and what the backward allocates above the UNet's, writes only trainer-owned state, and is needed by
+    // nothing before the NEXT step's side branch (FR-net -> head -> CLIP forward, which reads the updated W). It is therefore enqueued on
+    // the side stream and NOT joined: the next step's VAE encode (context stream; arena region [id_region_end, vae_region_end), frozen
+    // weights, the caller's image) runs beside it, and its side branch queues behind it in stream order. Whoever else touches the
+    // context joins first (Ctx::join_tail). Off under the profiler / debug taps / graph capture / use_rm_mlp (whose tail reads the
+    // caller's `ids`) and with CB_TAIL_OVERLAP=0: the tail then runs on the context stream as before. Same kernels, same order: bitwise.
+    const bool defer_tail = fork && T->tail_overlap && !c.use_rm_mlp && !ctx->debug_taps && !ctx->prof.on && !T->capturing;
     {
         Phase ph(L, "phase:backward_unet_clip");
+        if (defer_tail) {
+            G.backward_until(tape_mark);
+            CB_CHECK(id_region_end <= vae_region_end && vae_region_end <= ctx->arena.off, CB_ERR_STATE, "step arena regions out of order");
+            CB_HIP(hipEventRecord(ctx->ev_tail_fork, main_stream));
+            CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_tail_fork, 0));
+            G.L.stream = ctx->aux;
+        }
         G.backward();
     }
+    struct TailDone {      // record the tail's end on every exit path of the function below (use_rm_mlp returns early, but never defers)
+        Ctx* ctx; Graph& G; hipStream_t main; bool on;
+        const void* owner;
+        ~TailDone() { if (on) { (void)hipEventRecord(ctx->ev_tail, ctx->aux); ctx->tail_pending = true; ctx->tail_owner = owner; G.L.stream = main; } }
+    } tail_done{ctx, G, main_stream, defer_tail, T};
     Phase ph_tail(L, "phase:head_bwd_adamw");
     CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");
     if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());
@@ -739,6 +767,7 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
         g.t = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * sizeof(int64_t)));
     }
     hipStream_t s = ctx->stream;
+    ctx->join_tail();                 // an eager step may have left its tail on the side stream
     auto stage = [&](void* dst, const void* src, size_t bytes) { CB_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s)); };
     stage(g.image, bt.image, (size_t)B * S_ * S_ * 3 * sizeof(float));
     stage(g.faces, bt.faces, (size_t)B * S_ * S_ * 6 * sizeof(float));
@@ -770,8 +799,10 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
         ctx->stream = g.cap;
         hipError_t rcb = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal);
         if (rcb != hipSuccess) { ctx->stream = s; CB_HIP(rcb); }
+        T->capturing = true;          // every forked stream must rejoin the capture stream: no deferred tail
         try { step_impl(T, sb, lr); }
-        catch (...) { ctx->stream = s; (void)hipStreamEndCapture(g.cap, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        catch (...) { T->capturing = false; ctx->stream = s; (void)hipStreamEndCapture(g.cap, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+        T->capturing = false;
         ctx->stream = s;
         CB_HIP(hipStreamEndCapture(g.cap, &graph));
         hipGraphExec_t exec = nullptr;
@@ -807,6 +838,8 @@ void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only) {
             if (sl.valid && sl.image == bt.image && sl.faces == bt.faces && sl.post_noise == bt.post_noise && sl.B == bt.B) prefetched = true;
         if (!prefetched) { step_graph(T, bt, lr); return; }
     }
+    // a deferred tail is left alone only by the NEXT step of the SAME trainer at the SAME batch size (same arena offsets)
+    if (ctx->tail_pending && (ctx->tail_owner != T || T->arena_B != bt.B || dry_only)) ctx->join_tail();
     if (ctx->dry || dry_only || T->arena_B != bt.B) {
         bool was_dry = ctx->dry;
         Stats saved = ctx->stats;

@@ -43,7 +43,7 @@ class CBError(RuntimeError):
 
 
 # ---------------------------------------------------------------- C structs (mirror include/celebbasis_hip.h)
-ABI_VERSION = 302        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
+ABI_VERSION = 303        # CB_ABI_VERSION of include/celebbasis_hip.h these bindings mirror
 
 
 class _Sized(C.Structure):
@@ -107,7 +107,7 @@ class Batch(C.Structure):
 # every symbol include/celebbasis_hip.h declares (tests/test_abi.py checks the .so exports all of them)
 ABI_SYMBOLS = [
     "cb_last_error", "cb_version", "cb_ctx_create", "cb_ctx_create_dtype", "cb_ctx_dtype", "cb_ctx_aux_stream", "cb_ctx_destroy", "cb_ctx_sync", "cb_ctx_stats", "cb_ctx_reset_stats",
-    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm", "cb_debug_glds_safe",
+    "cb_ctx_set_debug_taps", "cb_ctx_tap", "cb_ctx_profile_begin", "cb_ctx_profile_end", "cb_wtab_create", "cb_wtab_add", "cb_wtab_destroy", "cb_gemm", "cb_debug_glds_safe", "cb_debug_splitk_inlaunch", "cb_trainer_set_tail_overlap",
     "cb_pack_conv_weight", "cb_conv2d_fwd", "cb_conv2d_dgrad", "cb_groupnorm_silu_fwd", "cb_groupnorm_silu_bwd",
     "cb_layernorm_fwd", "cb_layernorm_bwd", "cb_geglu_fwd", "cb_geglu_bwd", "cb_attention", "cb_timestep_embedding",
     "cb_q_sample", "cb_mse_loss", "cb_ctx_set_warp_grid", "cb_face_warp_resize", "cb_row_surgery", "cb_adamw_step", "cb_nchw_to_nhwc",
@@ -124,7 +124,7 @@ _ARGTYPES = {
     "cb_last_error": [], "cb_version": [],
     "cb_ctx_create": [_I, _P, _P], "cb_ctx_create_dtype": [_I, _P, _I, _P], "cb_ctx_dtype": [_P, _P], "cb_ctx_aux_stream": [_P, _P], "cb_ctx_destroy": [_P], "cb_ctx_sync": [_P], "cb_ctx_stats": [_P, _P, _P, _P, _P],
     "cb_ctx_reset_stats": [_P], "cb_ctx_set_debug_taps": [_P, _I], "cb_ctx_tap": [_P, C.c_char_p, _P, _L, _P],
-    "cb_debug_glds_safe": [_I], "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
+    "cb_debug_glds_safe": [_I], "cb_debug_splitk_inlaunch": [_I], "cb_trainer_set_tail_overlap": [_P, _I], "cb_ctx_profile_begin": [_P], "cb_ctx_profile_end": [_P, C.c_char_p, _L],
     "cb_wtab_create": [_P], "cb_wtab_add": [_P, C.c_char_p, _P, _I, _I, _P], "cb_wtab_destroy": [_P],
     "cb_gemm": [_P, _P], "cb_pack_conv_weight": [_P, _P, _P, _I, _I, _I, _I],
     "cb_conv2d_fwd": [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I],
@@ -586,6 +586,11 @@ class Trainer(_Handle):
     def set_graph_replay(self, on=True):
         """whole-step HIP-graph replay (cb_trainer_set_graph_replay); opt-in (or CB_STEP_GRAPH=1)"""
         check(load().cb_trainer_set_graph_replay(self.h, C.c_int(1 if on else 0)))
+
+    def set_tail_overlap(self, on=True):
+        """deferred step tail (cb_trainer_set_tail_overlap): default on; off = the CLIP gradient chain / head backward / AdamW are
+        joined into the context stream before `step` returns (A/B measurements, bitwise comparison)"""
+        check(load().cb_trainer_set_tail_overlap(self.h, C.c_int(1 if on else 0)))
 
     def graph_stats(self):
         c, r = C.c_int64(), C.c_int64()

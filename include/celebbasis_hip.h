@@ -58,7 +58,7 @@ const char* cb_last_error(void);
  * a binding compares the two at load time (celebbasis_amd/lib.py does). Every descriptor struct that has grown since 100 starts with
  * `struct_size` = sizeof(the struct as the CALLER compiled it); the library rejects any other size with CB_ERR_ARG instead of
  * reading fields the caller never wrote. */
-#define CB_ABI_VERSION 302
+#define CB_ABI_VERSION 303
 int cb_version(void);
 
 /* ---- context ------------------------------------------------------------------------------------ */
@@ -67,7 +67,8 @@ int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out); 
 int cb_ctx_dtype(cb_ctx* ctx, int* dtype);
 /* The library-owned side stream (hipStream_t) on which cb_trainer_step runs the identity branch — it reads the caller's `faces`,
  * `ids` and `tokens` buffers there, forked from AND JOINED BACK INTO the context stream with events inside the call: when the call
- * returns every read is ordered before later context-stream work, so no record_stream is needed for it (exposed for profilers). */
+ * returns every read of CALLER memory is ordered before later context-stream work, so no record_stream is needed for it (exposed for
+ * profilers). The step's deferred tail (cb_trainer_set_tail_overlap) also runs here; it touches library-owned memory only. */
 int cb_ctx_aux_stream(cb_ctx* ctx, void** hip_stream);
 int cb_ctx_destroy(cb_ctx* ctx);
 int cb_ctx_sync(cb_ctx* ctx);
@@ -124,6 +125,12 @@ int cb_debug_force_plan(int BM, int BN, int split);
  * makes every later launch of this process drain the queue (`vmcnt(0)`) and use a full barrier instead — the slow reference pipeline the
  * counted one must agree with bit for bit (also: environment CB_GLDS_SAFE=1). Process-global, not thread safe. */
 int cb_debug_glds_safe(int on);
+/* diagnostics: a split-K launch of the LDS-DMA kernels folds its partial slabs INSIDE the launch — every block publishes its fp32 slab
+ * (agent-scope release), draws a ticket from a per-tile arrival counter, and the tile's last block sums all slabs in split order and
+ * runs the epilogue (deterministic: the order does not depend on who arrives last). on == 0 restores partials + the separate
+ * splitk_reduce_kernel launch, which sums in the same order: the two must agree bit for bit (tests/test_gpu_ops.py; also environment
+ * CB_SPLITK_INLAUNCH=0). Process-global, not thread safe. */
+int cb_debug_splitk_inlaunch(int on);
 
 /* OIHW -> implicit-GEMM packs. dgrad=0: [O][ky][kx][I]; dgrad=1: [I][ky'][kx'][O] with the kernel flipped; dgrad=2 (3x3 only):
  * [I][4][4][O], the input gradient of "nearest x2 upsample + conv3x3" (openaimodel.py Upsample) as ONE 4x4 stride-2 pad-1 conv over dy
@@ -303,6 +310,18 @@ int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
  * streams take the hardware queues cb_trainer_prefetch's overlap needs. With replay on, the eager path still serves the first step at
  * a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from cb_trainer_prefetch. */
 int cb_trainer_set_graph_replay(cb_trainer* t, int enable);
+/* Deferred step tail (default ON; environment CB_TAIL_OVERLAP=0 or enable = 0 turns it off). Everything of a step after the UNet's
+ * input gradient has reached the conditioning — the CLIP text transformer's input-gradient chain (~190 launches of 77-row problems),
+ * the coefficient head's backward and AdamW (ddpm.py:1442-1454) — reads no caller memory and is needed by nothing before the NEXT
+ * step's identity branch (which reads the updated weights). cb_trainer_step therefore enqueues it on the library's side stream and
+ * does NOT make the context stream wait for it: the next step's VAE encode (context stream, frozen weights only) runs beside it, the
+ * next step's identity branch queues behind it in side-stream order. Same kernels in the same order: results are bitwise those of
+ * the joined form. What changes for the CALLER: when cb_trainer_step returns, the trainable state (mlp.*, adam.*, step) may still be
+ * in flight on the side stream although the context stream has drained. Every library entry that could observe it — cb_ctx_sync,
+ * cb_trainer_get_state / _set_state, cb_ctx_tap, every op- and graph-level call on the context, the next cb_trainer_step — joins
+ * first (one hipStreamWaitEvent). cb_trainer_loss_to does not need to (the loss is written on the context stream). The tail is
+ * not deferred under cb_ctx_profile_begin, debug taps, graph capture, or use_rm_mlp (whose tail reads the caller's `ids`). */
+int cb_trainer_set_tail_overlap(cb_trainer* t, int enable);
 int cb_trainer_graph_stats(cb_trainer* t, int64_t* captures, int64_t* replays);
 /* Optional software pipelining across steps: enqueue the gradient-free first stage of the NEXT batch (VAE encode -> latent,
  * FR backbone -> face features; only image / faces / post_noise / B of `next` are read) on a library-owned stream so that it

@@ -152,7 +152,7 @@ def test_descriptor_struct_size_guard(cbf):
     """a caller compiled against another header revision passes a descriptor of another size: rejected, not read"""
     lib, ctx = cbf
     d = lib.GemmDesc()
-    assert d.struct_size == C.sizeof(lib.GemmDesc) and lib.load().cb_version() == lib.ABI_VERSION == 302
+    assert d.struct_size == C.sizeof(lib.GemmDesc) and lib.load().cb_version() == lib.ABI_VERSION == 303
     d.struct_size -= 8
     assert lib.load().cb_gemm(ctx.h, C.byref(d)) != 0 and b"struct_size" in lib.load().cb_last_error()
     ad = lib.AttentionDesc(); ad.struct_size = 0

@@ -383,6 +383,54 @@ def test_graph_replay_is_bitwise_the_eager_step_sd14(cb):
     REPORT["graph_replay.sd14"] = g["stats"]
 
 
+def _tail_run(lib, ctx, m, seed, script, overlap):
+    """`script` = [(B, lr), ...] on a fresh trainer with the step's tail deferred to the side stream (`overlap`) or joined; nothing is read
+    back between the steps (the loss goes to a device tensor in stream order), so consecutive steps really overlap"""
+    from oracle import cb_oracle as O
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = cached_weights(O, shapes, seed)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    ctx.set_debug_taps(False)
+    tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+    tr.set_tail_overlap(overlap)
+    losses = []
+    for s, (B, lr) in enumerate(script):
+        dev = {k: dv(v) for k, v in make_batch(B, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 300 + s, m["max_ids"]).items()}
+        tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], lr)
+        del dev                                  # freed in context-stream order right after the call: the tail reads no caller memory
+        losses.append(tr.loss_tensor(torch.device("cuda:0")))
+    out = dict(W=tr.get_state("mlp.weight").clone(), b=tr.get_state("mlp.bias").clone(), mW=tr.get_state("adam.m_weight").clone(),
+               vW=tr.get_state("adam.v_weight").clone(), idc=tr.get_state("id_coefficients").clone(), ide=tr.get_state("id_embeddings").clone(),
+               gW=tr.get_state("mlp.grad_weight").clone(), step=float(tr.get_state("step")[0]), losses=[float(l) for l in losses])
+    tr.close()
+    return out
+
+
+def test_deferred_tail_is_bitwise_the_joined_step_mini(cb):
+    """cb_trainer_set_tail_overlap (default on): the CLIP input-gradient chain, the head's backward and AdamW of step i run on the side
+    stream beside step i+1's VAE encode and are joined lazily. Same kernels, same order, disjoint arena regions: the end state after
+    back-to-back steps — across a change of batch size, which re-plans the arena and must join first — is BITWISE the joined form's."""
+    lib, ctx = cb
+    script = [(1, 5e-3)] * 6 + [(2, 1e-2)] * 3 + [(1, 5e-3)] * 3
+    a = _tail_run(lib, ctx, MINI, 4, script, True)
+    b = _tail_run(lib, ctx, MINI, 4, script, False)
+    assert a["step"] == b["step"] == len(script)
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    for k in ("W", "b", "mW", "vW", "idc", "ide", "gW"):
+        assert torch.equal(a[k], b[k]), f"deferred tail changed {k}: max diff {(a[k] - b[k]).abs().max().item():.3e}"
+
+
+def test_deferred_tail_is_bitwise_the_joined_step_sd14(cb):
+    """the same at SD v1-4 size, bs=1: 6 back-to-back steps of the ~1 400-launch two-stream step"""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    a = _tail_run(lib, ctx, SD14(O), 8, [(1, 5e-3)] * 6, True)
+    b = _tail_run(lib, ctx, SD14(O), 8, [(1, 5e-3)] * 6, False)
+    assert a["losses"] == b["losses"], (a["losses"], b["losses"])
+    for k in ("W", "b", "mW", "vW", "idc", "ide", "gW"):
+        assert torch.equal(a[k], b[k]), f"deferred tail changed {k}: max diff {(a[k] - b[k]).abs().max().item():.3e}"
+
+
 SD14 = lambda O: dict(unet=O.UNET_SD14, vae=O.VAE_SD14, clip=O.CLIP_L14, fr=O.FR_R100, es=2, inner=512, max_ids=10, image=512,
                       placeholder=O.PLACEHOLDER_SKS)
 

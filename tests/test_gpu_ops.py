@@ -215,7 +215,8 @@ def test_gemm_n80_tiles(cb, bm, M, N, K, extra, split):
     ran = [r["kernel"] for r in prof]
     # a pinned plan the problem is not eligible for is dropped silently by the planner (cb_gemm_tiles.h): the test must see the kernel it names
     assert any(k.startswith(f"gemm_glds80_kernel<float,{bm},80,") for k in ran), f"the {bm}x80 kernel did not run: {ran}"
-    assert (split > 1) == any(k.startswith("splitk_reduce") for k in ran), (split, ran)
+    # split-K folds its partials inside the launch (cb_debug_splitk_inlaunch, on by default): no reduce kernel follows
+    assert not any(k.startswith("splitk_reduce") for k in ran), (split, ran)
     key = f"gemm[{M}x{N}x{K},a0b0,batch1,{extra}]"
     REPORT[f"n80.{bm}/{split}." + key] = REPORT.pop(key)
 
@@ -268,6 +269,48 @@ def test_n80_fast_pieces_match_safe_mode(cb):
     for (safe, bm, M, N, K), v in outs.items():
         if safe == 0:
             assert v.abs().max() > 0 and torch.equal(v, outs[(1, bm, M, N, K)]), (bm, M, N, K)
+
+
+@pytest.mark.parametrize("plan", [(64, 80, 4), (32, 80, 8), (16, 80, 4), (16, 80, 2), (64, 128, 3), (128, 128, 4), (128, 64, 2), (64, 64, 6)])
+def test_splitk_inlaunch_matches_reduce_kernel(cb, plan):
+    """Split-K launches fold their fp32 partial slabs INSIDE the launch: the tile's last-arriving block (agent-scope release / ticket /
+    acquire, cb_gemm_tiles.h::splitk_arrive) sums all slabs in split order and runs the epilogue. cb_debug_splitk_inlaunch(0) restores
+    partials + splitk_reduce_kernel, which sums in the same order: BIT FOR BIT the same C, whichever block arrives last — each case is
+    launched 12 times in a row (other launches in flight on the stream, L1-warm reducers) and every repeat must match, every word."""
+    lib, ctx = cb
+    L = lib.load()
+    bm, bn, split = plan
+    cases = [(64, 1280, 2560, "bias+res"), (77, 768, 3072, "bias"), (256, 1280, 5120, "none"), (130, 88, 520, "beta"), (1024, 640, 1280, "res")]
+    try:
+        lib.check(L.cb_debug_force_plan(bm, bn, split))
+        for ci, (M, N, K, extra) in enumerate(cases):
+            A = rnd(1, M, K, seed=ci + 1).to(_dev()); B = rnd(1, N, K, seed=ci + 20).to(_dev())
+            bias = rnd(N, seed=ci + 40).to(_dev()) if "bias" in extra else None
+            R = rnd(M, N, seed=ci + 60).to(_dev()) if "res" in extra else None
+            C0 = rnd(M, N, seed=ci + 80).to(_dev())
+            outs = {}
+            for mode, reps in ((0, 1), (1, 12)):
+                lib.check(L.cb_debug_splitk_inlaunch(mode))
+                for r in range(reps):
+                    Cd = C0.clone()
+                    d = lib.GemmDesc()
+                    d.A, d.B, d.C = A.data_ptr(), B.data_ptr(), Cd.data_ptr()
+                    d.M, d.N, d.K = M, N, K
+                    d.lda = d.ldb = K; d.ldc = N; d.batch = 1; d.alpha = 1.0
+                    d.beta = 1.0 if "beta" in extra else 0.0
+                    if bias is not None: d.bias = bias.data_ptr()
+                    if R is not None: d.R = R.data_ptr(); d.ldr = N
+                    lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+                    outs[(mode, r)] = Cd
+            ctx.sync()
+            ref = outs[(0, 0)].cpu()
+            assert ref.abs().max() > 0 and torch.isfinite(ref).all()
+            for r in range(12):
+                got = outs[(1, r)].cpu()
+                assert torch.equal(got, ref), f"plan {plan}, case {cases[ci]}, repeat {r}: in-launch reduction differs from splitk_reduce_kernel " \
+                                              f"(max {(got - ref).abs().max().item():.3e}, {(got != ref).sum().item()} words)"
+    finally:
+        lib.check(L.cb_debug_splitk_inlaunch(1)); lib.check(L.cb_debug_force_plan(0, 0, 0))
 
 
 @pytest.mark.parametrize("plan", [(64, 80), (32, 80), (16, 80), (64, 128), (64, 64)])

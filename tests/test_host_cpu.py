@@ -21,7 +21,7 @@ def test_abi_exports_every_declared_symbol(built_lib):
     missing = [s for s in sorted(declared) if not hasattr(built_lib, s)]
     assert not missing, f"declared in the header but not exported: {missing}"
     assert declared == set(lib.ABI_SYMBOLS), declared ^ set(lib.ABI_SYMBOLS)
-    assert built_lib.cb_version() == 302          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
+    assert built_lib.cb_version() == 303          # CB_ABI_VERSION of include/celebbasis_hip.h (struct_size-guarded descriptors)
 
 
 def test_integration_stub_matches_the_library(built_lib):
@@ -36,7 +36,7 @@ def test_integration_stub_matches_the_library(built_lib):
     block = re.search(r"```python\n(# ldm/models/diffusion/native_step.py.*?)```", text, re.S).group(1)
     block = block.replace('C.CDLL("libcelebbasis_hip.so")', f"C.CDLL({built_lib._name!r})")
     ns = {}
-    exec(compile(block, "INTEGRATION.md:native_step", "exec"), ns)          # runs the stub's own `assert lib.cb_version() == 302`
+    exec(compile(block, "INTEGRATION.md:native_step", "exec"), ns)          # runs the stub's own `assert lib.cb_version() == 303`
     so = ns["lib"]
     for name in set(re.findall(r"lib\.(cb_[a-z0-9_]+)", block)):
         assert hasattr(so, name), name
