@@ -61,11 +61,13 @@ struct Ctx {
     int device = -1;             // -1: dry (no GPU): shape checks and accounting only
     hipStream_t stream = nullptr;
     hipStream_t aux = nullptr;           // library-owned side stream: independent branches of the step (FR-net || VAE encode)
+    hipStream_t aux2 = nullptr;          // library-owned: a training step's deferred tail (below)
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // Deferred tail of a training step (cb_models.hip, step_impl): the CLIP input-gradient chain, the coefficient head's backward and
-    // AdamW of step i are enqueued on `aux` and recorded in ev_tail instead of being joined into `stream` — step i+1's VAE encode
-    // (main stream, independent of the trainable tensors) then runs beside them. EVERY other consumer of this context joins first:
-    // launch() (all op- and graph-level entries), ensure_arena, the state / tap / sync entries (join_tail is one hipStreamWaitEvent).
+    // AdamW of step i are enqueued on `aux2` and recorded in ev_tail instead of being joined into `stream` — step i+1's VAE encode
+    // (main stream) and FR backbone (`aux`), both independent of the trainable tensors, then run beside them; step i+1's head waits
+    // for ev_tail on `aux`. EVERY other consumer of this context joins first: launch() (all op- and graph-level entries),
+    // ensure_arena, the state / tap / sync entries (join_tail is one hipStreamWaitEvent).
     hipEvent_t ev_tail = nullptr, ev_tail_fork = nullptr;
     bool tail_pending = false; const void* tail_owner = nullptr;
     void join_tail() {

@@ -51,6 +51,7 @@ Ctx::~Ctx() {
     if (!dry) {
         (void)hipStreamSynchronize(stream);
         if (aux) { (void)hipStreamSynchronize(aux); (void)hipStreamDestroy(aux); }
+        if (aux2) { (void)hipStreamSynchronize(aux2); (void)hipStreamDestroy(aux2); }
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (ev_tail) (void)hipEventDestroy(ev_tail);

@@ -225,17 +225,17 @@ __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)
         const long MN = (long)a.M * a.N;
         float* W = p.ws + ((long)split * a.batch + z) * MN;
         const bool v4 = vec && (a.N % 4 == 0);
+        const __amdgpu_buffer_rsrc_t srdW = make_srd(W);
 #pragma unroll
         for (int ps = 0; ps < WR / RPP; ++ps) {
             const int rl = ps * RPP + rsub, row = m0 + wm * WR + rl;
             if (row >= a.M || col >= a.N) continue;
             const float4 v0 = *reinterpret_cast<const float4*>(S + rl * WC + cc), v1 = *reinterpret_cast<const float4*>(S + rl * WC + cc + 4);
+            const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            if (p.cnt) { splitk_store8(srdW, W, (int)(((long)row * a.N + col) * 4), v, v4, a.N - col); continue; }     // host: M * N * 4 < 2 GiB
             float* w = W + (long)row * a.N + col;
             if (v4) { *reinterpret_cast<float4*>(w) = v0; *reinterpret_cast<float4*>(w + 4) = v1; }
-            else {
-                const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                for (int e = 0; e < 8 && col + e < a.N; ++e) w[e] = v[e];
-            }
+            else for (int e = 0; e < 8 && col + e < a.N; ++e) w[e] = v[e];
         }
         if (!p.cnt) return;                               // partials only: splitk_reduce_kernel follows
         const int tile = (m0 / BM) * p.tiles_n + n0 / BN;
@@ -674,6 +674,7 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         const bool vec = (col + 8 <= a.N);
         if (p.splitk > 1) {
             float* w = p.ws + (long)split * MN + (long)row * a.N + col;
+            if (p.cnt) { splitk_store8(make_srd(p.ws + (long)split * MN), p.ws + (long)split * MN, (int)(((long)row * a.N + col) * 4), v, vec && (a.N % 4 == 0), a.N - col); continue; }
             if (vec && (a.N % 4 == 0)) {
                 *reinterpret_cast<float4*>(w) = make_float4(v[0], v[1], v[2], v[3]);
                 *reinterpret_cast<float4*>(w + 4) = make_float4(v[4], v[5], v[6], v[7]);
@@ -846,6 +847,7 @@ static void launch_tiles_f32(const Plan& pl, dim3 grid, hipStream_t s, const KAr
 static bool splitk_inlaunch_on() { return plan_force().splitk_inlaunch != 0; }
 static int* splitk_counters(const Launch& L, const Plan& pl, int batch) {
     if (!splitk_inlaunch_on() || pl.splitk <= 1 || !L.cnt) return nullptr;
+    if ((long)pl.tiles_m * pl.BM * (long)pl.tiles_n * pl.BN * 4 >= (1L << 31) - 64) return nullptr;     // slab offsets are 31-bit buffer offsets
     return L.cnt->take((size_t)pl.tiles_m * pl.tiles_n * batch);
 }
 

@@ -603,8 +603,8 @@ void trainer_prefetch(Trainer* T, const Batch& bt) {
 static void step_impl(Trainer* T, const Batch& bt, float lr) {
     Ctx* ctx = T->ctx;
     const TrainerCfg& c = T->cfg;
-    // no join of the previous step's deferred tail here: it runs on the side stream, this step's side branch queues behind it and the
-    // VAE encode on the context stream touches neither its arena regions nor the trainable tensors (see the end of this function)
+    // no join of the previous step's deferred tail here: it runs on its own stream; this step's VAE encode (context stream) and FR
+    // backbone (side stream) touch neither its arena cells nor the trainable tensors, the head below waits for it (see the end of this function)
     Graph G(ctx, /*join_tail=*/false);
     const Launch& L = G.L;
     const int B = bt.B, S_ = c.image_size, w = c.clip.width, es = c.es, K = c.inner_dim, T77 = c.clip.ctx_len;
@@ -642,6 +642,9 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         k_coef_gather(L, xn->pf(), T->coef, bt.ids, 2, B, 2, O, c.max_ids);
     } else {
         Ten* feat = prefetched ? G.wrap(ps->feat, NF, 1, 1, T->fr.feat, false, DT_F32) : first_stage_faces(G, T, bt);
+        // the previous step's deferred tail (third stream) ends in AdamW on W / b, and it still reads the arena cells that are rewritten
+        // from here on (xn, cn, v, pre, the CLIP activations); the FR backbone above touched neither
+        if (fork && ctx->tail_pending) CB_HIP(hipStreamWaitEvent(G.L.stream, ctx->ev_tail, 0));
         v = G.make(NF, 1, 1, I, false, DT_F32);
         k_l2norm_fwd(L, v->pf(), nullptr, feat->pf(), NF, I);
         Lin head; head.w = T->W; head.b = T->b; head.in = I; head.out = O;
@@ -682,8 +685,8 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     }
 
     const size_t vae_region_end = ctx->arena.off;    // arena [id_region_end, vae_region_end): the first stage (context stream, before the join)
-    // join: the UNet needs the conditioning. ev_join was recorded on the side stream BEHIND the previous step's deferred tail, so this
-    // wait also orders that tail before everything below
+    // join: the UNet needs the conditioning. ev_join was recorded on the side stream AFTER its wait for the previous step's deferred
+    // tail, so this wait also orders that tail before everything below
     if (fork) { CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0)); ctx->tail_pending = false; }
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
@@ -699,9 +702,11 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     // (7) backward: UNet dgrad -> context -> CLIP dgrad -> rows p, p+1 -> basis^T -> norm -> LeakyReLU -> dW, db
     // The tail — everything after d context: ~190 launches of 77-row problems, the head's backward, AdamW — reads only the identity /
     // CLIP region of the arena and what the backward allocates above the UNet's, writes only trainer-owned state, and is needed by
-    // nothing before the NEXT step's side branch (FR-net -> head -> CLIP forward, which reads the updated W). It is therefore enqueued on
-    // the side stream and NOT joined: the next step's VAE encode (context stream; arena region [id_region_end, vae_region_end), frozen
-    // weights, the caller's image) runs beside it, and its side branch queues behind it in stream order. Whoever else touches the
+    // nothing before the NEXT step's head (FR-net -> HEAD -> CLIP forward: the head reads the updated W). It is therefore enqueued on a
+    // third stream and NOT joined: the next step's VAE encode (context stream; arena region [id_region_end, vae_region_end), frozen
+    // weights, the caller's image) and FR backbone (side stream; its own activations, frozen weights, the caller's faces) run beside it,
+    // and the side stream waits for it right before the head. (On the side stream itself it bought nothing: FR-net + CLIP forward already
+    // take as long as the VAE encode, so a tail queued in front of them only moved the critical path there.) Whoever else touches the
     // context joins first (Ctx::join_tail). Off under the profiler / debug taps / graph capture / use_rm_mlp (whose tail reads the
     // caller's `ids`) and with CB_TAIL_OVERLAP=0: the tail then runs on the context stream as before. Same kernels, same order: bitwise.
     const bool defer_tail = fork && T->tail_overlap && !c.use_rm_mlp && !ctx->debug_taps && !ctx->prof.on && !T->capturing;
@@ -711,15 +716,15 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
             G.backward_until(tape_mark);
             CB_CHECK(id_region_end <= vae_region_end && vae_region_end <= ctx->arena.off, CB_ERR_STATE, "step arena regions out of order");
             CB_HIP(hipEventRecord(ctx->ev_tail_fork, main_stream));
-            CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_tail_fork, 0));
-            G.L.stream = ctx->aux;
+            CB_HIP(hipStreamWaitEvent(ctx->aux2, ctx->ev_tail_fork, 0));
+            G.L.stream = ctx->aux2;
         }
         G.backward();
     }
     struct TailDone {      // record the tail's end on every exit path of the function below (use_rm_mlp returns early, but never defers)
         Ctx* ctx; Graph& G; hipStream_t main; bool on;
         const void* owner;
-        ~TailDone() { if (on) { (void)hipEventRecord(ctx->ev_tail, ctx->aux); ctx->tail_pending = true; ctx->tail_owner = owner; G.L.stream = main; } }
+        ~TailDone() { if (on) { (void)hipEventRecord(ctx->ev_tail, ctx->aux2); ctx->tail_pending = true; ctx->tail_owner = owner; G.L.stream = main; } }
     } tail_done{ctx, G, main_stream, defer_tail, T};
     Phase ph_tail(L, "phase:head_bwd_adamw");
     CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");

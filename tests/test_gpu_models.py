@@ -101,30 +101,41 @@ def test_frnet_mini_vs_reference_golden(cb, golden_dir):
     close("frnet_mini.features", out, fx["out"], 1e-4)
 
 
+@pytest.mark.parametrize("inlaunch", [1, 0])
 @pytest.mark.parametrize("plan", [(16, 80, 2), (32, 80, 3), (64, 80, 1), (64, 64, 2), (64, 64, 4), (128, 128, 1)])
-def test_frnet_mini_fused_epilogues_under_pinned_plans(cb, golden_dir, plan):
+def test_frnet_mini_fused_epilogues_under_pinned_plans(cb, golden_dir, plan, inlaunch):
     """the FR backbone's fused conv epilogues (PReLU on the output; the next block's BatchNorm as a second output) on every route a plan can
-    send them through: the 80-column tiles with in-block k-groups, a cross-block split-K whose REDUCE kernel then applies the epilogue, the
-    64x64 and 128x128 tiles — pinned with cb_debug_force_plan (a layer the pinned tile is not eligible for keeps the planner's choice) and
-    held to the reference's golden features (round-4 advisor finding: the epilogue had no test under forced split-K / 80-column tiles)."""
+    send them through: the 80-column tiles with in-block k-groups, a cross-block split-K whose last-arriving block (in-launch reduction,
+    the default) or whose REDUCE kernel (cb_debug_splitk_inlaunch(0)) then applies the epilogue, the 64x64 and 128x128 tiles — pinned with
+    cb_debug_force_plan (a layer the pinned tile is not eligible for keeps the planner's choice) and held to the reference's golden
+    features (round-4 advisor finding: the epilogue had no test under forced split-K / 80-column tiles)."""
     from oracle import cb_oracle as O
     lib, ctx = cb
+    if not inlaunch and plan[2] == 1:
+        pytest.skip("no split-K in this plan: one route")
     fx = load(golden_dir, "frnet_mini.pt")
     c = fx["cfg"]
     W = O.init_weights(O.frnet_param_shapes(c), seed=fx["weight_seed"])
     f = lib.FrNet(ctx, lib.WeightTable(W), layers=c["layers"], width=c["width"], in_size=c["in_size"], feat=c["feat"])
     lib.check(lib.load().cb_debug_force_plan(*plan))
+    lib.check(lib.load().cb_debug_splitk_inlaunch(inlaunch))
     ctx.profile_begin()
     try:
         out = f.forward(dv(fx["x"].permute(0, 2, 3, 1)))
         ctx.sync()
     finally:
         lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
-        ran = [r["kernel"] for r in ctx.profile_end()]
-    close(f"frnet_mini.features[plan {plan}]", out, fx["out"], 1e-4)
-    if plan[2] > 1:
-        assert any(k.startswith("splitk_reduce") for k in ran), ran
-    REPORT[f"frnet_mini.pinned_plan{plan}.kernels"] = sorted(set(ran))
+        lib.check(lib.load().cb_debug_splitk_inlaunch(1))
+        prof = ctx.profile_end()
+        ran = [r["kernel"] for r in prof]
+    close(f"frnet_mini.features[plan {plan}, inlaunch {inlaunch}]", out, fx["out"], 1e-4)
+    n_reduce = sum(r["launches"] for r in prof if r["kernel"].startswith("splitk_reduce"))
+    n_regstaged = sum(r["launches"] for r in prof if r["kernel"].startswith("gemm_kernel<"))     # the 3-channel stem conv: its split-K keeps the reduce launch
+    if plan[2] > 1 and not inlaunch:
+        assert n_reduce > n_regstaged, prof
+    else:
+        assert n_reduce <= n_regstaged, prof
+    REPORT[f"frnet_mini.pinned_plan{plan}.inlaunch{inlaunch}.kernels"] = sorted(set(ran))
 
 
 def test_frnet_mini_without_the_lds_dma_kernels(golden_dir):

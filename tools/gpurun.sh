@@ -44,6 +44,8 @@ case "$what" in
     db=$(find gpurun_out/trace_$tag -name "*.db" | head -1)
     # every measurement leg of bench.py runs warmup + steps + 1 profiled step of its own kernels
     python tools/prof_stats.py "$db" gpurun_out/${tag}_bench_kernel_stats.csv $((STEPS + 3)) | head -60
+    python tools/trace_overlap.py "$db" > gpurun_out/${tag}_stream_overlap.txt 2>&1; cat gpurun_out/${tag}_stream_overlap.txt
+    python tools/trace_timeline.py "$db" > gpurun_out/${tag}_timeline.txt 2>&1; tail -15 gpurun_out/${tag}_timeline.txt
     find gpurun_out/trace_$tag -size +8M -delete ;;
   trace3)    # the config-3 (bf16, bs=4) leg alone -> gpurun_out/<tag>_config3_kernel_stats.csv
     tag=$1; shift
