@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 BUILD = os.path.join(HERE, "_build")
 LIB = os.path.join(HERE, "libcelebbasis_hip.so")
-SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_flash_bf16_v2.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
+SOURCES = ["cb_gemm.hip", "cb_gemm_glds.hip", "cb_gemm_bf16_p8.hip", "cb_flash.hip", "cb_flash_bf16.hip", "cb_flash_bf16_v2.hip", "cb_kernels.hip", "cb_engine.hip", "cb_models.hip",
            "cb_abi.hip"]
 HEADERS = ["cb_common.h", "cb_device.h", "cb_gemm_tiles.h", "cb_plan_table.inc", "cb_engine.h", "cb_models.h", os.path.join("..", "..", "include", "celebbasis_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-unused-variable",
@@ -27,7 +27,7 @@ EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_V
 # cb_gemm_glds.hip): a register spill would add scratch loads / stores to that count and let a tile be read before it has landed.
 # The build therefore fails if any kernel of these files has scratch, spills or a dynamic stack (-Rpass-analysis remarks).
 # (The f2_* attention kernels drain with vmcnt(0) and do not depend on the count: scratch there is reported, not fatal.)
-NO_SCRATCH = {"cb_gemm_glds.hip": ("gemm_glds", True), "cb_flash_bf16_v2.hip": ("f2_", False)}
+NO_SCRATCH = {"cb_gemm_glds.hip": ("gemm_glds", True), "cb_gemm_bf16_p8.hip": ("gemm_bf16_p8", True), "cb_flash_bf16_v2.hip": ("f2_", False)}
 
 
 def source_digest():

@@ -226,7 +226,7 @@ int cb_wtab_destroy(cb_wtab* wt) {
 // ------------------------------------------------------------------ diagnostics
 int cb_debug_force_plan(int BM, int BN, int split) {
     CB_TRY
-    CB_CHECK((BM == 0 && BN == 0) || ((BM == 64 || BM == 128) && (BN == 64 || BN == 128)) || (BM == 256 && BN == 128) ||
+    CB_CHECK((BM == 0 && BN == 0) || ((BM == 64 || BM == 128) && (BN == 64 || BN == 128)) || (BM == 256 && (BN == 128 || BN == 256)) || (BM == 512 && BN == 128) ||
                  (BN == 80 && (BM == 16 || BM == 32 || BM == 64)), CB_ERR_ARG,
              "force_plan: tile %dx%d", BM, BN);
     PlanForce& f = plan_force();

@@ -69,7 +69,7 @@ struct Ctx {
     // for ev_tail on `aux`. EVERY other consumer of this context joins first: launch() (all op- and graph-level entries),
     // ensure_arena, the state / tap / sync entries (join_tail is one hipStreamWaitEvent).
     hipEvent_t ev_tail = nullptr, ev_tail_fork = nullptr;
-    bool tail_pending = false; const void* tail_owner = nullptr;
+    bool tail_pending = false; const void* tail_owner = nullptr; int tail_layout = 0;    // layout: arena layout class of the step that left the tail
     void join_tail() {
         if (!tail_pending) return;
         tail_pending = false;

@@ -132,71 +132,6 @@ template <int ROWS, int RB, int ESZ, int NTHR = 256> struct GConvGen {    // gen
 // ds_write_b32, lanes = consecutive columns — and reads it back as 8-column pieces: a lane then owns 8 consecutive outputs of
 // one row, adds bias / per-image row bias / residual / beta*C with 16- and 32-byte loads, rounds ONCE to T and issues one
 // (bf16) or two (fp32) 16-byte stores; 8 / 4 lanes cover a whole 128-byte line of C.
-__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
-    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
-}
-__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
-    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
-    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
-}
-__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
-    bf16x8_t o;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
-    *reinterpret_cast<bf16x8_t*>(p) = o;
-}
-__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
-    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
-    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
-}
-// one 8-column piece of an output row: v = alpha*acc + bias, + rowbias / residual / beta*C, rounded once to T. `vec`: the piece lies
-// inside N; the 16-byte path needs aligned C / rowbias / R pieces, everything else goes element by element.
-template <typename T>
-__device__ __forceinline__ void glds_finish_piece(const GemmArgs& a, float (&v)[8], const float (&bcol)[8], T* __restrict__ Cp, const T* __restrict__ Rp,
-                                                  const T* __restrict__ rowbias, long ldrb, int row, int col, bool vec) {
-    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-#pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] = a.alpha * v[e] + bcol[e];
-    T* c = Cp + (long)row * a.ldc + col;
-    const T* rb = rowbias ? rowbias + (long)(row / a.rows_per_img) * ldrb + col : nullptr;
-    const T* rr = Rp ? Rp + (long)row * a.ldr + col : nullptr;
-    if (vec && al16(c) && (!rb || al16(rb)) && (!rr || al16(rr))) {
-        float t[8];
-        if (rb) { ld8(rb, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
-        if (rr) { ld8(rr, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
-        if (a.beta != 0.f) { ld8(c, t);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
-        if (a.prelu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : a.prelu[col + e] * v[e]; }
-        st8(c, v);
-        if (a.C2) {                                                   // second output: the next layer's per-channel affine of this one
-            T* c2 = static_cast<T*>(a.C2) + (long)row * a.ldc + col;
-            float w[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) w[e] = a.c2_scale[col + e] * v[e] + a.c2_shift[col + e];
-            if (al16(c2)) st8(c2, w);
-            else for (int e = 0; e < 8; ++e) c2[e] = (T)w[e];
-        }
-    } else {
-        for (int e = 0; e < 8 && col + e < a.N; ++e) {
-            float x = v[e];
-            if (rb) x += (float)rb[e];
-            if (rr) x += (float)rr[e];
-            if (a.beta != 0.f) x += a.beta * (float)c[e];
-            if (a.prelu) x = x > 0.f ? x : a.prelu[col + e] * x;
-            c[e] = (T)x;
-            if (a.C2) (static_cast<T*>(a.C2) + (long)row * a.ldc + col)[e] = (T)(a.c2_scale[col + e] * x + a.c2_shift[col + e]);
-        }
-    }
-}
 template <typename T, int BM, int BN, int WM = 2>
 __device__ __forceinline__ void gemm_glds_epilogue(const KArgs& p, f32x16 (&acc)[BM / WM / 32][BN / 64], char* lds, int m0, int n0, int wm,
                                                    int wn, int lane, int wave, int split, int z, int zb, int zh) {
@@ -725,6 +660,7 @@ static const GVariant& gvariant() {
     return v;
 }
 static int bf16_bk() { return gvariant().rb / 2; }
+static bool bf16_p8(const GemmArgs& a) { return bf16_bk() == 64 && gemm_bf16_p8_ok(a); }
 template <typename T, int AK, int RB, int ST, bool FAST>
 static void launch_glds_go(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     if (pl.BM == 128 && pl.BN == 128) hipLaunchKernelGGL((gemm_glds_kernel<T, 128, 128, AK, RB, ST, FAST>), grid, dim3(256), 0, s, ka);
@@ -750,6 +686,7 @@ static void launch_glds(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& k
 template <int AK>
 static void launch_tiles_bf16(const Plan& pl, dim3 grid, hipStream_t s, const KArgs& ka) {
     const GVariant& v = gvariant();
+    if (is_p8_tile(pl.BM, pl.BN)) { gemm_bf16_p8_launch(pl.BN, grid, s, ka); return; }      // the phase-pipelined tiles (cb_gemm_bf16_p8.hip)
     if (pl.BM == 256) {
         CB_CHECK(v.glds && v.rb == 128 && pl.BN == 128, CB_ERR_STATE, "gemm_bf16: the 256x128 tile exists for the default LDS-DMA variant only");
         set_dyn_lds(reinterpret_cast<const void*>(&gemm_glds256_kernel<bf16_t, AK>), GLDS256_LDS);
@@ -875,10 +812,11 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
     const std::string key = plan_key(a, bk);
     if (t->seen.count(key)) return;
     t->seen[key] = 1;
-    static const int tiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}};
+    static const int tiles[10][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}, {256, 256}, {512, 128}};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24};
     const bool n80 = sizeof(T) == 4 && n80_ok(a);
-    const int ntile = n80 ? 8 : ((sizeof(T) == 2 && bk == 64) ? 5 : 4);           // the 8-wave 256x128 tile: bf16, default ring only
+    const bool p8 = sizeof(T) == 2 && bf16_p8(a);
+    const int ntile = p8 ? 10 : (n80 ? 8 : ((sizeof(T) == 2 && bk == 64) ? 5 : 4));           // the 8-wave tiles: bf16, default ring only
     const int ksteps = cdiv(a.K, bk);
     const size_t out_elems = (size_t)a.M * (size_t)std::max<long>(a.ldc, a.N);
     size_t ws_max = 0;
@@ -905,13 +843,16 @@ static void autotune(const Launch& L, const GemmArgs& a, int bk, double speed) {
         float ms = 0.f; CB_HIP(hipEventElapsedTime(&ms, e0, e1));
         return (double)ms * 1e3 / 5.0;
     };
-    const Plan model = make_plan(a, bk, speed, n80);
+    const Plan model = make_plan(a, bk, speed, n80, p8);
     const double t_model = (model.splitk <= 1 || (size_t)model.splitk * a.M * a.N * sizeof(float) <= ws_max) ? time_plan(model) : -1.0;
     double best = 1e30; Plan bp = model;
     for (int ti = 0; ti < ntile; ++ti) {
         const int BM = tiles[ti][0], BN = tiles[ti][1];
         if (BM == 256 && !(sizeof(T) == 2 && bk == 64)) continue;
-        if ((BM >= 128 && a.M <= 64) || (BN == 128 && a.N <= 64) || (BM == 256 && a.M <= 128)) continue;
+        if (BN == 80 && !n80) continue;
+        if (BN == 256 && (!p8 || a.N <= 128)) continue;
+        if (BM == 512 && (!p8 || a.M <= 256)) continue;
+        if ((BM >= 128 && a.M <= 64) || (BN == 128 && a.N <= 64) || (BM >= 256 && a.M <= 128)) continue;
         for (int sp : splits) {
             if (sp > 1 && ksteps / sp < 2) break;
             if (sp > 1 && (size_t)sp * a.M * a.N * sizeof(float) > ws_max) break;
@@ -1033,7 +974,7 @@ bool gemm_f32_glds(const Launch& L, const GemmArgs& a, float* ws, size_t ws_byte
 }
 
 size_t gemm_bf16_ws_bytes(const GemmArgs& a) {
-    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed);
+    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed, false, bf16_p8(a));
     if (pl.splitk <= 1) return 0;
     return (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
 }
@@ -1057,10 +998,11 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
         CB_CHECK(a.lda % 8 == 0 && a.sAb % 8 == 0 && a.sAh % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: A strides must be multiples of 8 elements");
     }
     CB_CHECK(a.ldb % 8 == 0 && a.sBb % 8 == 0 && a.sBh % 8 == 0, CB_ERR_SHAPE, "gemm_bf16: B strides must be multiples of 8 elements");
-    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed);
+    Plan pl = make_plan(a, bf16_bk(), plan_knobs().bf16_speed, false, bf16_p8(a));
     if (L.stats) { L.stats->gemm_flops += 2.0 * a.M * a.N * (double)a.K * a.batch; L.stats->gemm_launches++; }
     int* const cnt = splitk_counters(L, pl, a.batch);
     L.count(pl.splitk > 1 && !cnt ? 2 : 1);
+    gemm_log(a, pl, bf16_bk());
     if (pl.splitk > 1) {
         size_t need = (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
         CB_CHECK(L.dry || (ws && ws_bytes >= need), CB_ERR_OOM, "gemm: split-K workspace too small (%zu < %zu)", ws_bytes, need);
@@ -1099,7 +1041,8 @@ void gemm_bf16(const Launch& L, const GemmArgs& a, float* ws, size_t ws_bytes) {
     CB_HIP(hipGetLastError());
     if (prof) {
         char nm[96];
-        snprintf(nm, sizeof nm, "gemm_%skernel<bf16,%d,%d,%s>", pl.BM == 256 ? "glds256_" : "glds_", pl.BM, pl.BN, a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
+        snprintf(nm, sizeof nm, "gemm_%skernel<bf16,%d,%d,%s>", is_p8_tile(pl.BM, pl.BN) ? "bf16_p8_" : (pl.BM == 256 ? "glds256_" : "glds_"), pl.BM, pl.BN,
+                 a.a_kind == LD_ROW ? "ROW" : (convf ? "CONVF" : "CONV"));
         rec.variant = L.prof->id_of(nm);
         CB_HIP(hipEventRecord(rec.e1, L.stream)); L.prof->recs.push_back(rec);
     }

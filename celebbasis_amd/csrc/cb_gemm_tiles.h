@@ -5,6 +5,7 @@
 // (row, chunk) mapping, the LDS image and its XOR swizzle are the same for both element types.
 #pragma once
 #include "cb_device.h"
+#include <type_traits>
 #include <unordered_map>
 
 namespace cb {
@@ -95,6 +96,72 @@ __device__ __forceinline__ void splitk_fold8(float (&v)[8], const float* __restr
     }
 }
 
+// ---- epilogue pieces shared by the LDS-DMA kernels (cb_gemm_glds.hip, cb_gemm_bf16_p8.hip): 8 consecutive outputs of one row
+__device__ __forceinline__ void ld8(const bf16_t* p, float (&v)[8]) {
+    const bf16x8_t t = *reinterpret_cast<const bf16x8_t*>(p);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (float)t[e];
+}
+__device__ __forceinline__ void ld8(const float* p, float (&v)[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void st8(bf16_t* p, const float (&v)[8]) {
+    bf16x8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (bf16_t)v[e];
+    *reinterpret_cast<bf16x8_t*>(p) = o;
+}
+__device__ __forceinline__ void st8(float* p, const float (&v)[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+// one 8-column piece of an output row: v = alpha*acc + bias, + rowbias / residual / beta*C, rounded once to T. `vec`: the piece lies
+// inside N; the 16-byte path needs aligned C / rowbias / R pieces, everything else goes element by element.
+template <typename T>
+__device__ __forceinline__ void glds_finish_piece(const GemmArgs& a, float (&v)[8], const float (&bcol)[8], T* __restrict__ Cp, const T* __restrict__ Rp,
+                                                  const T* __restrict__ rowbias, long ldrb, int row, int col, bool vec) {
+    auto al16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = a.alpha * v[e] + bcol[e];
+    T* c = Cp + (long)row * a.ldc + col;
+    const T* rb = rowbias ? rowbias + (long)(row / a.rows_per_img) * ldrb + col : nullptr;
+    const T* rr = Rp ? Rp + (long)row * a.ldr + col : nullptr;
+    if (vec && al16(c) && (!rb || al16(rb)) && (!rr || al16(rr))) {
+        float t[8];
+        if (rb) { ld8(rb, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+        if (rr) { ld8(rr, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += t[e]; }
+        if (a.beta != 0.f) { ld8(c, t);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += a.beta * t[e]; }
+        if (a.prelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.f ? v[e] : a.prelu[col + e] * v[e]; }
+        st8(c, v);
+        if (a.C2) {                                                   // second output: the next layer's per-channel affine of this one
+            T* c2 = static_cast<T*>(a.C2) + (long)row * a.ldc + col;
+            float w[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) w[e] = a.c2_scale[col + e] * v[e] + a.c2_shift[col + e];
+            if (al16(c2)) st8(c2, w);
+            else for (int e = 0; e < 8; ++e) c2[e] = (T)w[e];
+        }
+    } else {
+        for (int e = 0; e < 8 && col + e < a.N; ++e) {
+            float x = v[e];
+            if (rb) x += (float)rb[e];
+            if (rr) x += (float)rr[e];
+            if (a.beta != 0.f) x += a.beta * (float)c[e];
+            if (a.prelu) x = x > 0.f ? x : a.prelu[col + e] * x;
+            c[e] = (T)x;
+            if (a.C2) (static_cast<T*>(a.C2) + (long)row * a.ldc + col)[e] = (T)(a.c2_scale[col + e] * x + a.c2_shift[col + e]);
+        }
+    }
+}
 // ROW operand: element (r, k) at byte (r*ld + k)*ESZ. Per-slot row offsets are loop invariant.
 template <int ROWS, int ESZ>
 struct RowOffs {
@@ -298,7 +365,8 @@ inline void plan_table_parse(std::unordered_map<std::string, PlanEntry>& t, cons
         std::string line(p, e ? (size_t)(e - p) : strlen(p));
         char key[160]; int bm, bn, sp;
         const bool ok = sscanf(line.c_str(), "%159s %d %d %d", key, &bm, &bn, &sp) == 4 && sp >= 1;
-        const bool pow2 = (bm == 64 || bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (bm != 256 || bn == 128);
+        const bool pow2 = ((bm == 64 || bm == 128 || bm == 256) && (bn == 64 || bn == 128) && (bm != 256 || bn == 128)) ||
+                          (bm == 256 && bn == 256) || (bm == 512 && bn == 128);   // the phase-pipelined bf16 tiles (cb_gemm_bf16_p8.hip)
         const bool n80 = bn == 80 && (bm == 16 || bm == 32 || bm == 64);          // fp32 80-column tiles (cb_gemm_glds.hip)
         if (ok && (pow2 || n80))
             t[key] = PlanEntry{bm, bn, sp};
@@ -339,38 +407,46 @@ inline PlanForce& plan_force() {
     }();
     return f;
 }
+// the phase-pipelined bf16 tiles, 256 x 256 and 512 x 128 (cb_gemm_bf16_p8.hip): eligibility of a problem, launch (bn selects the tile)
+bool gemm_bf16_p8_ok(const GemmArgs& a);
+void gemm_bf16_p8_launch(int bn, dim3 grid, hipStream_t s, const KArgs& ka);
+inline bool is_p8_tile(int BM, int BN) { return (BM == 256 && BN == 256) || (BM == 512 && BN == 128); }
+
 // bke = elements of k per tile (16 for fp32, 32 for bf16); speed = MFMA rate relative to the fp32 kernel
 // n80: the caller can run the fp32 80-column tiles (64 / 32 / 16 rows x 80 columns, k-groups inside the block) on this problem
-inline Plan make_plan(const GemmArgs& a, int bke, double speed, bool n80 = false) {
+// p8: the caller can run the phase-pipelined bf16 tiles on this problem (a table entry / pinned plan naming one is ignored otherwise)
+inline Plan make_plan(const GemmArgs& a, int bke, double speed, bool n80 = false, bool p8 = false) {
     // Pick the (tile, split-K) pair with the smallest modelled time. Unit = one MAC on one CU at the fp32 MFMA rate.
     // Measured on MI355X (profiles/r01): 128x128 tiles ~78 TF, 64x64 tiles ~45 TF on the same conv shapes, so small tiles
     // are only worth it when the big ones cannot fill the 256 CUs even with split-K.
     // the fifth shape (8-wave 256x128 tile of the bf16 LDS-DMA kernel) is never chosen by the model: only a measured table entry
     // or cb_debug_force_plan selects it
-    static const int tiles[8][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}};
+    static const int tiles[10][2] = {{128, 128}, {128, 64}, {64, 128}, {64, 64}, {256, 128}, {64, 80}, {32, 80}, {16, 80}, {256, 256}, {512, 128}};
     const PlanKnobs& kn = plan_knobs();
-    const double eff[8] = {kn.eff[0], kn.eff[1], kn.eff[2], kn.eff[3], 1.0, kn.eff80, kn.eff80, kn.eff80};
+    const double eff[10] = {kn.eff[0], kn.eff[1], kn.eff[2], kn.eff[3], 1.0, kn.eff80, kn.eff80, kn.eff80, 1.0, 1.0};
     static const int splits[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64};
     const int ksteps = cdiv(a.K, bke);
     double best = 1e300;
     Plan pl{128, 128, 1, 1, 1, ksteps * bke};
     PlanForce pf = plan_force();
-    if (pf.BN == 80 && !n80) pf = PlanForce{};                      // a pinned 80-column tile only binds the problems that can run it
+    if (pf.BN == 80 && !n80) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; }   // a pinned 80-column tile only binds the problems that can run it
+    if (is_p8_tile(pf.BM, pf.BN) && !p8) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; }   // likewise the 256 x 256 bf16 tile
     if (!pf.BM && !pf.split) {
         const auto& tab = plan_table();
         if (!tab.empty()) {
             auto it = tab.find(plan_key(a, bke));
-            if (it != tab.end() && it->second.split <= ksteps && (it->second.BN != 80 || n80)) {
+            if (it != tab.end() && it->second.split <= ksteps && (it->second.BN != 80 || n80) && (!is_p8_tile(it->second.BM, it->second.BN) || p8)) {
                 const PlanEntry& e = it->second;
                 const int kps = cdiv(ksteps, e.split) * bke;
                 return Plan{e.BM, e.BN, (int)cdiv(a.M, e.BM), (int)cdiv(a.N, e.BN), (int)cdiv(a.K, kps), kps};
             }
         }
     }
-    for (int t = 0; t < 8; ++t) {
+    for (int t = 0; t < 10; ++t) {
         const int BM = tiles[t][0], BN = tiles[t][1];
-        if (t == 4 && pf.BM != 256) continue;
-        if (t > 4 && !n80) continue;
+        if ((t == 4 || t >= 8) && pf.BM != BM) continue;             // the 8-wave tiles: never by model, only pinned (or from the table, above)
+        if (t >= 8 && !p8) continue;
+        if (t > 4 && t < 8 && !n80) continue;
         if (pf.BM && (pf.BM != BM || pf.BN != BN)) continue;
         if (!pf.BM && BM == 128 && a.M <= 64) continue;
         if (!pf.BM && BN == 128 && a.N <= 64) continue;

@@ -616,17 +616,22 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     const int NF = 2 * B;
     const bool fork = !ctx->dry && ctx->aux != nullptr;
     hipStream_t main_stream = G.L.stream;
-    if (fork) {
-        CB_HIP(hipEventRecord(ctx->ev_fork, main_stream));        // everything enqueued so far (incl. the previous step) ...
-        CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));    // ... happens before the side branch
-        G.L.stream = ctx->aux;
-    }
     // a batch whose first stage was enqueued by trainer_prefetch: wait for it instead of recomputing (bitwise the same values)
     Trainer::Prefetch::Slot* ps = nullptr;
     if (!ctx->dry)
         for (auto& sl : T->pf.slot)
             if (sl.valid && sl.image == bt.image && sl.faces == bt.faces && sl.post_noise == bt.post_noise && sl.B == B) ps = &sl;
     const bool prefetched = ps != nullptr;
+    // The previous step's deferred tail may stay in flight only under a step with the SAME arena layout (same batch size — checked by
+    // trainer_step — and the same first-stage form): a prefetched step allocates neither the FR backbone's nor the VAE's activations, so
+    // everything behind them sits at other offsets, and this step's first stage would write where that tail still reads.
+    const int layout = 2 * B + (prefetched ? 1 : 0);
+    if (ctx->tail_pending && ctx->tail_layout != layout) ctx->join_tail();
+    if (fork) {
+        CB_HIP(hipEventRecord(ctx->ev_fork, main_stream));        // everything enqueued so far (incl. the previous step) ...
+        CB_HIP(hipStreamWaitEvent(ctx->aux, ctx->ev_fork, 0));    // ... happens before the side branch
+        G.L.stream = ctx->aux;
+    }
     if (prefetched) {
         CB_HIP(hipStreamWaitEvent(G.L.stream, ps->done, 0)); CB_HIP(hipStreamWaitEvent(main_stream, ps->done, 0));
         ps->valid = false;                              // consumed; the slot is rewritten no earlier than the prefetch after next
@@ -723,9 +728,11 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     }
     struct TailDone {      // record the tail's end on every exit path of the function below (use_rm_mlp returns early, but never defers)
         Ctx* ctx; Graph& G; hipStream_t main; bool on;
-        const void* owner;
-        ~TailDone() { if (on) { (void)hipEventRecord(ctx->ev_tail, ctx->aux2); ctx->tail_pending = true; ctx->tail_owner = owner; G.L.stream = main; } }
-    } tail_done{ctx, G, main_stream, defer_tail, T};
+        const void* owner; int layout;
+        ~TailDone() {
+            if (on) { (void)hipEventRecord(ctx->ev_tail, ctx->aux2); ctx->tail_pending = true; ctx->tail_owner = owner; ctx->tail_layout = layout; G.L.stream = main; }
+        }
+    } tail_done{ctx, G, main_stream, defer_tail, T, layout};
     Phase ph_tail(L, "phase:head_bwd_adamw");
     CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");
     if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());

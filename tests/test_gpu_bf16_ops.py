@@ -114,6 +114,90 @@ def test_conv_bf16_tile256(cbf, tile256, N, H, W, Cin, Cout, ks, mode):
     test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, "bias")
 
 
+# ---- the phase-pipelined 256 x 256 tile (cb_gemm_bf16_p8.hip): 8 waves in two groups one barrier apart, four phases per k-tile,
+# LDS-DMA half-tiles in flight across the barriers (one counted vmcnt(4) per k-tile). Pinned with cb_debug_force_plan(256, 256, split);
+# a problem the tile cannot run (K % 64, general conv gathers) silently keeps the planner's choice, so the tests assert the kernel name.
+def _p8_ran(ctx, fn):
+    ctx.profile_begin()
+    try:
+        fn()
+    finally:
+        ran = [r["kernel"] for r in ctx.profile_end()]
+    return ran
+
+
+@pytest.mark.parametrize("M,N,K,split,extra", [
+    (1024, 512, 640, 1, "bias+res"),        # full tiles, 10 k-tiles
+    (777, 300, 320, 1, "bias"),             # ragged M / N: zero-filled rows, masked stores
+    (512, 320, 2880, 3, "bias+beta"),       # split-K (15 k-tiles per split) + in-launch reduction
+    (300, 200, 64, 1, "none"),              # ONE k-tile: prologue + drained tail only
+    (256, 256, 128, 1, "alpha"),            # two k-tiles: both ring buffers once
+    (4096, 1280, 1280, 1, "bias"),          # 16 x 5 tiles, 20 k-tiles (the 32x32-level Linear at bs = 4)
+    (130, 88, 192, 2, "res"),               # split-K with an odd number of k-tiles per split (3 -> 2 + 1)
+])
+@pytest.mark.parametrize("tile", [(256, 256), (512, 128)])
+def test_gemm_bf16_tile_p8(cbf, tile, M, N, K, split, extra):
+    lib, ctx = cbf
+    L = lib.load()
+    lib.check(L.cb_debug_force_plan(tile[0], tile[1], split))
+    try:
+        ran = _p8_ran(ctx, lambda: test_gemm_bf16(cbf, M, N, K, 1, extra))
+    finally:
+        lib.check(L.cb_debug_force_plan(0, 0, 0))
+    assert any(k.startswith(f"gemm_bf16_p8_kernel<bf16,{tile[0]},{tile[1]},ROW>") for k in ran), ran
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,ks,mode", [(2, 32, 32, 64, 160, 3, "same"), (2, 33, 31, 64, 128, 3, "down"), (1, 16, 16, 128, 256, 1, "same"),
+                                                     (4, 64, 64, 320, 320, 3, "same"), (1, 24, 20, 192, 96, 3, "same")])
+@pytest.mark.parametrize("tile", [(256, 256), (512, 128)])
+def test_conv_bf16_tile_p8(cbf, tile, N, H, W, Cin, Cout, ks, mode):
+    """implicit-GEMM gathers on the phase-pipelined tile: the scalar (tap, channel) walk with per-lane validity re-derived at a tap change,
+    stride 2, 1x1, three k-tiles per tap; forward and — where the gather is of the plain kind — the input gradient"""
+    lib, ctx = cbf
+    L = lib.load()
+    lib.check(L.cb_debug_force_plan(tile[0], tile[1], 1))
+    try:
+        ran = _p8_ran(ctx, lambda: test_conv_bf16_fwd_dgrad(cbf, N, H, W, Cin, Cout, ks, mode, "bias"))
+    finally:
+        lib.check(L.cb_debug_force_plan(0, 0, 0))
+    assert any(k.startswith(f"gemm_bf16_p8_kernel<bf16,{tile[0]},{tile[1]},CONVF>") for k in ran), ran
+
+
+@pytest.mark.parametrize("tile", [(256, 256), (512, 128)])
+def test_p8_counted_wait_matches_safe_mode_and_repeats(cbf, tile):
+    """cb_debug_glds_safe(1) drains the DMA queue (vmcnt(0)) where the pipeline waits for vmcnt(4): a half-tile read before it landed, or
+    re-staged before its last reader was done, shows up as a difference — BIT FOR BIT equality on step-sized GEMMs and convolutions
+    (one / several waves of blocks, split-K, ragged tails), and 8 back-to-back repeats of the counted pipeline must all agree (race screen)."""
+    lib, ctx = cbf
+    L = lib.load()
+    shapes = [(4096, 320, 2880, 1), (1024, 640, 5760, 2), (16384, 320, 320, 1), (1024, 1280, 11520, 4), (777, 300, 320, 1), (16384, 1280, 1280, 1)]
+    outs = {}
+    try:
+        for safe, reps in ((1, 1), (0, 8)):
+            lib.check(L.cb_debug_glds_safe(safe))
+            for (M, N, K, split) in shapes:
+                lib.check(L.cb_debug_force_plan(tile[0], tile[1], split))
+                Ad, Bd = d16(r16(rnd(1, M, K, seed=M + 1))), d16(r16(rnd(1, N, K, seed=N + 2)))
+                for r in range(reps):
+                    Cd = torch.zeros(M, N, device=Ad.device, dtype=Ad.dtype)
+                    d = lib.GemmDesc()
+                    d.A, d.B, d.C = Ad.data_ptr(), Bd.data_ptr(), Cd.data_ptr()
+                    d.M, d.N, d.K = M, N, K
+                    d.lda = d.ldb = K; d.ldc = N; d.batch = 1; d.alpha = 1.0; d.dtype = lib.DTYPE_BF16
+                    lib.check(L.cb_gemm(ctx.h, C.byref(d)))
+                    outs[(safe, M, N, K, r)] = Cd
+                ctx.sync()
+    finally:
+        lib.check(L.cb_debug_glds_safe(0)); lib.check(L.cb_debug_force_plan(0, 0, 0))
+    for (M, N, K, split) in shapes:
+        ref = outs[(1, M, N, K, 0)].cpu()
+        assert torch.isfinite(ref.float()).all() and ref.float().abs().max() > 0
+        for r in range(8):
+            got = outs[(0, M, N, K, r)].cpu()
+            assert torch.equal(got, ref), f"tile {tile} {M}x{N}x{K}/{split} repeat {r}: counted-wait and drained pipelines differ " \
+                                          f"(max {(got.float() - ref.float()).abs().max().item():.3e}, {(got != ref).sum().item()} elements)"
+
+
 @pytest.mark.parametrize("dtype", ["bf16", "f32"])
 def test_glds_counted_wait_matches_safe_mode(cbf, dtype):
     """the LDS-DMA kernel's tile ring is synchronised by a hand-counted `s_waitcnt vmcnt(N)` + raw `s_barrier`

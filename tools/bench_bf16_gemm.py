@@ -44,6 +44,10 @@ def main():
     variant = os.environ.get("CB_BF16_GEMM", "default")
     ctx = lib.Context(dtype="bf16")
     L = lib.load()
+    if len(sys.argv) > 2 and sys.argv[1] == "--plan":          # round 6: --plan 256x256x1 pins a (tile, split) for every eligible shape
+        bm, bn, sp = (int(v) for v in sys.argv[2].split("x"))
+        lib.check(L.cb_debug_force_plan(bm, bn, sp))
+        variant = f"plan{sys.argv[2]}"
     g = torch.Generator().manual_seed(0)
     rows, tot_fl, tot_t = [], 0.0, 0.0
     for (N, H, W, Ci, Co, cnt) in CONVS:
@@ -56,7 +60,7 @@ def main():
         fn = lambda: lib.check(L.cb_conv2d_fwd(ctx.h, lib.ptr(x, BF), lib.ptr(wp, BF), lib.ptr(b), None, None, lib.ptr(y, BF), N, H, W, Ci, Co, 3, 0))
         t = timeit(fn)
         fl = 2.0 * N * H * W * Co * Ci * 9
-        rows.append(dict(op=f"conv {N}x{H}x{W} {Ci}->{Co}", us=round(t * 1e6, 1), tflops=round(fl / t / 1e12, 1)))
+        rows.append(dict(op=f"conv {N}x{H}x{W} {Ci}->{Co}", us=round(t * 1e6, 1), tflops=round(fl / t / 1e12, 1), cnt=cnt))
         tot_fl += fl * cnt; tot_t += t * cnt
     for (M, Nn, K, cnt) in LINS:
         A = torch.randn(M, K, generator=g).to(BF).to(DEV); B = (torch.randn(Nn, K, generator=g) * K ** -0.5).to(BF).to(DEV)
@@ -68,7 +72,7 @@ def main():
         fn = lambda: lib.check(L.cb_gemm(ctx.h, C.byref(d)))
         t = timeit(fn)
         fl = 2.0 * M * Nn * K
-        rows.append(dict(op=f"gemm {M}x{Nn}x{K}", us=round(t * 1e6, 1), tflops=round(fl / t / 1e12, 1)))
+        rows.append(dict(op=f"gemm {M}x{Nn}x{K}", us=round(t * 1e6, 1), tflops=round(fl / t / 1e12, 1), cnt=cnt))
         tot_fl += fl * cnt; tot_t += t * cnt
     for r in rows:
         print(f"{variant:8s} {r['op']:28s} {r['us']:9.1f} us {r['tflops']:8.1f} TF")
