@@ -496,7 +496,7 @@ def test_eight_rank_launch_of_bench_and_config5_dry():
 
 def test_build_guard_flags_scratch_in_counted_wait_kernels():
     """celebbasis_amd/build.py parses -Rpass-analysis=kernel-resource-usage remarks and fails the build when a kernel whose software
-    pipeline counts its VMEM instructions (cb_gemm_glds.hip, cb_flash_bf16_v2.hip) has scratch, spills or a dynamic stack"""
+    pipeline counts its VMEM instructions (cb_gemm_glds.hip, cb_gemm_bf16_p8.hip, cb_flash_bf16_v2.hip) has scratch, spills or a dynamic stack"""
     from celebbasis_amd import build
     ok = """x.hip:5:1: remark: Function Name: _ZN2cb16gemm_glds_kernelIfLi64ELi64ELi0ELi128ELi2EEEvNS_5KArgsE [-Rpass-analysis=kernel-resource-usage]
 x.hip:5:1: remark:     VGPRs: 47 [-Rpass-analysis=kernel-resource-usage]
@@ -515,7 +515,7 @@ x.hip:9:1: remark:     ScratchSize [bytes/lane]: 64 [-Rpass-analysis=kernel-reso
     assert build.check_no_scratch("", "gemm_glds") == ([], 0)          # no remarks at all is an error for the caller (seen == 0)
     d = build.source_digest()
     assert set(d) == {"src_sha", "plan_table_sha"} and len(d["src_sha"]) == 16 and d == build.source_digest()
-    assert set(build.NO_SCRATCH) == {"cb_gemm_glds.hip", "cb_flash_bf16_v2.hip"}
+    assert set(build.NO_SCRATCH) == {"cb_gemm_glds.hip", "cb_gemm_bf16_p8.hip", "cb_flash_bf16_v2.hip"}
 
 
 def test_four_ranks_against_a_deleted_build_dir_compile_once(tmp_path):
@@ -531,7 +531,8 @@ with open(os.environ['STUB_LOG'], 'a') as f:
     f.write(('link ' if '-shared' in a else 'cc ') + os.path.basename(out) + '\\n')
 time.sleep(0.15)
 if '-Rpass-analysis=kernel-resource-usage' in a:
-    sys.stderr.write('x.hip:1:1: remark: Function Name: gemm_glds_stub [-Rpass]\\nx.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\\n')
+    sys.stderr.write('x.hip:1:1: remark: Function Name: gemm_glds_stub [-Rpass]\\nx.hip:1:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\\n'
+                     'x.hip:2:1: remark: Function Name: gemm_bf16_p8_stub [-Rpass]\\nx.hip:2:1: remark:     ScratchSize [bytes/lane]: 0 [-Rpass]\\n')
 open(out, 'w').write('stub')
 """)
     stub.chmod(0o755)
@@ -760,9 +761,10 @@ def test_argument_errors_on_a_dry_context(built_lib):
 
 def test_plan_table_is_well_formed(tmp_path):
     """celebbasis_amd/csrc/cb_plan_table.inc (generated by tools/make_plan_table.py from offline autotune records): every entry parses
-    as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (256x128 only for the bf16 64-element k-tile,
-    the 80-column tiles only for fp32 ROW / plain-conv problems without a batch), and the generator reproduces the committed table
-    from the committed records (round 4's fp32 re-measurement + the records carried over from round 2)"""
+    as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (the 8-wave tiles — 256x128 and the
+    phase-pipelined 256x256 / 512x128 — only for the bf16 64-element k-tile, the latter two only for K % 64 == 0 ROW / plain-conv
+    problems; the 80-column tiles only for fp32 ROW / plain-conv problems without a batch), and the generator reproduces the committed
+    table from the committed records (round 6's re-measurement of every kernel + the records carried over from round 2)"""
     import subprocess
     import sys
     inc = os.path.join(ROOT, "celebbasis_amd", "csrc", "cb_plan_table.inc")
@@ -776,15 +778,17 @@ def test_plan_table_is_well_formed(tmp_path):
         assert len(f) == 8 and key not in keys, key
         keys.add(key)
         bm, bn, sp = int(bm), int(bn), int(sp)
-        assert (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64), (256, 128), (64, 80), (32, 80), (16, 80)) and sp >= 1
+        assert (bm, bn) in ((128, 128), (128, 64), (64, 128), (64, 64), (256, 128), (64, 80), (32, 80), (16, 80), (256, 256), (512, 128)) and sp >= 1
         if bn == 80:                                      # fp32 (dtype 0), k-tile 32, ROW (0) or conv (2) without upsample / transposed flags, batch 1
             assert f[0] == "32" and f[1] == "0" and f[2] in ("0", "2") and f[6] == "1" and (int(f[7]) & 3) == 0
-        if bm == 256:
-            assert f[0] == "64" and f[1] == "1"          # the 8-wave tile exists for bf16 (dtype code 1), 64-element k-tiles only
+        if bm >= 256:
+            assert f[0] == "64" and f[1] == "1"          # the 8-wave tiles exist for bf16 (dtype code 1), 64-element k-tiles only
+        if (bm, bn) in ((256, 256), (512, 128)):         # cb_gemm_bf16_p8.hip: whole 64-element k-tiles, ROW or plain conv gathers
+            assert int(f[5]) % 64 == 0 and f[2] in ("0", "2") and (int(f[7]) & 3) == 0
         assert -(-int(f[5]) // int(f[0])) >= sp           # never more splits than k-tiles
     before = open(inc).read()
     try:
-        recs = [os.path.join(ROOT, "profiles", n) for n in ("r04_autotune.txt", "r04_autotune_carried_from_r02.txt")]
+        recs = [os.path.join(ROOT, "profiles", n) for n in ("r06_autotune.txt", "r04_autotune_carried_from_r02.txt")]
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py")] + recs, capture_output=True, text=True, check=True).stdout
         assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of the committed records"
     finally:

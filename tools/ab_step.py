@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--steps", type=int, default=15)
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--bf16", action="store_true")
+    ap.add_argument("--only", action="store_true", help="the default configuration only (for process-level A/B: CB_PLAN_FILE, CB_* switches)")
+    ap.add_argument("--tag", default="")
     args = ap.parse_args()
     from celebbasis_amd import build as cb_build
     cb_build.build(verbose=False)
@@ -42,6 +44,8 @@ def main():
 
     L = lib.load()
     variants = [("tail+inlaunch", 1, 1), ("tail only", 1, 0), ("inlaunch only", 0, 1), ("neither (round 5)", 0, 0)]
+    if args.only:
+        variants = variants[:1]
     res = {v[0]: [] for v in variants}
     host = {v[0]: [] for v in variants}
     for i in range(3):
@@ -64,13 +68,13 @@ def main():
             torch.cuda.synchronize()
             res[name].append((time.perf_counter() - t0) / args.steps * 1e3)
     lib.check(L.cb_debug_splitk_inlaunch(1)); tr.set_tail_overlap(True)
-    out = dict(workload="config 3 (bf16, bs=4)" if args.bf16 else "config 2 (fp32, bs=1)", steps=args.steps, rounds=args.rounds,
+    out = dict(tag=args.tag, plan_file=os.environ.get("CB_PLAN_FILE"), workload="config 3 (bf16, bs=4)" if args.bf16 else "config 2 (fp32, bs=1)", steps=args.steps, rounds=args.rounds,
                ms_per_step={k: [round(x, 3) for x in v] for k, v in res.items()},
                ms_per_step_best={k: round(min(v), 3) for k, v in res.items()},
                host_enqueue_ms={k: [round(x, 2) for x in v] for k, v in host.items()},
                loss=float(tr.get_state("loss")[0]))
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "ab_step_bf16.json" if args.bf16 else "ab_step.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", ("ab_step_bf16" if args.bf16 else "ab_step") + (("_" + args.tag) if args.tag else "") + ".json"), "w") as f:
         json.dump(out, f, indent=1)
     print(json.dumps(out))
 
