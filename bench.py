@@ -15,7 +15,7 @@ collective is the checkpoint-merge all_gather after the timed region (RCCL), who
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   `roofline`      dominant kernel of the fp32 step, measured live with HIP events around every GEMM-class launch of one extra
-                  step. Numbers of the committed rocprofv3 trace / PMC passes (profiles/r05*) are added next to the live ones ONLY
+                  step. Numbers of the committed rocprofv3 trace / PMC passes (profiles/r06*) are added next to the live ones ONLY
                   when their stamp (sha of the kernel sources + plan table, `build`) is this tree's; otherwise `profile_stale` is
                   true and the line carries live measurements alone;
   `cpu_baseline`  the CPU oracle (a from-scratch restatement = kind "port") timed on this box's host cores on a bounded sample;
@@ -52,7 +52,10 @@ def trace_symbols(kernel):
     m4 = re.match(r"gemm_kernel_occ4<(\w+),(\w+)>", kernel)
     mg = re.match(r"gemm_glds_kernel<(float|bf16),(\d+),(\d+),(\w+)>", kernel)       # <T, BM, BN, AK, row bytes, stages, FAST>
     m80 = re.match(r"gemm_glds80_kernel<float,(\d+),80,(\w+)>", kernel)               # <BM, AK, stages, FAST>
+    mp8 = re.match(r"gemm_bf16_p8_kernel<bf16,(\d+),(\d+),(\w+)>", kernel)           # <AK, waves along M, ablation>
     ak3 = {"ROW": 0, "CONV": 1, "CONVF": 2}
+    if mp8:
+        return [f"gemm_bf16_p8_kernel<{ak3[mp8.group(3)]}, {2 if mp8.group(2) == '256' else 4}, 0>"]
     if mg:
         t = "float" if mg.group(1) == "float" else "__bf16"
         return [f"gemm_glds_kernel<{t}, {mg.group(2)}, {mg.group(3)}, {ak3[mg.group(4)]}, 128, 2, {f}>" for f in ("true", "false")]
@@ -72,13 +75,13 @@ def tree_stamp():
 
 def pmc_traffic(kernel, bf16=False):
     """HBM-side bytes per launch of the dominant kernel from the committed rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE need
-    separate passes and cannot be collected inside this process): profiles/r05*_pmc_hbm_traffic{,_config3}.json, written by
+    separate passes and cannot be collected inside this process): profiles/r06*_pmc_hbm_traffic{,_config3}.json, written by
     tools/pmc_traffic.py from `rocprofv3 --kernel-trace --pmc ... -- python bench.py`. Corrected as MI355X_MICROARCH.md's HBM
     section prescribes for gfx950: FETCH_SIZE tallies the 128-B requests of 16-B/lane reads and `buffer_load ... lds` at 64 B, so
     traffic = 2 x FETCH_SIZE + WRITE_SIZE. The file is used only when it was measured on THIS tree (stamp = sha of the kernel
     sources + plan table); otherwise (None, {"stale": ...}). Returns (bytes | None, detail)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r05*_pmc_hbm_traffic{'_config3' if bf16 else ''}.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r06*_pmc_hbm_traffic{'_config3' if bf16 else ''}.json")))
     syms = trace_symbols(kernel)
     if not files or not syms:
         return None, None
@@ -107,7 +110,7 @@ HBM_GROUP_SYMBOLS = {
 }
 
 
-def rocprof_trace(bf16=False, prefix="r05"):
+def rocprof_trace(bf16=False, prefix="r06"):
     """the newest committed rocprofv3 kernel trace of this leg — profiles/<prefix>*_bench_kernel_stats.csv = `bench.py --no-config3`
     (the fp32 step alone), profiles/<prefix>*_config3_kernel_stats.csv = `bench.py --trace-leg config3` — if and only if its
     stamp line says it was taken on THIS tree. Returns (file | None, stale, {symbol: (calls_per_step, ms_per_step, avg_us)},
@@ -249,7 +252,11 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
         tms, tl = trace_ms(p)
         rows.append(dict(kernel=p["kernel"], launches=p["launches"], gflop=round(p["flops"] / 1e9, 1), ms_events=round(p["ms"], 3),
                          ms_trace=None if tms is None else round(tms, 3), launches_trace=None if tl is None else round(tl, 2),
-                         tflops_trace=None if not tms else round(p["flops"] / (tms * 1e-3) / 1e12, 2)))
+                         tflops_trace=None if not tms else round(p["flops"] / (tms * 1e-3) / 1e12, 2),
+                         # algorithmic operand + result bytes (A once, B once, C once) and the rate they move at: for the M <= 256 problems
+                         # (the 16-row 80-column tiles) that is the weight stream, and neither roofline is near (round-5 verdict item 5)
+                         algorithmic_mb=round(p.get("bytes", 0) / 1e6, 1),
+                         gbps_trace=None if not tms or not p.get("bytes") else round(p["bytes"] / (tms * 1e-3) / 1e9, 1)))
     covered = [r for r in rows if r["ms_trace"]]
     roofline = dict(bound="mfma", kernel=dom["kernel"], achieved=round(ach, 2), peak=peak_tflops, unit="TFLOP/s",
                     frac=round(ach / peak_tflops, 4), traffic=None, traffic_detail=None,
@@ -280,11 +287,11 @@ def profile_step(ctx, run, peak_tflops, bf16=False):
 
 
 def frac_range(value, bf16=False):
-    """roofline.frac of the dominant kernel over the committed bench lines of THIS tree (profiles/BENCH_r05_run*.json with the same
+    """roofline.frac of the dominant kernel over the committed bench lines of THIS tree (profiles/BENCH_r06_run*.json with the same
     stamp: other boxes of the pool) plus this run: [min, max, n]"""
     import glob
     st, vals = tree_stamp(), [value]
-    for p in glob.glob(os.path.join(ROOT, "profiles", "BENCH_r05_run*.json")):
+    for p in glob.glob(os.path.join(ROOT, "profiles", "BENCH_r06_run*.json")):
         try:
             d = json.load(open(p))
             if d.get("build") == st:
@@ -310,7 +317,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=64, help="host threads for the CPU baseline (reported as `cores`)")
     ap.add_argument("--batches", type=int, default=4, help="distinct replay batches kept resident in HBM")
     ap.add_argument("--graph", action="store_true", help="also measure the opt-in whole-step HIP-graph replay as a secondary leg (eager vs replay; "
-                    "profiles/BENCH_r05_run*.json were taken with it). Off by default: the runtime's graph path is erratic once other streams / "
+                    "profiles/BENCH_r06_run*.json were taken with it). Off by default: the runtime's graph path is erratic once other streams / "
                     "contexts exist (DESIGN §2) and a secondary leg must not be able to endanger the line")
     ap.add_argument("--no-graph", action="store_true", help="(default; kept for the profile targets of tools/gpurun.sh)")
     ap.add_argument("--dry", action="store_true", help="no GPU: dry contexts + gloo (launcher / sharding / merge / JSON contract only)")

@@ -109,6 +109,7 @@ int cb_ctx_set_warp_grid(cb_ctx* ctx, const float* host_grid, int S) {
     CB_TRY
     require(ctx, "ctx");
     Ctx& c = ctx->c;
+    ++c.warp_gen;                         // captured step graphs made under the previous table are dropped at their next use
     if (!host_grid) {
         // the prefetch stream and a replaying step graph read the table too and the context does not know them: wait for the device
         if (c.warp_grid && !c.dry) { c.join_tail(); CB_HIP(hipDeviceSynchronize()); CB_HIP(hipFree(c.warp_grid)); }
@@ -230,19 +231,19 @@ int cb_debug_force_plan(int BM, int BN, int split) {
                  (BN == 80 && (BM == 16 || BM == 32 || BM == 64)), CB_ERR_ARG,
              "force_plan: tile %dx%d", BM, BN);
     PlanForce& f = plan_force();
-    f.BM = BM; f.BN = BN; f.split = split > 0 ? split : 0;
+    f.BM = BM; f.BN = BN; f.split = split > 0 ? split : 0; ++f.gen;
     CB_END
 }
 
 int cb_debug_glds_safe(int on) {
     CB_TRY
-    plan_force().glds_safe = on ? 1 : 0;
+    plan_force().glds_safe = on ? 1 : 0; ++plan_force().gen;
     CB_END
 }
 
 int cb_debug_splitk_inlaunch(int on) {
     CB_TRY
-    plan_force().splitk_inlaunch = on ? 1 : 0;
+    plan_force().splitk_inlaunch = on ? 1 : 0; ++plan_force().gen;
     CB_END
 }
 

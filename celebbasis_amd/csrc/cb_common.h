@@ -260,7 +260,7 @@ void k_coef_scatter_grad(const Launch& L, float* gcoef, const float* dout, const
                          int max_ids);
 void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, const float* v, int R, int O, int I);
 void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step,
-             float lr, float b1, float b2, float eps, float wd);
+             float lr, float b1, float b2, float eps, float wd, const float* lr_dev = nullptr /* non-null: the rate is read from this device scalar */);
 void k_step_inc(const Launch& L, int* step);
 // y[M][N] = x[M][K] . W[N][K]^T + bias, M <= 8 (x, W, y are `dt`; bias fp32)
 void k_gemv(const Launch& L, DType dt, void* y, const void* x, const void* W, const float* bias, int M, int N, int K);

@@ -31,6 +31,27 @@ __device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
     return __builtin_bit_cast(unsigned, v);
 }
 
+// ---- "the last block to arrive finishes the job" (cdna_hip_programming.md §6 Guideline 16, form R1): every block has written its
+// partial results WRITE-THROUGH (sc1 / relaxed agent-scope atomic stores: the bytes leave the XCD's L2, so no release fence). Every
+// storing wave drains its stores (asm wait: the compiler does not count on it), barrier, ONE lane draws a ticket (relaxed, agent scope).
+// The block that draws n - 1 does ONE agent-scope acquire (drops this CU's L1), puts the counter back to zero for the next launch and
+// returns true (uniformly for its threads): it may now read every block's partials with plain loads. `flag`: one int of LDS the block
+// no longer uses (never a second __shared__ object in a kernel with a counted LDS-DMA pipeline). `cnt` must be zero at launch.
+__device__ __forceinline__ bool grid_arrive_last(int* cnt, int n, int* flag) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (ticket == n - 1) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        *flag = ticket;
+    }
+    __syncthreads();
+    return *flag == n - 1;
+}
+
 #define CB_DT_SWITCH(dt, T, ...)                                        \
     do {                                                                \
         if ((dt) == DT_BF16) { typedef bf16_t T; __VA_ARGS__; }         \

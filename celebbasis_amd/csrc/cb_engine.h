@@ -89,6 +89,7 @@ struct Ctx {
     DType load_dt = DT_F32;      // element type the weight loaders currently pack to (set by the *_load functions)
     // the face warp's constant sampling grid [S][S][2] as the caller's host evaluated it (cb_ctx_set_warp_grid); nullptr = analytic
     float* warp_grid = nullptr; int warp_S = 0;
+    long warp_gen = 0;           // bumped by every cb_ctx_set_warp_grid: a captured step graph holds the table's device pointer
     const float* warp_grid_for(int S) const { return (warp_grid && warp_S == S) ? warp_grid : nullptr; }
     Launch launch() { join_tail(); return launch_nojoin(); }
     Launch launch_nojoin() { Launch L; L.stream = stream; L.dry = dry; L.stats = &stats; L.prof = &prof; L.cnt = &arena.cnt; return L; }   // the trainer's own steps only

@@ -53,20 +53,7 @@ __device__ __forceinline__ float4 buf_ld4(__amdgpu_buffer_rsrc_t srd, int byte_o
 // launch, barrier, and then every thread reads ALL slabs (its own included) in split order: the sum does not depend on which block
 // arrived last — deterministic, and the same order as splitk_reduce_kernel. `flag` is one int of the block's (idle) tile ring: no
 // second __shared__ object (that would de-pipeline the k loop, guide §5 "three .s-level traps"). Returns true in the reducer block.
-__device__ __forceinline__ bool splitk_arrive(int* cnt, int splitk, int* flag) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const int ticket = __hip_atomic_fetch_add(cnt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (ticket == splitk - 1) {
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-            __hip_atomic_store(cnt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-        *flag = ticket;
-    }
-    __syncthreads();
-    return *flag == splitk - 1;
-}
+__device__ __forceinline__ bool splitk_arrive(int* cnt, int splitk, int* flag) { return grid_arrive_last(cnt, splitk, flag); }
 // 8 consecutive fp32 partials of one output row -> the block's slab, write-through. `srd` = the slab, `off` = byte offset in it.
 __device__ __forceinline__ void splitk_store8(__amdgpu_buffer_rsrc_t srd, float* slab, int off, const float (&v)[8], bool v4, int nvalid) {
     if (v4) {
@@ -397,7 +384,8 @@ inline const std::unordered_map<std::string, PlanEntry>& plan_table() {
 }
 
 // diagnostics (tools/tune_gemm.py): restrict the planner to one tile shape / split count; 0 = free. Not thread safe, not for production.
-struct PlanForce { int BM = 0, BN = 0, split = 0; int glds_safe = 0; int splitk_inlaunch = 1; };
+struct PlanForce { int BM = 0, BN = 0, split = 0; int glds_safe = 0; int splitk_inlaunch = 1;
+                   long gen = 0;   /* bumped by every cb_debug_* call that changes it: captured step graphs carry the value they were made under */ };
 inline PlanForce& plan_force() {
     static PlanForce f = [] {
         PlanForce g;
@@ -429,8 +417,8 @@ inline Plan make_plan(const GemmArgs& a, int bke, double speed, bool n80 = false
     double best = 1e300;
     Plan pl{128, 128, 1, 1, 1, ksteps * bke};
     PlanForce pf = plan_force();
-    if (pf.BN == 80 && !n80) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; }   // a pinned 80-column tile only binds the problems that can run it
-    if (is_p8_tile(pf.BM, pf.BN) && !p8) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; }   // likewise the 256 x 256 bf16 tile
+    if (pf.BN == 80 && !n80) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; pf.gen = keep.gen; }   // a pinned 80-column tile only binds the problems that can run it
+    if (is_p8_tile(pf.BM, pf.BN) && !p8) { const PlanForce keep = pf; pf = PlanForce{}; pf.glds_safe = keep.glds_safe; pf.splitk_inlaunch = keep.splitk_inlaunch; pf.gen = keep.gen; }   // likewise the 256 x 256 bf16 tile
     if (!pf.BM && !pf.split) {
         const auto& tab = plan_table();
         if (!tab.empty()) {

@@ -384,14 +384,43 @@ __device__ __forceinline__ void gn_block_reduce(float* __restrict__ part, float*
         for (int rr = 0; rr < m.rif; ++rr)
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += chs[((long)rr * C + c) * 2]; b += chs[((long)rr * C + c) * 2 + 1]; }
         float* o = part + ((long)blockIdx.x * G + g) * 2;
-        o[0] = a; o[1] = b;
+        // write-through (sc1): the launch's last-arriving block reads these from another CU / XCD (grid_arrive_last)
+        __hip_atomic_store(o, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(o + 1, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 static size_t gn_lds_bytes(int C) { int Q = C / 4; int rif = Q <= 256 ? 256 / Q : 1; return (size_t)rif * C * 2 * sizeof(float); }
 
+// one wave per (n, g): reduce chunk partials in double -> stats (mean, rstd) and per-channel {mean, rstd, gamma, beta}
+template <typename T>
+__device__ __forceinline__ void gn_final_one(int w, int lane, float* __restrict__ stats, float* __restrict__ chn, const float* __restrict__ part,
+                                             const T* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ beta, int HW, int C,
+                                             int G, int nchunk, float eps) {
+    int n = w / G, g = w % G, cpg = C / G;
+    double a = 0, b = 0;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
+        a += o[0]; b += o[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    double cnt = (double)HW * cpg;
+    double sh = ld1(x + (long)n * HW * C + g * cpg);
+    double mloc = a / cnt;
+    double var = b / cnt - mloc * mloc;
+    if (var < 0) var = 0;
+    float mean = (float)(mloc + sh), rstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (lane == 0) { stats[w * 2] = mean; stats[w * 2 + 1] = rstd; }
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64)
+        *reinterpret_cast<float4*>(chn + ((long)n * C + c) * 4) = make_float4(mean, rstd, gamma[c], beta[c]);
+}
+// cnt != nullptr: the statistics pass finishes itself — the launch's last-arriving block (grid_arrive_last) reduces all chunk partials
+// and writes stats + the per-channel constants: no gn_final launch between the two passes (55 + 30 launches of the fp32 step)
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const T* __restrict__ x, int HW, int C,
-                                                          int G, int nchunk, int rpb) {
+                                                          int G, int nchunk, int rpb, int* cnt, float* __restrict__ stats,
+                                                          float* __restrict__ chn, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, int N, float eps) {
     extern __shared__ __attribute__((aligned(16))) float chs[];
     int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
@@ -420,8 +449,10 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ par
             }
     }
     gn_block_reduce(part, chs, m, sa, sb, C, G);
+    if (!cnt) return;
+    if (!grid_arrive_last(cnt, (int)gridDim.x, reinterpret_cast<int*>(chs))) return;
+    for (int w = threadIdx.x >> 6; w < N * G; w += 4) gn_final_one<T>(w, threadIdx.x & 63, stats, chn, part, x, gamma, beta, HW, C, G, nchunk, eps);
 }
-// one wave per (n, g): reduce chunk partials in double -> stats (mean, rstd) and per-channel {mean, rstd, gamma, beta}
 template <typename T>
 __global__ __launch_bounds__(256) void gn_final_kernel(float* __restrict__ stats, float* __restrict__ chn,
                                                         const float* __restrict__ part, const T* __restrict__ x,
@@ -429,23 +460,7 @@ __global__ __launch_bounds__(256) void gn_final_kernel(float* __restrict__ stats
                                                         int C, int G, int nchunk, float eps) {
     int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (w >= N * G) return;
-    int n = w / G, g = w % G, cpg = C / G;
-    double a = 0, b = 0;
-    for (int ch = lane; ch < nchunk; ch += 64) {
-        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
-        a += o[0]; b += o[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    double cnt = (double)HW * cpg;
-    double sh = ld1(x + (long)n * HW * C + g * cpg);
-    double mloc = a / cnt;
-    double var = b / cnt - mloc * mloc;
-    if (var < 0) var = 0;
-    float mean = (float)(mloc + sh), rstd = (float)(1.0 / sqrt(var + (double)eps));
-    if (lane == 0) { stats[w * 2] = mean; stats[w * 2 + 1] = rstd; }
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64)
-        *reinterpret_cast<float4*>(chn + ((long)n * C + c) * 4) = make_float4(mean, rstd, gamma[c], beta[c]);
+    gn_final_one<T>(w, lane, stats, chn, part, x, gamma, beta, HW, C, G, nchunk, eps);
 }
 // rebuild the per-channel constants from saved stats (backward entry through the ABI)
 __global__ void gn_expand_kernel(float* __restrict__ chn, const float* __restrict__ stats, const float* __restrict__ gamma,
@@ -647,7 +662,10 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
     float* part = ws;
     float* chn = ws + (size_t)N * nchunk * G * 2;
     const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
-    (void)L.count(fused ? 1 : 3);
+    // chip-wide form: the statistics launch finishes itself in its last-arriving block (CB_GN_INLAUNCH=0: separate gn_final launch)
+    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return !(e && e[0] == '0'); }();
+    int* const cnt = (!fused && inl && L.cnt) ? L.cnt->take(1) : nullptr;
+    (void)L.count(fused ? 1 : (cnt ? 2 : 3));
     if (L.dry) return;
     // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
     // launch-latency bound and would otherwise drown the achieved-bandwidth figure
@@ -663,8 +681,9 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
         });
     } else
     CB_DT_SWITCH(dt, T, {
-        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb);
-        hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
+        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb,
+                           cnt, stats, chn, gamma, beta, N, eps);
+        if (!cnt) hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
         if (GnVec<T>::VQ == 2 && C % 8 == 0)
             hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
         else
@@ -674,10 +693,26 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
     CB_HIP(hipGetLastError());
 }
 
+// one wave per (n, g): chunk partials -> per-channel {s1, s2} (already divided by the group size)
+__device__ __forceinline__ void gn_bwd_final_one(int w, int lane, float* __restrict__ gs, const float* __restrict__ part, int HW, int C, int G,
+                                                 int nchunk) {
+    int n = w / G, g = w % G, cpg = C / G;
+    double a = 0, b = 0;
+    for (int ch = lane; ch < nchunk; ch += 64) {
+        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
+        a += o[0]; b += o[1];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+    double cnt = (double)HW * cpg;
+    float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
+    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) { gs[((long)n * C + c) * 2] = s1; gs[((long)n * C + c) * 2 + 1] = s2; }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__ part, const T* __restrict__ x,
                                                               const T* __restrict__ dy, const float* __restrict__ chn, int HW,
-                                                              int C, int G, int nchunk, int rpb, int silu) {
+                                                              int C, int G, int nchunk, int rpb, int silu, int* cnt, float* __restrict__ gs,
+                                                              int N) {
     extern __shared__ __attribute__((aligned(16))) float chs[];
     int n = blockIdx.x / nchunk, chunk = blockIdx.x % nchunk;
     int r0 = chunk * rpb, r1 = min(HW, r0 + rpb);
@@ -712,23 +747,16 @@ __global__ __launch_bounds__(256) void gn_bwd_partial_kernel(float* __restrict__
             }
     }
     gn_block_reduce(part, chs, m, sa, sb, C, G);
+    if (!cnt) return;                                  // (cnt: as in gn_partial_kernel — the last-arriving block finishes the statistics)
+    if (!grid_arrive_last(cnt, (int)gridDim.x, reinterpret_cast<int*>(chs))) return;
+    for (int w = threadIdx.x >> 6; w < N * G; w += 4) gn_bwd_final_one(w, threadIdx.x & 63, gs, part, HW, C, G, nchunk);
 }
 // one wave per (n, g): chunk partials -> per-channel {s1, s2} (already divided by the group size)
 __global__ __launch_bounds__(256) void gn_bwd_final_kernel(float* __restrict__ gs, const float* __restrict__ part, int N, int HW,
                                                             int C, int G, int nchunk) {
     int w = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (w >= N * G) return;
-    int n = w / G, g = w % G, cpg = C / G;
-    double a = 0, b = 0;
-    for (int ch = lane; ch < nchunk; ch += 64) {
-        const float* o = part + (((long)n * nchunk + ch) * G + g) * 2;
-        a += o[0]; b += o[1];
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
-    double cnt = (double)HW * cpg;
-    float s1 = (float)(a / cnt), s2 = (float)(b / cnt);
-    for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64) { gs[((long)n * C + c) * 2] = s1; gs[((long)n * C + c) * 2 + 1] = s2; }
+    gn_bwd_final_one(w, lane, gs, part, HW, C, G, nchunk);
 }
 template <typename T, int VQ>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(T* __restrict__ dx, const T* __restrict__ x,
@@ -785,7 +813,9 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
     float* chn = ws + (size_t)N * nchunk * G * 2;
     float* gs = chn + (size_t)N * C * 4;
     const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
-    (void)L.count(fused ? 1 : (chn_valid ? 3 : 4));
+    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return !(e && e[0] == '0'); }();
+    int* const cnt = (!fused && inl && L.cnt) ? L.cnt->take(1) : nullptr;
+    (void)L.count(fused ? 1 : (chn_valid ? 3 : 4) - (cnt ? 1 : 0));
     if (L.dry) return;
     const double esz = (double)dt_size(dt);
     const bool big = (double)N * HW * C * esz >= 64e6;
@@ -806,8 +836,8 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
     long nquads = (long)N * HW * (C / 4);
     CB_DT_SWITCH(dt, T, {
         hipLaunchKernelGGL((gn_bwd_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, (const T*)dy,
-                           chn, HW, C, G, nchunk, rpb, silu);
-        hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
+                           chn, HW, C, G, nchunk, rpb, silu, cnt, gs, N);
+        if (!cnt) hipLaunchKernelGGL(gn_bwd_final_kernel, dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, gs, part, N, HW, C, G, nchunk);
         if (GnVec<T>::VQ == 2 && C % 8 == 0)
             hipLaunchKernelGGL((gn_bwd_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, (T*)dx, (const T*)x,
                                (const T*)dy, chn, gs, nquads, HW, C, silu, acc_beta);
@@ -1703,7 +1733,9 @@ void k_outer_grad(const Launch& L, float* dW, float* db, const float* dpre, cons
 // torch.optim.AdamW single-tensor update (ddpm.py:1454; defaults betas (0.9,0.999), eps 1e-8, wd 1e-2).
 // The step counter lives on the device so the whole training step can be replayed from a hipGraph.
 __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float* __restrict__ v, const float* __restrict__ g,
-                             long n, const int* __restrict__ step, float lr, float b1, float b2, float eps, float wd) {
+                             long n, const int* __restrict__ step, float lr_arg, const float* __restrict__ lr_dev, float b1, float b2,
+                             float eps, float wd) {
+    const float lr = lr_dev ? *lr_dev : lr_arg;       // a captured step graph reads the learning rate from a device scalar: one graph serves every lr
     int t = *step;
     double bc1 = 1.0 - pow((double)b1, (double)t);
     double bc2 = 1.0 - pow((double)b2, (double)t);
@@ -1720,8 +1752,8 @@ __global__ void adamw_kernel(float* __restrict__ p, float* __restrict__ m, float
     }
 }
 void k_adamw(const Launch& L, float* p, float* m, float* v, const float* g, long n, const int* step, float lr, float b1, float b2,
-             float eps, float wd) {
-    LAUNCH(adamw_kernel, grid1d(n), dim3(256), L, p, m, v, g, n, step, lr, b1, b2, eps, wd);
+             float eps, float wd, const float* lr_dev) {
+    LAUNCH(adamw_kernel, grid1d(n), dim3(256), L, p, m, v, g, n, step, lr, lr_dev, b1, b2, eps, wd);
 }
 __global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
 void k_step_inc(const Launch& L, int* step) { LAUNCH(step_inc_kernel, dim3(1), dim3(64), L, step); }

@@ -125,6 +125,7 @@ struct Trainer {
     float* id_emb = nullptr; float* id_coef = nullptr;   // [max_ids][es*width], [max_ids][es*inner]
     float* sqrt_ac = nullptr; float* sqrt_1mac = nullptr;
     float* loss = nullptr;                        // device scalar
+    float* lr_dev = nullptr;                      // device scalar: the learning rate of a REPLAYED step (written before every hipGraphLaunch)
     size_t arena_need = 0; int arena_B = 0;
     bool capturing = false;                       // step_impl runs under hipStreamBeginCapture (no deferred tail)
     bool tail_overlap = true;                     // cb_trainer_set_tail_overlap / CB_TAIL_OVERLAP=0: the step's tail on the side stream, joined lazily
@@ -151,7 +152,10 @@ struct Trainer {
     // hands out the same addresses every step (cb_engine.h). Results are bitwise those of the eager path: same kernels, same order.
     struct StepGraph {
         bool enabled = false;
-        struct Entry { int B = 0; float lr = 0.f; hipGraphExec_t exec = nullptr; long used = 0; const void* arena_base = nullptr; };
+        // a graph bakes in: the arena's addresses, the context's warp-grid table pointer, the (tile, split-K) plans and pipeline
+        // variants in force at capture. Each has a generation stamp; an entry captured under other stamps is dropped, not replayed.
+        struct Entry { int B = 0; hipGraphExec_t exec = nullptr; long used = 0; const void* arena_base = nullptr; long warp_gen = 0, plan_gen = 0; };
+        bool broken = false;                      // a capture / instantiate failed once: the trainer stays on eager launches
         std::vector<Entry> cache;                 // at most kMaxGraphs, least recently used evicted
         float* image = nullptr; float* faces = nullptr; int64_t* ids = nullptr; int64_t* tokens = nullptr; int64_t* t = nullptr;
         float* noise = nullptr; float* post_noise = nullptr;       // staging, sized for kMaxBatch

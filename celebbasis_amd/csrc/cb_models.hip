@@ -1,6 +1,7 @@
 // cb_models.hip — UNet / VAE encoder / CLIP text transformer / iresnet / CelebBasis head / training step,
 // expressed on the tape runtime. Weight names follow the reference state-dict keys.
 #include "cb_models.h"
+#include "cb_gemm_tiles.h"
 #include <cmath>
 
 namespace cb {
@@ -481,6 +482,7 @@ void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T) {
     T->id_coef = wt.has("id_coefficients") ? ctx->upload(wt, "id_coefficients", {cfg.max_ids, cfg.es * cfg.inner_dim})
                                            : zeros((size_t)cfg.max_ids * cfg.es * cfg.inner_dim);
     T->loss = zeros(64);
+    T->lr_dev = zeros(64);
     // ddpm.py:126-178 register_schedule with util.py:21-25 "linear" (sqrt-space linspace), float64 -> float32
     std::vector<float> sa(cfg.timesteps), sb(cfg.timesteps);
     double s0 = std::sqrt((double)cfg.linear_start), s1 = std::sqrt((double)cfg.linear_end), ac = 1.0;
@@ -734,6 +736,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         }
     } tail_done{ctx, G, main_stream, defer_tail, T, layout};
     Phase ph_tail(L, "phase:head_bwd_adamw");
+    const float* lr_dev = T->capturing ? T->lr_dev : nullptr;      // a captured step reads the rate from the device: one graph per batch size
     CB_CHECK(ctx->dry || emb1->ginit, CB_ERR_STATE, "no gradient reached the text embeddings");
     if (!emb1->g) emb1->g = ctx->arena.allocf((size_t)emb1->numel());
     float* dzz = ctx->arena.allocf((size_t)NF * es * w);
@@ -746,7 +749,7 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
         // d coef[id] = sum of dxn over the rows that gathered it (dense gradient: absent identities get zero, like autograd's
         // index backward; torch's AdamW then still applies weight decay to those rows)
         k_coef_scatter_grad(L, T->gC, dxn, bt.ids, 2, B, 2, O, c.max_ids);
-        k_adamw(L, T->coef, T->mC, T->vC, T->gC, (long)c.max_ids * O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
+        k_adamw(L, T->coef, T->mC, T->vC, T->gC, (long)c.max_ids * O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, lr_dev);
         return;
     }
     float* dact = ctx->arena.allocf((size_t)NF * O);
@@ -756,8 +759,8 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     k_outer_grad(L, T->gW, T->gb, dpre, v->pf(), NF, O, I);
 
     // (8) AdamW on the 525 312 trainable floats (ddpm.py:1442-1454)
-    k_adamw(L, T->W, T->mW, T->vW, T->gW, (long)O * I, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
-    k_adamw(L, T->b, T->mb, T->vb, T->gb, (long)O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay);
+    k_adamw(L, T->W, T->mW, T->vW, T->gW, (long)O * I, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, lr_dev);
+    k_adamw(L, T->b, T->mb, T->vb, T->gb, (long)O, T->step, lr, c.adam_b1, c.adam_b2, c.adam_eps, c.weight_decay, lr_dev);
 }
 
 void trainer_set_graph_replay(Trainer* T, bool on) { T->graph.enabled = on; }
@@ -788,39 +791,54 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
     stage(g.ids, bt.ids, (size_t)B * 2 * sizeof(int64_t));
     stage(g.tokens, bt.tokens, (size_t)B * T77 * sizeof(int64_t));
     stage(g.t, bt.t, (size_t)B * sizeof(int64_t));
-    // a graph is valid for the arena it was captured on: a larger batch size in between re-allocates the step arena (ensure_arena) and
-    // every address inside the older graphs is gone with it
+    // a graph is valid for the arena it was captured on (a larger batch size in between re-allocates the step arena and every address
+    // inside the older graphs is gone with it), for the warp-grid table the context held (its device pointer is a captured kernel
+    // argument; cb_ctx_set_warp_grid may have freed or replaced it since) and for the GEMM plans / pipeline switches in force
+    // (cb_debug_force_plan and friends change which kernels a step launches): anything captured under other stamps is dropped
+    const long plan_gen = plan_force().gen;
     for (size_t i = 0; i < g.cache.size();) {
-        if (g.cache[i].arena_base != ctx->arena.base) {
+        if (g.cache[i].arena_base != ctx->arena.base || g.cache[i].warp_gen != ctx->warp_gen || g.cache[i].plan_gen != plan_gen) {
             CB_HIP(hipStreamSynchronize(s));
             (void)hipGraphExecDestroy(g.cache[i].exec);
             g.cache.erase(g.cache.begin() + i);
         } else ++i;
     }
     Trainer::StepGraph::Entry* e = nullptr;
-    for (auto& x : g.cache) if (x.B == B && x.lr == lr) e = &x;
+    for (auto& x : g.cache) if (x.B == B) e = &x;
     if (!e) {
         Batch sb;
         sb.image = g.image; sb.faces = g.faces; sb.ids = g.ids; sb.tokens = g.tokens; sb.t = g.t; sb.noise = g.noise; sb.post_noise = g.post_noise;
         sb.B = B;
         hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
         ctx->arena.reset();
         // the caller's stream may be the legacy default stream (PyTorch's current stream usually is), which cannot be captured: the
-        // step's host code runs once against a library-owned capture stream; the instantiated graph is launched on the caller's
-        if (!g.cap) CB_HIP(hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking));
-        ctx->stream = g.cap;
-        hipError_t rcb = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal);
-        if (rcb != hipSuccess) { ctx->stream = s; CB_HIP(rcb); }
-        T->capturing = true;          // every forked stream must rejoin the capture stream: no deferred tail
-        try { step_impl(T, sb, lr); }
-        catch (...) { T->capturing = false; ctx->stream = s; (void)hipStreamEndCapture(g.cap, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
-        T->capturing = false;
-        ctx->stream = s;
-        CB_HIP(hipStreamEndCapture(g.cap, &graph));
-        hipGraphExec_t exec = nullptr;
-        hipError_t rc = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        CB_HIP(rc);
+        // step's host code runs once against a library-owned capture stream; the instantiated graph is launched on the caller's.
+        // A runtime that refuses the capture or the instantiation must not take the training run down: the trainer falls back to
+        // eager launches for good (graph.broken) and this step runs eagerly.
+        bool ok = true;
+        if (!g.cap) ok = hipStreamCreateWithFlags(&g.cap, hipStreamNonBlocking) == hipSuccess;
+        if (ok) {
+            ctx->stream = g.cap;
+            ok = hipStreamBeginCapture(g.cap, hipStreamCaptureModeThreadLocal) == hipSuccess;
+            if (ok) {
+                T->capturing = true;          // every forked stream must rejoin the capture stream: no deferred tail
+                try { step_impl(T, sb, lr); }
+                catch (...) { T->capturing = false; ctx->stream = s; (void)hipStreamEndCapture(g.cap, &graph); if (graph) (void)hipGraphDestroy(graph); throw; }
+                T->capturing = false;
+                ok = hipStreamEndCapture(g.cap, &graph) == hipSuccess && graph != nullptr;
+            }
+            ctx->stream = s;
+            if (ok) ok = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess;
+            if (graph) (void)hipGraphDestroy(graph);
+        }
+        if (!ok) {
+            (void)hipGetLastError();
+            g.broken = true;
+            ctx->arena.reset();
+            step_impl(T, bt, lr);            // eager, on the caller's own buffers (nothing was launched by the failed capture)
+            return;
+        }
         if ((int)g.cache.size() >= kMaxGraphs) {
             size_t lru = 0;
             for (size_t i = 1; i < g.cache.size(); ++i) if (g.cache[i].used < g.cache[lru].used) lru = i;
@@ -828,10 +846,14 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
             (void)hipGraphExecDestroy(g.cache[lru].exec);
             g.cache.erase(g.cache.begin() + lru);
         }
-        Trainer::StepGraph::Entry ne; ne.B = B; ne.lr = lr; ne.exec = exec; ne.arena_base = ctx->arena.base;
+        Trainer::StepGraph::Entry ne; ne.B = B; ne.exec = exec; ne.arena_base = ctx->arena.base; ne.warp_gen = ctx->warp_gen; ne.plan_gen = plan_gen;
         g.cache.push_back(ne);
         e = &g.cache.back();
         g.captures++;
+    }
+    {   // the rate of THIS step: a 4-byte memset node ahead of the graph (no host buffer whose lifetime would matter)
+        unsigned bits; memcpy(&bits, &lr, sizeof bits);
+        CB_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(T->lr_dev), (int)bits, 1, s));
     }
     e->used = ++g.tick;
     CB_HIP(hipGraphLaunch(e->exec, s));
@@ -844,7 +866,7 @@ void trainer_step(Trainer* T, const Batch& bt, float lr, bool dry_only) {
     // graph replay from the second step at a batch size on (the first one runs eagerly: it sizes the arena and latches the per-kernel
     // dynamic-LDS attributes); not while the live profiler is recording (its event pairs are host calls) or debug taps are collected (they are
     // registered by the host code of an eager step), and not for a batch whose first stage was prefetched (that path waits on a prefetch event the captured graph does not know)
-    if (T->graph.enabled && !ctx->dry && !dry_only && T->arena_B == bt.B && !ctx->prof.on && !ctx->debug_taps) {
+    if (T->graph.enabled && !T->graph.broken && !ctx->dry && !dry_only && T->arena_B == bt.B && !ctx->prof.on && !ctx->debug_taps) {
         bool prefetched = false;
         for (auto& sl : T->pf.slot)
             if (sl.valid && sl.image == bt.image && sl.faces == bt.faces && sl.post_noise == bt.post_noise && sl.B == bt.B) prefetched = true;

@@ -13,8 +13,8 @@ instead of on the CPU oracle:
     python oracle/gen_horizon.py fp32noise2 -> horizon_sd14_b1_noise2.pt  the default (white-noise) stream with other frozen weights and another batch stream
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
-`oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first 10 steps of the fp32 run are the ones
-tests/test_gpu_models.py::test_train_10_steps_sd14_drift recomputes live, which ties the fixture to the live oracle.
+`oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first steps of the fp32 run are the ones
+tests/test_gpu_models.py::test_train_4_steps_sd14_live_oracle recomputes live, which ties the fixture to the live oracle.
 Per step the file holds the loss, the coefficients of every face in the batch (meta_net.py:289, [2B, es, inner]) and the EMA
 dictionary rows of the identities in the batch (embedding_manager.py:484-489); the MLP gradient is kept for a few steps on every
 16th row (a 32 768-element sample: the full 2 MB per step would not be a small fixture)."""
@@ -52,6 +52,12 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # the DEFAULT (white-noise) stream drawn again: other frozen weights, another batch stream
             fp32noise2=dict(B=1, steps=800, lr=5e-3, seed=11, batch_seed0=7000, out="horizon_sd14_b1_noise2.pt", grad_steps=(), slim=True,
                             coef_steps=0, id_coef_stride=4),
+            # round 6: the default stream on the face-warp table of ANOTHER host — the GPU box's EPYC, whose F.affine_grid differs from this
+            # host's in 14 % of the elements by one ulp (tests/golden/warp_grid_gpubox_512.npz, captured there by
+            # tools/probes/capture_host_affine_grid.py). This is the oracle on the table the PRODUCT'S DEFAULT path (lib.Trainer builds the
+            # table with the host's own F.affine_grid) uses on that box: tests/test_gpu_models.py::test_train_120_steps_sd14_default_table
+            fp32boxgrid=dict(B=1, steps=120, lr=5e-3, seed=8, out="horizon_sd14_b1_boxgrid.pt", grad_steps=(), slim=True, coef_steps=120,
+                             grid_npz="warp_grid_gpubox_512.npz"),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
 ROW_STRIDE = 16
 
@@ -62,6 +68,23 @@ def main(which, steps=None):
         r["steps"] = int(steps)
     if r.get("threads"):
         torch.set_num_threads(r["threads"])
+    if r.get("grid_npz"):
+        import numpy as np
+        from oracle.replay import fixture_host_warp_grid
+        z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "tests", "golden", r["grid_npz"]))
+        S = int(z["S"])
+        table = fixture_host_warp_grid(S).numpy().copy()
+        table.reshape(-1)[np.unpackbits(z["mask"])[:table.size].astype(bool)] = z["values"]
+        import hashlib
+        assert hashlib.sha1(table.tobytes()).hexdigest()[:12] == str(z["sha1_host"]), "captured table does not reproduce its digest"
+        table_t = torch.from_numpy(table)
+        real_grid = O.F.affine_grid
+
+        def host_grid(theta, size, align_corners=None):          # the reference's call with its constant matrix at S x S -> the other host's table
+            if list(size[-2:]) == [S, S] and align_corners and torch.equal(theta[0], torch.tensor(O.TRANS_MATRIX, dtype=torch.float32)):
+                return table_t[None].expand(theta.shape[0], S, S, 2).contiguous()
+            return real_grid(theta, size, align_corners=align_corners)
+        O.F.affine_grid = host_grid
     if r.get("grad_noise"):
         eps, gen, real = float(r["grad_noise"]), torch.Generator().manual_seed(77), O.adamw_step
 
@@ -76,7 +99,7 @@ def main(which, steps=None):
     st = O.TrainState(W)
     ids = sorted({1 + (b % (m["max_ids"] - 1)) for b in range(r["B"])})
     seed0 = int(r.get("batch_seed0", 100))
-    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=seed0, id_coef_stride=int(r.get("id_coef_stride", 1)), row_stride=ROW_STRIDE, ids=ids, photo=bool(r.get("photo")),
+    rec = dict(cfg=dict(B=r["B"], lr=r["lr"], weight_seed=r["seed"], batch_seed0=seed0, grid_npz=r.get("grid_npz"), id_coef_stride=int(r.get("id_coef_stride", 1)), row_stride=ROW_STRIDE, ids=ids, photo=bool(r.get("photo")),
                         torch=torch.__version__, threads=torch.get_num_threads()),
                loss=[], coef=[], id_coef=[], id_emb_norm=[], gW_rows={}, gb={})
     W0 = st.Wm.clone()

@@ -371,14 +371,54 @@ def test_graph_replay_is_bitwise_the_eager_step_mini(cb):
     e, g = out[False], out[True]
     assert e["stats"] == dict(captures=0, replays=0), e["stats"]
     # eager: the first step at B=1, the first at B=2 and the first back at B=1 (each re-plans the step arena; the B=2 arena is larger, so
-    # the B=1 graph captured before it is dropped and re-captured afterwards). Captures: (1, 5e-3), (2, 1e-2), (1, 5e-3) again,
-    # (1, 2.5e-3); a capture step launches its graph too
-    # (at mini size the arena's slack covers B=2 and nothing is re-allocated: 3 captures)
-    assert g["stats"]["captures"] in (3, 4) and g["stats"]["replays"] == len(script) - 3, g["stats"]
+    # the B=1 graph captured before it is dropped and re-captured afterwards). One graph per batch size — the learning rate is read from
+    # a device scalar (round 6; one graph per (B, lr) before) —: captures B=1, B=2 and, if the arena moved, B=1 again; a capture step
+    # launches its graph too (at mini size the arena's slack covers B=2 and nothing is re-allocated: 2 captures)
+    assert g["stats"]["captures"] in (2, 3) and g["stats"]["replays"] == len(script) - 3, g["stats"]
     assert g["losses"] == e["losses"], (g["losses"], e["losses"])
     for k in ("W", "b", "idc", "ide", "gW"):
         assert torch.equal(g[k], e[k]), f"graph replay changed {k}: max diff {(g[k] - e[k]).abs().max().item():.3e}"
     REPORT["graph_replay.mini"] = g["stats"]
+
+
+def test_graph_replay_drops_graphs_captured_under_another_warp_table_or_plan(cb):
+    """round-5 advisor finding: a captured step holds the context's warp-grid device pointer and the GEMM plans in force as baked-in
+    kernel arguments / nodes. cb_ctx_set_warp_grid and the cb_debug_* switches bump generation stamps; a graph captured under other
+    stamps is dropped and re-captured at its next use — the replaying trainer stays BITWISE on the eager one across both changes."""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    m = MINI
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = cached_weights(O, shapes, 5)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    ctx.set_debug_taps(False)
+    base = ctx.warp_grid_host.clone() if getattr(ctx, "warp_grid_host", None) is not None and ctx.warp_grid_host.shape[0] == m["image"] else None
+    out = {}
+    try:
+        for graph in (False, True):
+            tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+            grid0 = ctx.warp_grid_host.clone()
+            tr.set_graph_replay(graph)
+            for s in range(9):
+                if s == 3:
+                    ctx.set_warp_grid(grid0 + 1e-3)                      # another table (a shifted crop): frees / rewrites the device buffer
+                if s == 6:
+                    lib.check(lib.load().cb_debug_force_plan(64, 64, 1))  # other kernels for every GEMM the pin binds
+                dev = {k: dv(v) for k, v in make_batch(1, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 500 + s, m["max_ids"]).items()}
+                tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], 5e-3 * (1 + s % 2))
+                del dev
+            out[graph] = dict(W=tr.get_state("mlp.weight").clone(), idc=tr.get_state("id_coefficients").clone(), loss=float(tr.get_state("loss")[0]),
+                              stats=tr.graph_stats())
+            lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+            ctx.set_warp_grid(grid0)
+            tr.close()
+    finally:
+        lib.check(lib.load().cb_debug_force_plan(0, 0, 0))
+        if base is not None:
+            ctx.set_warp_grid(base)
+    e, g = out[False], out[True]
+    assert g["stats"]["captures"] == 3 and g["stats"]["replays"] == 8, g["stats"]        # one capture per stamp set; two learning rates, one graph
+    assert g["loss"] == e["loss"] and torch.equal(g["W"], e["W"]) and torch.equal(g["idc"], e["idc"])
 
 
 def test_graph_replay_is_bitwise_the_eager_step_sd14(cb):
@@ -455,15 +495,17 @@ def test_train_step_sd14_bs2_vs_oracle(cb):
     run_steps(lib, ctx, SD14(O), B=2, steps=1, lr=1e-2, seed=6, check_aux=True)
 
 
-def test_train_10_steps_sd14_drift(cb, golden_dir):
-    """BASELINE config 2 over a horizon AT FULL SIZE: 10 optimiser steps, SD v1-4 512x512 bs=1, against the oracle on the same
-    replay stream. Every step checks loss / dW / db; the drift table (gpurun_out/sd14_drift.json) records how the errors grow
-    with the step count; the end state meets the north_star bar (coefficients within 1e-3 L2)"""
+def test_train_4_steps_sd14_live_oracle(cb, golden_dir):
+    """BASELINE config 2 AT FULL SIZE against the LIVE oracle on this box (the product's default warp table on both sides): 4 optimiser
+    steps, SD v1-4 512x512 bs=1, on the replay stream. Every step checks loss / dW / db; the end state meets the north_star bar
+    (coefficients within 1e-3 L2), and the live oracle reproduces the losses of the committed trajectories, which ties those fixtures
+    to it. (10 steps through round 5; the horizon on the default table is now test_train_120_steps_sd14_default_table — 120 steps against
+    a stored oracle run — and the 70 s of live oracle time went with it.)"""
     from oracle import cb_oracle as O
     lib, ctx = cb
     torch.set_num_threads(min(64, os.cpu_count() or 1))
     drift = []
-    run_steps(lib, ctx, SD14(O), B=1, steps=10, lr=5e-3, seed=8, check_aux=False, drift=drift)
+    run_steps(lib, ctx, SD14(O), B=1, steps=4, lr=5e-3, seed=8, check_aux=False, drift=drift)
     REPORT["step[512px,B1].drift"] = drift
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/sd14_drift.json", "w") as f:
@@ -473,33 +515,50 @@ def test_train_10_steps_sd14_drift(cb, golden_dir):
     # the committed 100-step oracle trajectory (tests/golden/horizon_sd14_b1.pt, generated on other host cores) starts with these
     # very steps: the oracle recomputed live here must reproduce its losses
     fx = load(golden_dir, "horizon_sd14_b1.pt")
-    for d, ref in zip(drift, fx["loss"][:10].tolist()):
+    for d, ref in zip(drift, fx["loss"][:4].tolist()):
         assert abs(d["loss_ref"] - ref) <= 2e-5 * abs(ref), (d["step"], d["loss_ref"], ref)
     # AdamW's update has size lr whatever the gradient's size, so the weight delta's relative error stays bounded instead of compounding
     assert drift[-1]["weight_delta_rel_l2"] <= 2e-2
 
 
-def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
+def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None, grid="fixture_host"):
     """HIP trainer over the replay stream of a committed oracle trajectory (oracle/gen_horizon.py -> tests/golden/horizon_*.pt):
     per-step table of |loss - ref| / ref, max-over-faces L2 of the step's coefficients (meta_net.py:289: the quantity north_star's
-    bar is stated on), L2 of the EMA dictionary rows (embedding_manager.py:484-489), and the MLP gradient on the sampled rows"""
+    bar is stated on), L2 of the EMA dictionary rows (embedding_manager.py:484-489), and the MLP gradient on the sampled rows.
+    grid = "fixture_host": the warp table of the host that generated the trajectory is handed in through the ABI; "default": the
+    product's own table (lib.Trainer builds it with this host's F.affine_grid) — for trajectories generated ON this host's table."""
+    try:
+        return _run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj, grid)
+    finally:                                               # whatever happened: no debug taps, this host's own table (round-5 advisor finding)
+        ctx.set_debug_taps(False)
+        ctx._warp_S = None; ctx.ensure_warp_grid(512)
+
+
+def _run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj, grid):
     from oracle import cb_oracle as O
     from oracle.replay import make_batch
     c = fx["cfg"]
     m = SD14(O)
     shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
     W = cached_weights(O, shapes, c["weight_seed"])
+    ctx._warp_S = None                                     # the Trainer below installs this host's own table ...
     tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
-    # the warp's constant sampling grid as the host that generated the trajectory evaluated it (this box's torch rounds the K = 3 bmm of
-    # F.affine_grid differently in 14 % of the elements: oracle/replay.py::fixture_host_warp_grid); restored afterwards
-    from oracle.replay import fixture_host_warp_grid
-    ctx.set_warp_grid(fixture_host_warp_grid(512))
+    if grid == "fixture_host":
+        # ... replaced by the warp's constant sampling grid as the host that generated the trajectory evaluated it (this box's torch
+        # rounds the K = 3 bmm of F.affine_grid differently in 14 % of the elements: oracle/replay.py::fixture_host_warp_grid)
+        from oracle.replay import fixture_host_warp_grid
+        ctx.set_warp_grid(fixture_host_warp_grid(512))
     B, ids, rs = c["B"], c["ids"], c["row_stride"]
     cst = int(c.get("id_coef_stride", 1))          # slim multi-seed fixtures keep the learned rows of every cst-th step
     steps = min(steps, int(fx["steps"]))
     table = []
     traj = dict(coef=[], id_coef=[], gW_rows=[], loss=[])
-    ctx.set_debug_taps(True)
+    ncoef = int(fx["coef"].shape[0])                 # slim long-horizon fixtures keep the step coefficients of their first steps only (or none)
+    # Host reads are made only where the fixture has something to compare: the per-step coefficients are a debug tap (an eager step with a
+    # sync), the learned rows a get_state (sync); the loss goes to a device scalar in stream order and is read once at the end. On the
+    # slim three-draw fixtures (learned rows every 4th step, no step coefficients) three steps in four are enqueued back to back, as in
+    # production — deferred tail and all (round 6: 39 -> 30 s per 800-step run on the GPU box).
+    ctx.set_debug_taps(ncoef > 0)
     # the replay stream is generated on host cores (the photo-like faces: two float64 512^3 products per channel and step): a few worker
     # threads build the batches ahead of the GPU, same bytes in the same order
     from concurrent.futures import ThreadPoolExecutor
@@ -509,20 +568,24 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     ahead = {0: None}
     for s_ in range(1, min(steps, 24)):
         ahead[s_] = pool.submit(gen, s_)
+    losses_dev = []
     for s in range(steps):
         fut = ahead.pop(s)
         batch = first if s == 0 else fut.result()
         if s + 24 < steps:
             ahead[s + 24] = pool.submit(gen, s + 24)
+        if s == ncoef and ncoef > 0:
+            ctx.set_debug_taps(False)
         dev = {k: dv(v) for k, v in batch.items()}
         tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], c["lr"])
-        coef = ctx.tap("coef").reshape(2 * B, -1)
-        loss = float(tr.get_state("loss")[0])
-        idc = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)[ids]
-        row = dict(step=s + 1, loss_rel=abs(loss - float(fx["loss"][s])) / abs(float(fx["loss"][s])))
+        losses_dev.append(tr.loss_tensor(torch.device("cuda:0")))
+        row = dict(step=s + 1)
+        idc = coef = None
         if (s + 1) % cst == 0:
+            idc = tr.get_state("id_coefficients").reshape(m["max_ids"], -1)[ids]
             row["id_coef_l2"] = (idc - fx["id_coef"][(s + 1) // cst - 1]).norm(dim=1).max().item()
-        if s < fx["coef"].shape[0]:                   # slim long-horizon fixtures keep the step coefficients of their first steps only
+        if s < ncoef:
+            coef = ctx.tap("coef").reshape(2 * B, -1)
             row["coef_l2"] = (coef - fx["coef"][s]).norm(dim=1).max().item()
         if s + 1 in fx.get("gW_rows", {}):
             g = tr.get_state("mlp.grad_weight").reshape(-1, 512)[::rs]
@@ -530,13 +593,15 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
             row["grad_weight_rel_l2_sampled_rows"] = ((g - ref).norm() / ref.norm()).item()
             row["grad_weight_cosine_sampled_rows"] = (g.reshape(-1) @ ref.reshape(-1) / (g.norm() * ref.norm())).item()
         table.append(row)
-        if save_traj:
-            traj["coef"].append(coef.clone()); traj["id_coef"].append(idc.clone()); traj["loss"].append(loss)
+        if save_traj and coef is not None and idc is not None:
+            traj["coef"].append(coef.clone()); traj["id_coef"].append(idc.clone())
+    losses = torch.stack(losses_dev).cpu().tolist()
+    for row, loss in zip(table, losses):
+        row["loss_rel"] = abs(loss - float(fx["loss"][row["step"] - 1])) / abs(float(fx["loss"][row["step"] - 1]))
+    traj["loss"] = losses
     if save_traj:
         torch.save({k: (torch.stack(v) if k != "loss" else torch.tensor(v, dtype=torch.float64)) for k, v in traj.items() if len(v)}, save_traj)
     pool.shutdown(wait=True)
-    ctx.set_debug_taps(False)
-    ctx._warp_S = None; ctx.ensure_warp_grid(512)          # back to this host's own table
     if steps == int(fx["steps"]) and "W0_rows" in fx:
         w = tr.get_state("mlp.weight").reshape(-1, 512)[::rs]
         d_hip, d_ref = w - fx["W0_rows"], fx["Wm_rows"] - fx["W0_rows"]
@@ -560,11 +625,38 @@ def run_horizon(lib, ctx, fx, steps, tag, report, bars, save_traj=None):
     return summary
 
 
+def test_train_120_steps_sd14_default_table(cb, golden_dir):
+    """The full-horizon tests above hand the library the FIXTURE host's warp table through the ABI. This one runs the PRODUCT'S DEFAULT:
+    lib.Trainer builds the table with this host's own F.affine_grid (lib.Context.ensure_warp_grid) and nothing is handed in. The oracle
+    trajectory tests/golden/horizon_sd14_b1_boxgrid.pt (oracle/gen_horizon.py fp32boxgrid: config 2's default stream, 120 steps) was
+    generated on exactly that table — the GPU box's EPYC evaluation, captured there (tests/golden/warp_grid_gpubox_512.npz,
+    tools/probes/capture_host_affine_grid.py; 14 % of the elements one ulp off the fixture host's). A host whose F.affine_grid gives
+    yet another table cannot run the comparison and says so. Bars: north_star's 1e-3 on the learned coefficients at every step and the
+    implementation's own invariant — per-step coefficients within 2e-5 — over all 120 steps."""
+    import hashlib
+    import numpy as np
+    lib, ctx = cb
+    path = os.path.join(golden_dir, "horizon_sd14_b1_boxgrid.pt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/horizon_sd14_b1_boxgrid.pt not generated (python oracle/gen_horizon.py fp32boxgrid)")
+    z = np.load(os.path.join(golden_dir, "warp_grid_gpubox_512.npz"))
+    M = torch.tensor([lib.WARP_TRANS_MATRIX], dtype=torch.float32)
+    mine = torch.nn.functional.affine_grid(M, size=[1, 3, 512, 512], align_corners=True)[0].contiguous().numpy()
+    if hashlib.sha1(mine.tobytes()).hexdigest()[:12] != str(z["sha1_host"]):
+        pytest.skip(f"this host's F.affine_grid table ({hashlib.sha1(mine.tobytes()).hexdigest()[:12]}) is not the one the trajectory was generated on "
+                    f"({z['sha1_host']}, {z['cpu']})")
+    fx = load(golden_dir, "horizon_sd14_b1_boxgrid.pt")
+    assert fx["cfg"].get("grid_npz") == "warp_grid_gpubox_512.npz" and int(fx["steps"]) >= 100
+    s = run_horizon(lib, ctx, fx, int(fx["steps"]), "horizon_sd14_b1_default_table", REPORT,
+                    dict(id_coef_l2_max=1e-3, coef_l2_max=2e-5, loss_rel_max=2e-4), grid="default")
+    assert s["coef_l2_steps"] == s["steps"] >= 100
+
+
 def test_train_800_steps_sd14_horizon(cb, golden_dir):
     """BASELINE config 2 at FULL SIZE over its own horizon: 800 optimiser steps (aigc_id.yaml:135) of SD v1-4 512x512 bs=1 on the HIP
     path against the oracle trajectory committed in tests/golden/horizon_sd14_b1_800.pt (oracle/gen_horizon.py fp32long, 3.6 h of host
-    time; its first 100 steps are horizon_sd14_b1.pt, which also holds the sampled gradient rows, and its first ten are the ones
-    test_train_10_steps_sd14_drift recomputes live) — the DEFAULT replay stream, whose face crops are white noise.
+    time; its first 100 steps are horizon_sd14_b1.pt, which also holds the sampled gradient rows, and its first four are the ones
+    test_train_4_steps_sd14_live_oracle recomputes live) — the DEFAULT replay stream, whose face crops are white noise.
     Table: gpurun_out/horizon_sd14_b1_800.json (committed: profiles/r05_sd14_horizon800.json).
 
     north_star's bar — learned coefficients (EMA dictionary, embedding_manager.py:484-489) within 1e-3 L2 of the CPU path at fixed seed —
@@ -872,7 +964,7 @@ def test_sampler_sd14_vs_oracle(cb, n):
     Wd = O.init_weights(O.vae_decoder_param_shapes(O.VAE_SD14), seed=8)
     d = lib.VAEDecoder(ctx, lib.WeightTable(Wd), lib.vae_cfg(**O.VAE_SD14))
     torch.set_num_threads(min(64, os.cpu_count() or 1))
-    pick = sorted({0, n // 2, n - 1})            # the oracle decodes a subset (first / middle / last image of the chunked decode)
+    pick = sorted({0, n - 1})                    # the oracle decodes a subset (first / last image of the chunked decode)
     with torch.no_grad():
         ref, _ = O.ddim_sample(W, cfg, x_T, c, uc, s, scale=10.0)
         ref_img = O.decode_first_stage(Wd, O.VAE_SD14, ref[pick], 0.18215)
@@ -1251,7 +1343,7 @@ def test_two_person_prompt_conditioning_vs_oracle(cb):
 
 
 def test_run_config5_tool_first_identity_vs_oracle(cb, tmp_path):
-    """tools/run_config5.py is the config-5 driver whose numbers DESIGN quotes: run it for real (SD v1-4 size, one identity, three
+    """tools/run_config5.py is the config-5 driver whose numbers DESIGN quotes: run it for real (SD v1-4 size, one identity, two
     bs=2 training steps, a 2-step DDIM with 2 samples, decode) and replay the training of its first identity on the CPU oracle
     from the replay description it dumps — the learned coefficient row must be inside north_star's 1e-3 L2 bar, the images finite
     and non-degenerate, the JSON line complete"""
@@ -1261,7 +1353,7 @@ def test_run_config5_tool_first_identity_vs_oracle(cb, tmp_path):
     from oracle import cb_oracle as O
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = tmp_path / "first.pt"
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config5.py"), "--identities", "1", "--train-steps", "3", "--ddim-steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config5.py"), "--identities", "1", "--train-steps", "2", "--ddim-steps", "2",
                         "--n-samples", "2", "--dump-first", str(dump)], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])

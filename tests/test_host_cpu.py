@@ -569,23 +569,25 @@ def test_bench_uses_committed_profiles_only_when_their_stamp_is_this_tree(tmp_pa
     body = "name,calls,total_ms,ms_per_step,avg_us,min_us,max_us,pct\n" \
            '"gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>",378,79.8,8.867,211.1,72.2,736.1,20.8\n"splitk_reduce_kernel<float>",3924,22.5,2.509,5.75,2.8,14.6,5.9\n'
     good = f"# stamp src_sha={st['src_sha']} plan_table_sha={st['plan_table_sha']} nsteps=9\n# rocprofv3\n" + body
-    (tmp_path / "profiles" / "r05z_bench_kernel_stats.csv").write_text(good)
+    (tmp_path / "profiles" / "r06z_bench_kernel_stats.csv").write_text(good)
     src, stale, per, base = bench.rocprof_trace(False)
-    assert src == "r05z_bench_kernel_stats.csv" and stale is False and abs(base["splitk_reduce_kernel"] - 2.509) < 1e-9
+    assert src == "r06z_bench_kernel_stats.csv" and stale is False and abs(base["splitk_reduce_kernel"] - 2.509) < 1e-9
     assert per["gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>"][0] == 42.0           # launches per step from calls / nsteps
     # one profiler label = the scalar-offset (FAST) and the per-lane form of the kernel; the 80-column tiles: <BM, A kind, stages, FAST>
     assert bench.trace_symbols("gemm_glds_kernel<float,128,128,CONVF>") == ["gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>",
                                                                             "gemm_glds_kernel<float, 128, 128, 2, 128, 2, false>"]
     assert bench.trace_symbols("gemm_glds80_kernel<float,32,80,ROW>")[0] == "gemm_glds80_kernel<32, 0, 2, true>"
-    (tmp_path / "profiles" / "r05z_bench_kernel_stats.csv").write_text(good.replace(st["src_sha"], "0" * 16))
+    assert bench.trace_symbols("gemm_bf16_p8_kernel<bf16,256,256,CONVF>") == ["gemm_bf16_p8_kernel<2, 2, 0>"]      # <A kind, waves along M, ablation>
+    assert bench.trace_symbols("gemm_bf16_p8_kernel<bf16,512,128,ROW>") == ["gemm_bf16_p8_kernel<0, 4, 0>"]
+    (tmp_path / "profiles" / "r06z_bench_kernel_stats.csv").write_text(good.replace(st["src_sha"], "0" * 16))
     src, stale, per, base = bench.rocprof_trace(False)
     assert stale is True and per == {} and base == {}
     pmc = {"stamp": st, "per_symbol": {"gemm_glds_kernel<float, 128, 128, 2, 128, 2, true>": {"launches": 210, "fetch_bytes_per_launch": 90e6, "write_bytes_per_launch": 24e6}}}
-    (tmp_path / "profiles" / "r05z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    (tmp_path / "profiles" / "r06z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
     t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
     assert t == 204000000 and det["stale"] is False and det["fetch_size_bytes_per_launch_raw"] == 90000000      # 2 x FETCH_SIZE + WRITE_SIZE
     pmc["stamp"] = {"src_sha": "x", "plan_table_sha": "y"}
-    (tmp_path / "profiles" / "r05z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
+    (tmp_path / "profiles" / "r06z_pmc_hbm_traffic.json").write_text(json.dumps(pmc))
     t, det = bench.pmc_traffic("gemm_glds_kernel<float,128,128,CONVF>")
     assert t is None and det["stale"] is True
 
@@ -764,7 +766,7 @@ def test_plan_table_is_well_formed(tmp_path):
     as "<key> <BM> <BN> <split>", keys are unique, tiles are ones the kernels implement (the 8-wave tiles — 256x128 and the
     phase-pipelined 256x256 / 512x128 — only for the bf16 64-element k-tile, the latter two only for K % 64 == 0 ROW / plain-conv
     problems; the 80-column tiles only for fp32 ROW / plain-conv problems without a batch), and the generator reproduces the committed
-    table from the committed records (round 6's re-measurement of every kernel + the records carried over from round 2)"""
+    table from the committed records (round 4's fp32 records, round 6's bf16 re-measurement, the records carried over from round 2)"""
     import subprocess
     import sys
     inc = os.path.join(ROOT, "celebbasis_amd", "csrc", "cb_plan_table.inc")
@@ -788,7 +790,9 @@ def test_plan_table_is_well_formed(tmp_path):
         assert -(-int(f[5]) // int(f[0])) >= sp           # never more splits than k-tiles
     before = open(inc).read()
     try:
-        recs = [os.path.join(ROOT, "profiles", n) for n in ("r06_autotune.txt", "r04_autotune_carried_from_r02.txt")]
+        # fp32 plans: round 4's records (unchanged summation orders: the 800-step trajectories are the ones validated in round 5);
+        # bf16 plans: round 6's re-measurement with the phase-pipelined tiles among the candidates
+        recs = [os.path.join(ROOT, "profiles", n) for n in ("r04_autotune.txt:f32", "r04_autotune_carried_from_r02.txt", "r06_autotune.txt:bf16")]
         out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_plan_table.py")] + recs, capture_output=True, text=True, check=True).stdout
         assert "shapes measured" in out and open(inc).read() == before, "cb_plan_table.inc is not what the generator makes of the committed records"
     finally:
