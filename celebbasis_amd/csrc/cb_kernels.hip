@@ -288,7 +288,8 @@ void k_nhwc_to_nchw(const Launch& L, DType sdt, float* dst, const void* src, int
 }
 
 // y = x*scale[c] + shift[c], then optional PReLU(slope[c]) (iresnet.py:44-63: eval BatchNorm + PReLU)
-__global__ void channel_affine_kernel(float* __restrict__ y, const float* __restrict__ x, const float* __restrict__ scale,
+// (y and x may be the SAME buffer — the de-fused PReLU of cb_gemm.hip runs in place — so neither carries __restrict__)
+__global__ void channel_affine_kernel(float* y, const float* x, const float* __restrict__ scale,
                                       const float* __restrict__ shift, const float* __restrict__ prelu, long rows, int C) {
     long total = rows * C;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {

@@ -58,7 +58,9 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # table with the host's own F.affine_grid) uses on that box: tests/test_gpu_models.py::test_train_120_steps_sd14_default_table
             fp32boxgrid=dict(B=1, steps=120, lr=5e-3, seed=8, out="horizon_sd14_b1_boxgrid.pt", grad_steps=(), slim=True, coef_steps=120,
                              grid_npz="warp_grid_gpubox_512.npz"),
-            bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)))
+            bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)),
+            # round 6: config 3's stream continued to 100 steps (its first 20 are the `bf16` fixture's): a horizon beyond 20 for the bf16 path
+            bf16long=dict(B=4, steps=100, lr=2e-2, seed=5, out="horizon_sd14_b4_100.pt", grad_steps=(), slim=True, coef_steps=100))
 ROW_STRIDE = 16
 
 
