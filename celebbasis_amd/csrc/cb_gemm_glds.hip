@@ -537,25 +537,36 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
 
 #pragma unroll
     for (int s = 0; s < STAGES - 1; ++s)
+        if (!FAST || s < ktg) {                               // (FAST pieces carry no k limit: a tile past the group's end is never issued)
 #pragma unroll
-        for (int pc = 0; pc < NA + NB; ++pc) piece(pc, s, lds80 + s * Q::STAGE);
+            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, s, lds80 + s * Q::STAGE);
+        }
 
     const int g = wave / WMV, wm = wave - g * WMV;
     const int lg = lane >> 4, lr = lane & 15, sw = lr >> 1;
     const int arow_off = (g * BM + wm * 16 + lr) * 128, brow_off = Q::A_BUF + (g * 80 + lr) * 128;
-    static_assert(STAGES == 2, "two ring slots: the slot of a k-tile is its parity");
-    // one k-tile; `slot` = kt & 1 is a compile-time constant at both call sites (the loop runs in pairs), so every LDS address of the tile
-    // is an immediate offset: no vector adds for the fragment reads, no scalar ring bookkeeping
-    auto tile = [&](int kt, int slot) {
+    static_assert(STAGES == 2 || STAGES == 3, "ring slots are compile-time constants: the k loop is unrolled by STAGES");
+    // one k-tile; `slot` = kt % STAGES is a compile-time constant at every call site (the loop runs in groups of STAGES), so every LDS
+    // address of the tile is an immediate offset: no vector adds for the fragment reads, no scalar ring bookkeeping.
+    // STAGES = 3 puts TWO k-tiles in flight per CU (round-6 experiment for the launches with at most one block per CU, measured flat:
+    // see launch_n80_go).
+    auto tile = [&](int kt, auto slotc) {
+        constexpr int slot = decltype(slotc)::value;
+        // tile kt has landed when all but the newest STAGES - 2 tiles are complete; the tiles past the group's end are not issued in the
+        // FAST form, so near the end fewer are outstanding and the wait is a full drain (wave-uniform branch)
         if (p.safe) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); }
-        else { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+        else {
+            if (STAGES == 3 && (!FAST || kt + 1 < ktg)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NA + NB) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+        }
         const char* st = lds80 + slot * Q::STAGE;
         // the next tile's pieces go out in one clump: spreading them between the MFMAs was measured and changes nothing (profiles/README.md,
-        // round 4). FAST has no per-lane k limit: the tile past the group's end is simply not issued (the wait above is vmcnt(0), nothing
-        // counts on a constant number of outstanding pieces)
-        if (!FAST || kt + 1 < ktg) {
+        // round 4). FAST has no per-lane k limit: the tile past the group's end is simply not issued
+        if (!FAST || kt + STAGES - 1 < ktg) {
+            constexpr int nslot = (slot + STAGES - 1) % STAGES;           // the slot read in the previous iteration: every wave is past its reads
 #pragma unroll
-            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + 1, lds80 + (slot ^ 1) * Q::STAGE);
+            for (int pc = 0; pc < NA + NB; ++pc) piece(pc, kt + STAGES - 1, lds80 + nslot * Q::STAGE);
         }
         // all twelve fragment reads of the k-tile first (chunk 4s + lg is the lane's k-slot quadruple of half tile s), then the 40 MFMAs:
         // with one wave per SIMD nobody else covers the LDS latency, so it is paid once per k-tile instead of once per half tile
@@ -575,8 +586,16 @@ __device__ __forceinline__ void gemm_glds80_body(const KArgs& p, char* lds80) {
         }
     };
     int kt = 0;
-    for (; kt + 1 < ktg; kt += 2) { tile(kt, 0); tile(kt + 1, 1); }
-    if (kt < ktg) tile(kt, 0);
+    if constexpr (STAGES == 2) {
+        for (; kt + 1 < ktg; kt += 2) { tile(kt, std::integral_constant<int, 0>{}); tile(kt + 1, std::integral_constant<int, 1>{}); }
+        if (kt < ktg) tile(kt, std::integral_constant<int, 0>{});
+    } else {
+        for (; kt + 2 < ktg; kt += 3) {
+            tile(kt, std::integral_constant<int, 0>{}); tile(kt + 1, std::integral_constant<int, 1>{}); tile(kt + 2, std::integral_constant<int, 2>{});
+        }
+        if (kt < ktg) tile(kt, std::integral_constant<int, 0>{});
+        if (kt + 1 < ktg) tile(kt + 1, std::integral_constant<int, 1>{});
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     // ---- the KW partial strips meet in LDS; D layout of 16x16x4: lane holds column lr, rows 4 * lg + r
@@ -748,7 +767,11 @@ size_t gemm_f32_glds_ws_bytes(const GemmArgs& a) {
     Plan pl = make_plan(a, f32_glds_bk(), f32_glds_speed(), n80_ok(a));
     return pl.splitk <= 1 ? 0 : (size_t)pl.splitk * a.batch * (size_t)a.M * a.N * sizeof(float);
 }
-// the 80-column tiles: dynamic LDS (40 / 56 / 96 KB for BM = 64 / 32 / 16), two ring stages (three were measured slower: fewer blocks per CU)
+// the 80-column tiles: dynamic LDS (36 / 56 / 96 KB for BM = 64 / 32 / 16), two ring stages. Three stages were measured twice and are not
+// instantiated: round 4 on the 4096-row conv (two blocks per CU become one: 87 -> 106 us), round 6 as a per-launch policy — three stages
+// exactly where the grid has at most 256 blocks, i.e. for the M <= 256 weight-streaming problems, whose CUs then hold two k-tiles in
+// flight instead of one: 36.40 - 36.45 ms per fp32 step against 36.39 - 36.45 (three stages everywhere: 37.6; profiles/README.md). Those
+// launches are not waiting for bytes. The kernel body keeps the general ring (STAGES is a template parameter, slots are compile-time).
 template <int BM, int AK, bool FAST>
 static void launch_n80_go(dim3 grid, hipStream_t s, const KArgs& ka) {
     constexpr int LDS = G80<BM, 2>::LDS;

@@ -415,8 +415,8 @@ __device__ __forceinline__ void gn_final_one(int w, int lane, float* __restrict_
     for (int c = g * cpg + lane; c < (g + 1) * cpg; c += 64)
         *reinterpret_cast<float4*>(chn + ((long)n * C + c) * 4) = make_float4(mean, rstd, gamma[c], beta[c]);
 }
-// cnt != nullptr: the statistics pass finishes itself — the launch's last-arriving block (grid_arrive_last) reduces all chunk partials
-// and writes stats + the per-channel constants: no gn_final launch between the two passes (55 + 30 launches of the fp32 step)
+// cnt != nullptr (experiment, CB_GN_INLAUNCH=1): the statistics pass finishes itself — the launch's last-arriving block
+// (grid_arrive_last) reduces all chunk partials and writes stats + the per-channel constants: no gn_final launch between the two passes
 template <typename T>
 __global__ __launch_bounds__(256) void gn_partial_kernel(float* __restrict__ part, const T* __restrict__ x, int HW, int C,
                                                           int G, int nchunk, int rpb, int* cnt, float* __restrict__ stats,
@@ -663,8 +663,10 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
     float* part = ws;
     float* chn = ws + (size_t)N * nchunk * G * 2;
     const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
-    // chip-wide form: the statistics launch finishes itself in its last-arriving block (CB_GN_INLAUNCH=0: separate gn_final launch)
-    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return !(e && e[0] == '0'); }();
+    // chip-wide form, experiment (CB_GN_INLAUNCH=1): the statistics launch finishes itself in its last-arriving block instead of a
+    // gn_final launch. Measured on the config-2 step and NOT adopted (36.75 against 36.09 ms, profiles/README.md round 6): one block
+    // reducing N x 32 groups x up to 1024 chunk partials is a longer serial tail than the 8-block gn_final launch plus its boundary.
+    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return e && e[0] == '1'; }();
     int* const cnt = (!fused && inl && L.cnt) ? L.cnt->take(1) : nullptr;
     (void)L.count(fused ? 1 : (cnt ? 2 : 3));
     if (L.dry) return;
@@ -814,7 +816,7 @@ void k_groupnorm_bwd(const Launch& L, DType dt, void* dx, const void* x, const v
     float* chn = ws + (size_t)N * nchunk * G * 2;
     float* gs = chn + (size_t)N * C * 4;
     const bool fused = gn_use_fused(HW, C, G, dt_size(dt));
-    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return !(e && e[0] == '0'); }();
+    static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return e && e[0] == '1'; }();       // experiment, see k_groupnorm_fwd
     int* const cnt = (!fused && inl && L.cnt) ? L.cnt->take(1) : nullptr;
     (void)L.count(fused ? 1 : (chn_valid ? 3 : 4) - (cnt ? 1 : 0));
     if (L.dry) return;

@@ -948,7 +948,7 @@ def test_host_sampler_mini_vs_oracle(cb):
 
 @pytest.mark.parametrize("n", [1, 8])
 def test_sampler_sd14_vs_oracle(cb, n):
-    """SD v1-4 sizes: guided DDIM steps (batch-2n UNet passes at 64x64; two steps at n = 1, one at n = 8) + decode to 512x512 against the
+    """SD v1-4 sizes: a guided DDIM step (a batch-2n UNet pass at 64x64) + decode to 512x512 against the
     CPU oracle; n = 8 is the reference's n_samples (stable_txt2img.py:108, config 5): a batch-16 UNet pass and the chunked 8-image decode"""
     from oracle import cb_oracle as O
     lib, ctx = cb
@@ -957,7 +957,7 @@ def test_sampler_sd14_vs_oracle(cb, n):
     u = lib.UNet(ctx, lib.WeightTable(W), lib.unet_cfg(**cfg))
     g = torch.Generator().manual_seed(6)
     x_T = torch.randn(n, 4, 64, 64, generator=g); c = torch.randn(n, 77, 768, generator=g); uc = torch.randn(n, 77, 768, generator=g)
-    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 2 if n == 1 else 1, 0.0)     # n = 8: one step keeps the CPU oracle's share of the suite short
+    s = O.ddim_schedule(O.make_schedule()["alphas_cumprod"], 1, 0.0)     # one step keeps the CPU oracle's share of the suite short (the multi-step loop: ddim_mini)
     x, _ = u.ddim_sample(dv(x_T), dv(c), dv(uc), s["timesteps"], s["alphas"], s["alphas_prev"], s["sigmas"], s["sqrt_one_minus_alphas"], scale=10.0)
     ctx.sync()
     u.close()
@@ -1343,8 +1343,8 @@ def test_two_person_prompt_conditioning_vs_oracle(cb):
 
 
 def test_run_config5_tool_first_identity_vs_oracle(cb, tmp_path):
-    """tools/run_config5.py is the config-5 driver whose numbers DESIGN quotes: run it for real (SD v1-4 size, one identity, two
-    bs=2 training steps, a 2-step DDIM with 2 samples, decode) and replay the training of its first identity on the CPU oracle
+    """tools/run_config5.py is the config-5 driver whose numbers DESIGN quotes: run it for real (SD v1-4 size, one identity, one
+    bs=2 training step, a 2-step DDIM with 2 samples, decode) and replay the training of its first identity on the CPU oracle
     from the replay description it dumps — the learned coefficient row must be inside north_star's 1e-3 L2 bar, the images finite
     and non-degenerate, the JSON line complete"""
     import subprocess
@@ -1353,7 +1353,7 @@ def test_run_config5_tool_first_identity_vs_oracle(cb, tmp_path):
     from oracle import cb_oracle as O
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dump = tmp_path / "first.pt"
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config5.py"), "--identities", "1", "--train-steps", "2", "--ddim-steps", "2",
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "run_config5.py"), "--identities", "1", "--train-steps", "1", "--ddim-steps", "2",
                         "--n-samples", "2", "--dump-first", str(dump)], capture_output=True, text=True, timeout=900, cwd=root)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
