@@ -668,30 +668,46 @@ void k_groupnorm_fwd(const Launch& L, DType dt, void* y, const void* x, const fl
     // reducing N x 32 groups x up to 1024 chunk partials is a longer serial tail than the 8-block gn_final launch plus its boundary.
     static const bool inl = [] { const char* e = getenv("CB_GN_INLAUNCH"); return e && e[0] == '1'; }();
     int* const cnt = (!fused && inl && L.cnt) ? L.cnt->take(1) : nullptr;
-    (void)L.count(fused ? 1 : (cnt ? 2 : 3));
+    const double esz = (double)dt_size(dt);
+    // A tensor beyond the 256 MiB Infinity Cache (config 3's VAE levels at bs = 4: 268 MB in bf16) is normalised in image groups of at
+    // most CB_GN_SPLIT_MB (128) MB: the statistics pass pulls a group through the cache and the apply pass that follows finds it there
+    // — 1R + 1W of HBM traffic instead of 2R + 1W. Same kernels on the same per-image data: bitwise the one-shot result.
+    static const long split_mb = [] { const char* e = getenv("CB_GN_SPLIT_MB"); return e ? atol(e) : 128L; }();
+    const double img_mb = (double)HW * C * esz / 1e6;
+    int per = N;
+    if (!fused && split_mb > 0 && N > 1 && img_mb * N > 2.0 * split_mb) per = std::max(1, (int)(split_mb / img_mb));
+    (void)L.count(fused ? 1 : (cnt ? 2 : 3) * (long)cdiv(N, per));
     if (L.dry) return;
     // records are split by size class: tensors beyond the 256 MB Infinity Cache really stream from HBM, the UNet-sized ones are
     // launch-latency bound and would otherwise drown the achieved-bandwidth figure
-    const double esz = (double)dt_size(dt);
     const bool big = (double)N * HW * C * esz >= 64e6;
     ProfRec rec; const bool prof = L.prof && L.prof->begin(&rec, silu ? (big ? "groupnorm_silu_fwd[>=64MB]" : "groupnorm_silu_fwd[<64MB]")
                                                                    : (big ? "groupnorm_fwd[>=64MB]" : "groupnorm_fwd[<64MB]"),
                                                              0.0, 3.0 * N * HW * (double)C * esz, L.stream);
-    long nquads = (long)N * HW * (C / 4);
     if (fused) {
         CB_DT_SWITCH(dt, T, {
             hipLaunchKernelGGL((gn_fused_fwd_kernel<T>), dim3(N * G), dim3(GNF_THREADS), 0, L.stream, (T*)y, (const T*)x, gamma, beta, stats, chn, HW, C, G, eps, silu);
         });
-    } else
-    CB_DT_SWITCH(dt, T, {
-        hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(N * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part, (const T*)x, HW, C, G, nchunk, rpb,
-                           cnt, stats, chn, gamma, beta, N, eps);
-        if (!cnt) hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(N * G, 4)), dim3(256), 0, L.stream, stats, chn, part, (const T*)x, gamma, beta, N, HW, C, G, nchunk, eps);
-        if (GnVec<T>::VQ == 2 && C % 8 == 0)
-            hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
-        else
-            hipLaunchKernelGGL((gn_apply_kernel<T, 1>), gn_apply_grid(nquads, C / 4), dim3(256), 0, L.stream, (T*)y, (const T*)x, chn, nquads, HW, C, silu);
-    });
+    } else {
+        for (int n0 = 0; n0 < N; n0 += per) {                 // image groups (one group unless the tensor exceeds the Infinity Cache, above)
+            const int Ng = std::min(per, N - n0);
+            const long eoff = (long)n0 * HW * C;
+            const long nquads = (long)Ng * HW * (C / 4);
+            float* part_g = part + (size_t)n0 * nchunk * G * 2;
+            float* stats_g = stats + (size_t)n0 * G * 2;
+            float* chn_g = chn + (size_t)n0 * C * 4;
+            CB_DT_SWITCH(dt, T, {
+                const T* xg = (const T*)x + eoff; T* yg = (T*)y + eoff;
+                hipLaunchKernelGGL((gn_partial_kernel<T>), dim3(Ng * nchunk), dim3(256), gn_lds_bytes(C), L.stream, part_g, xg, HW, C, G, nchunk, rpb,
+                                   cnt, stats_g, chn_g, gamma, beta, Ng, eps);
+                if (!cnt) hipLaunchKernelGGL((gn_final_kernel<T>), dim3(cdiv(Ng * G, 4)), dim3(256), 0, L.stream, stats_g, chn_g, part_g, xg, gamma, beta, Ng, HW, C, G, nchunk, eps);
+                if (GnVec<T>::VQ == 2 && C % 8 == 0)
+                    hipLaunchKernelGGL((gn_apply_kernel<T, GnVec<T>::VQ>), gn_apply_grid(nquads / 2, C / 8), dim3(256), 0, L.stream, yg, xg, chn_g, nquads, HW, C, silu);
+                else
+                    hipLaunchKernelGGL((gn_apply_kernel<T, 1>), gn_apply_grid(nquads, C / 4), dim3(256), 0, L.stream, yg, xg, chn_g, nquads, HW, C, silu);
+            });
+        }
+    }
     if (prof) L.prof->end(&rec, L.stream);
     CB_HIP(hipGetLastError());
 }
