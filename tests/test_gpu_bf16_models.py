@@ -191,6 +191,29 @@ def test_train_step_sd14_bf16_bs2_vs_oracle(cbf):
     run_steps_bf16(lib, ctx, full, B=2, steps=1, lr=1e-2, seed=5, taps=True)
 
 
+def test_train_100_steps_sd14_bf16_bs4_horizon(cbf, golden_dir):
+    """config 3 beyond 20 steps (round-5 verdict: "config 3 has no horizon beyond 20"): the same stream continued to 100 optimiser steps
+    against tests/golden/horizon_sd14_b4_100.pt (oracle/gen_horizon.py bf16long: fp32 oracle, bs=4, lr 2e-2; its first 20 steps are the
+    20-step fixture's). The table (gpurun_out/horizon_sd14_b4_100_bf16.json) shows how the bf16 path's distance to the fp32 oracle
+    grows with the step count; the asserted envelope is the measured one with margin, north_star's 1e-3 is reported, not met.
+    A fixture still being generated is compared over the steps it holds (>= 40)."""
+    lib, ctx = cbf
+    path = os.path.join(golden_dir, "horizon_sd14_b4_100.pt")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/horizon_sd14_b4_100.pt not generated (python oracle/gen_horizon.py bf16long)")
+    fx = dict(load(golden_dir, "horizon_sd14_b4_100.pt"))
+    n = int(fx["steps"])
+    if n < 40:
+        pytest.skip(f"horizon_sd14_b4_100.pt holds {n} steps so far")
+    fx20 = load(golden_dir, "horizon_sd14_b4.pt")
+    assert torch.equal(fx["coef"][:20], fx20["coef"][:20]), "the 100-step trajectory must start with the 20-step fixture"
+    fx["cfg"] = dict(fx20["cfg"], **fx["cfg"])
+    s = run_horizon(lib, ctx, fx, n, "horizon_sd14_b4_100_bf16", REPORT, dict(id_coef_l2_max=1.5e-2, loss_rel_max=2e-2))
+    tab = REPORT["horizon_sd14_b4_100_bf16.table"]
+    REPORT["bf16.sd14.horizon100.learned_coefficient_l2_at"] = {str(k): tab[k - 1]["id_coef_l2"] for k in (1, 10, 20, 40, 60, 80, 100) if k <= n}
+    REPORT["bf16.sd14.horizon100.within_north_star_1e-3"] = s["id_coef_l2_max"] <= 1e-3
+
+
 def test_train_20_steps_sd14_bf16_bs4_horizon(cbf, golden_dir):
     """BASELINE config 3 over a horizon AT FULL SIZE: 20 optimiser steps of SD v1-4 512x512 bs=4 (lr 2e-2) with the bf16 UNet / VAE
     against the fp32 oracle trajectory committed in tests/golden/horizon_sd14_b4.pt. The drift table (gpurun_out/horizon_sd14_b4_bf16.json,
