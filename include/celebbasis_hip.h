@@ -68,7 +68,8 @@ int cb_ctx_dtype(cb_ctx* ctx, int* dtype);
 /* The library-owned side stream (hipStream_t) on which cb_trainer_step runs the identity branch — it reads the caller's `faces`,
  * `ids` and `tokens` buffers there, forked from AND JOINED BACK INTO the context stream with events inside the call: when the call
  * returns every read of CALLER memory is ordered before later context-stream work, so no record_stream is needed for it (exposed for
- * profilers). The step's deferred tail (cb_trainer_set_tail_overlap) also runs here; it touches library-owned memory only. */
+ * profilers). The step's deferred tail (cb_trainer_set_tail_overlap) runs on a third library stream; it touches library-owned
+ * memory only. */
 int cb_ctx_aux_stream(cb_ctx* ctx, void** hip_stream);
 int cb_ctx_destroy(cb_ctx* ctx);
 int cb_ctx_sync(cb_ctx* ctx);
@@ -303,12 +304,19 @@ typedef struct {
 } cb_batch;
 int cb_trainer_step(cb_trainer* t, const cb_batch* batch, float lr);
 /* Whole-step HIP-graph replay. From the second step at a batch size on, cb_trainer_step copies the batch into
- * trainer-owned staging buffers and replays ONE captured graph of the step's ~1 650 launches (both streams) instead of enqueuing them
- * one by one; a graph is captured per (B, lr) and kept (8 most recent). Same kernels in the same order on the same addresses: results
- * are bitwise those of the eager path. OPT-IN (this call, or environment CB_STEP_GRAPH=1): on MI355X the step is GPU-bound — the
- * replayed step measures the same 37 ms as the eager one (what the graph saves is host CPU time) and the runtime's graph-internal
- * streams take the hardware queues cb_trainer_prefetch's overlap needs. With replay on, the eager path still serves the first step at
- * a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from cb_trainer_prefetch. */
+ * trainer-owned staging buffers and replays ONE captured graph of the step's ~1 400 launches (both streams) instead of enqueuing them
+ * one by one; ONE graph per batch size is kept (8 most recent): the learning rate is read from a device scalar that a 4-byte memset
+ * node writes ahead of every replay, so a schedule (warm-up, decay) replays the same graph. Same kernels in the same order on the same
+ * addresses: results are bitwise those of the eager path. A graph bakes in the step arena's addresses, the context's warp-grid table
+ * pointer (cb_ctx_set_warp_grid) and the GEMM plans / pipeline variants in force (cb_debug_*): each carries a generation stamp, and
+ * a graph captured under other stamps is dropped and re-captured at its next use. If the runtime refuses a capture or an
+ * instantiation, the step runs eagerly and the trainer stays on eager launches. OPT-IN (this call, or environment CB_STEP_GRAPH=1):
+ * on MI355X the step is GPU-bound — the replayed step measures the eager step's time within 0.3 % when the graph is captured in a
+ * process that has created no other streams / contexts, and 2.2x that (83 ms against 37) when it is captured after a prefetch stream
+ * or a second context exist: the runtime's graph-internal streams then take the hardware queues the step's own side streams use. That
+ * dependence on process history is the runtime's, not this library's to fix; it is why replay is not the default. With replay on, the
+ * eager path still serves the first step at a batch size, a step under cb_ctx_profile_begin or debug taps, and a batch consumed from
+ * cb_trainer_prefetch. */
 int cb_trainer_set_graph_replay(cb_trainer* t, int enable);
 /* Deferred step tail (default ON; environment CB_TAIL_OVERLAP=0 or enable = 0 turns it off). Everything of a step after the UNet's
  * input gradient has reached the conditioning — the CLIP text transformer's input-gradient chain (~190 launches of 77-row problems),
