@@ -72,8 +72,9 @@ struct Ctx {
     bool tail_pending = false; const void* tail_owner = nullptr; int tail_layout = 0;    // layout: arena layout class of the step that left the tail
     void join_tail() {
         if (!tail_pending) return;
+        // (`device`, not `dry`: plan_and_run flips `dry` for its sizing pass on a REAL context, and that pass must not swallow the join)
+        if (device >= 0 && ev_tail) CB_HIP(hipStreamWaitEvent(stream, ev_tail, 0));
         tail_pending = false;
-        if (!dry && ev_tail) CB_HIP(hipStreamWaitEvent(stream, ev_tail, 0));
     }
     bool dry = true;
     Arena arena;                 // per-step activations

@@ -471,6 +471,43 @@ def test_deferred_tail_is_bitwise_the_joined_step_mini(cb):
         assert torch.equal(a[k], b[k]), f"deferred tail changed {k}: max diff {(a[k] - b[k]).abs().max().item():.3e}"
 
 
+def test_deferred_tail_joins_before_other_users_of_the_context(cb):
+    """Whoever else touches the context while a step's tail is still in flight on the library's third stream must wait for it first
+    (Ctx::join_tail in Ctx::launch): here a UNet forward through the trainer's shared handle right after every step — it rewinds the
+    step arena and writes over the very activations the CLIP gradient chain of that tail still reads (plan_and_run: the join has to
+    survive its dry sizing pass, which a first version swallowed). Five such steps must end BITWISE where five steps with a full
+    device synchronisation before each forward end."""
+    from oracle import cb_oracle as O
+    lib, ctx = cb
+    m = MINI
+    shapes = O.trainer_param_shapes(m["unet"], m["vae"], m["clip"], m["fr"], es=m["es"], inner=m["inner"], max_ids=m["max_ids"])
+    W = cached_weights(O, shapes, 6)
+    lat = m["image"] // (2 ** (len(m["vae"]["ch_mult"]) - 1))
+    ctx.set_debug_taps(False)
+    g = torch.Generator().manual_seed(11)
+    xs = torch.randn(1, m["unet"]["in_channels"], lat, lat, generator=g); cs = torch.randn(1, 77, m["unet"]["context_dim"], generator=g)
+    ts = torch.tensor([17], dtype=torch.int64)
+    ends = []
+    for synced in (False, True):
+        tr = lib.Trainer(ctx, lib.WeightTable(W), trainer_cfg(lib, m))
+        u = tr.unet()
+        outs = []
+        for s in range(5):
+            dev = {k: dv(v) for k, v in make_batch(1, m["image"], lat, m["clip"]["vocab"], m["placeholder"], 700 + s, m["max_ids"]).items()}
+            tr.step(dev["image"], dev["faces"], dev["ids"], dev["tokens"], dev["t"], dev["noise"], dev["post_noise"], 5e-3)
+            del dev
+            if synced:
+                torch.cuda.synchronize()
+            outs.append(u.forward(dv(xs), dv(ts), dv(cs)).clone())
+        ends.append(dict(W=tr.get_state("mlp.weight").clone(), gW=tr.get_state("mlp.grad_weight").clone(), idc=tr.get_state("id_coefficients").clone(),
+                         outs=[o.cpu() for o in outs]))
+        u.close(); tr.close()
+    a, b = ends
+    for k in ("W", "gW", "idc"):
+        assert torch.equal(a[k], b[k]), f"{k}: a user of the context overtook the deferred tail (max diff {(a[k] - b[k]).abs().max().item():.3e})"
+    assert all(torch.equal(x, y) for x, y in zip(a["outs"], b["outs"]))
+
+
 def test_deferred_tail_is_bitwise_the_joined_step_sd14(cb):
     """the same at SD v1-4 size, bs=1: 6 back-to-back steps of the ~1 400-launch two-stream step"""
     from oracle import cb_oracle as O
