@@ -27,6 +27,8 @@ EXTRA = {src: (["-mllvm", "-amdgpu-mfma-vgpr-form"] if os.environ.get("CB_MFMA_V
 # cb_gemm_glds.hip): a register spill would add scratch loads / stores to that count and let a tile be read before it has landed.
 # The build therefore fails if any kernel of these files has scratch, spills or a dynamic stack (-Rpass-analysis remarks).
 # (The f2_* attention kernels drain with vmcnt(0) and do not depend on the count: scratch there is reported, not fatal.)
+if os.environ.get("CB_FLASH_ABL"):       # timing ablations of the fp32 attention backward (cb_flash.hip, FL_ABL): results are wrong under them
+    EXTRA["cb_flash.hip"] = EXTRA["cb_flash.hip"] + ["-DFL_ABL=" + str(int(os.environ["CB_FLASH_ABL"]))]
 NO_SCRATCH = {"cb_gemm_glds.hip": ("gemm_glds", True), "cb_gemm_bf16_p8.hip": ("gemm_bf16_p8", True), "cb_flash_bf16_v2.hip": ("f2_", False)}
 
 
@@ -172,11 +174,22 @@ def _build_locked(verbose, force):
 
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as ex:
         objs = list(ex.map(compile_one, SOURCES))
-    if force or _newer(objs, LIB):
+    # the library is relinked when an object is newer OR when it was linked from another set of objects (a flag change — CB_MFMA_VGPR_FORM,
+    # CB_FLASH_ABL — selects differently tagged objects that may all be older than the library)
+    manifest = os.path.join(BUILD, "linked_objects.txt")
+    want = "\n".join(os.path.basename(o) for o in objs)
+    try:
+        with open(manifest) as f:
+            same = f.read() == want
+    except OSError:
+        same = False
+    if force or not same or _newer(objs, LIB):
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs + ["-Wl,-rpath,/opt/rocm/lib"]
         if verbose:
             print("[celebbasis_amd.build]", " ".join(cmd), flush=True)
         subprocess.check_call(cmd)
+        with open(manifest, "w") as f:
+            f.write(want)
     return LIB
 
 

@@ -14,16 +14,22 @@
 //   max/sum/rescale factors of query j are already in the lanes that hold O^T[:, j].
 // Backward = two kernels with the same trick (no atomics, deterministic): dQ (block owns 64 queries, loops over K/V tiles)
 // and dK/dV (block owns 64 keys, loops over Q/dO tiles); both recompute P from the saved log-sum-exp.
-// LDS tiles are row-major [row][S2] with S2 = 2 (mod 32): the K-style fragment read (16 rows x one column per quarter)
-// is conflict-free, the V-style read (one row x 16 columns per quarter) is 2-way on half of its lanes; the fp32 MFMA
-// (32 cycles per 16x16x4) leaves ample LDS slack for that.
+// LDS tiles are row-major [row][S2] with S2 = DP + 4 = 4 (mod 16): both the K-style fragment read (16 rows x one column per
+// quarter) and the V-style read (one row x 16 columns per quarter) are conflict-free (FlCfg::S2; rounds 1 - 5 used 2 (mod 32), whose
+// V-style read was 2-way on half of its lanes: 34 % of the LDS-active cycles in profiles/r05_pmc_flash_f32.txt).
 #include "cb_common.h"
+#include <type_traits>
 
 namespace cb {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FL_ROWS = 64;      // rows (queries or keys) owned by a block: 4 waves x 16
+// Timing ablations of the two backward kernels (build with CB_FLASH_ABL=<bits>; results are WRONG under them, tools/bench_flash.py only):
+// 1 = no softmax arithmetic, 2 = no tile staging in the loop (no LDS stores, barriers, prefetch), 4 = MFMA A operands from registers (no LDS reads)
+#ifndef FL_ABL
+#define FL_ABL 0
+#endif
 
 __device__ __forceinline__ float quad_max(float v) { v = fmaxf(v, __shfl_xor(v, 16, 64)); return fmaxf(v, __shfl_xor(v, 32, 64)); }
 __device__ __forceinline__ float quad_sum(float v) { v += __shfl_xor(v, 16, 64); return v + __shfl_xor(v, 32, 64); }
@@ -32,7 +38,9 @@ template <int DT> struct FlCfg {
     static constexpr int DP = DT * 16;                          // padded head dim
     static constexpr int KS = (DT == 3) ? 10 : DT * 4;          // MFMA k-steps (4 wide) over the head dim; DT = 3 serves d <= 40
                                                                 // (SD's 64x64 attention): 10 steps, not 12 (the dispatcher sends 40 < d <= 48 to DT = 4)
-    static constexpr int S2 = ((DP + 31) / 32) * 32 + 2;        // LDS row stride, = 2 (mod 32), >= DP
+    static constexpr int S2 = DP + 4;                           // LDS row stride = 4 (mod 16): both fragment reads are conflict-free over the whole wave —
+                                                                // K-style (16 rows x one column per quarter): bank = S2*l15 + quarter, S2 mod 64 in {20, 36, 52, 4} walks the 16
+                                                                // multiples of 4; V-style (row 4*quarter + r, 16 columns): 4*S2 = 16 (mod 64) puts the quarters 16 banks apart
     static constexpr int TK = (DT >= 8) ? 32 : 64;              // rows of the streamed tile
     static constexpr int NT = TK / 16;                          // 16-row sub-tiles of the streamed tile
 };
@@ -95,11 +103,52 @@ __device__ __forceinline__ void fl_store(float* T, const float4 (&reg)[FlTile<DT
 #pragma unroll
     for (int j = 0; j < FlTile<DT>::N; ++j)
         if (all_used || st.loff[j] >= 0) {
-            float* t = T + st.loff[j];                       // S2 is even: 8-byte aligned pairs
-            *reinterpret_cast<float2*>(t) = make_float2(reg[j].x, reg[j].y);
-            *reinterpret_cast<float2*>(t + 2) = make_float2(reg[j].z, reg[j].w);
+            *reinterpret_cast<float4*>(T + st.loff[j]) = reg[j];        // S2 and the column are multiples of 4: 16-byte aligned
         }
 }
+
+// ---- LDS-DMA staging (round 6; d <= 48, i.e. the 64x64-level UNet attention, d = 40): the streamed tiles go global -> LDS directly
+// (`buffer_load ... lds`, 16 bytes per lane = 1 KiB per wave instruction) into TWO buffer pairs. Per tile the loop is
+//     { s_waitcnt vmcnt(0); s_barrier;  issue the DMA of tile t+1 into the other pair;  compute tile t from this pair }
+// — one barrier instead of two, no staging registers (12 .. 24 per thread), no ds_write instructions, no VALU address arithmetic: the
+// per-lane source offsets are loop invariant and the tile's base rides in the instruction's scalar offset. The barrier orders both
+// hazards: every wave's DMA of tile t has landed (RAW) and every wave has finished reading tile t-1, whose pair the next DMA overwrites
+// (WAR). Measured on the 64x64-level self-attention (N = 4096, d = 40; profiles/README.md round 6): the register staging with its two
+// barriers cost 73 of 704 us of the backward. The image is T[TK][S2] as before, S2 / 4 chunks of 16 bytes per row of which the last is
+// the row padding (loaded out of range = zeros, like the head-dim padding columns); the last 1 KiB instruction may run past the TK rows, so a
+// tile occupies TILE_BYTES = a whole number of KiB. Larger head dims keep the register staging: two pairs of their 21 KiB tiles do not fit
+// two blocks per CU.
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int DT> struct FlDma {
+    static constexpr bool ON = DT <= 3;                               // d <= 48 (two pairs of the d = 64 tiles would need > 64 KiB of dynamic LDS)
+    static constexpr int CPR = FlCfg<DT>::S2 / 4;                     // 16-byte chunks per LDS row
+    static constexpr int NI = (FlCfg<DT>::TK * CPR + 63) / 64;        // 1 KiB instructions per tile
+    static constexpr int NW = (NI + 3) / 4;                           // ... per wave (wave w issues instructions w, w + 4, ...)
+    static constexpr int TILE_BYTES = NI * 1024;
+    int off[NW];        // this lane's source byte offset inside the slice for instruction wave + 4 j; FL_OOB: padding chunk / beyond the tile
+    int row[NW];
+    __device__ __forceinline__ void init(long ld, int d, int wave, int lane) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int f = 64 * (wave + 4 * j) + lane, r = f / CPR, c = (f - r * CPR) * 4;
+            row[j] = r;
+            off[j] = (r < FlCfg<DT>::TK && c < d) ? (int)(((long)r * ld + c) * 4) : FL_OOB;
+        }
+    }
+    // tile = LDS address of the tile image, wave = this wave's index (both wave-uniform)
+    __device__ __forceinline__ void issue(__amdgpu_buffer_rsrc_t srd, char* tile, int wave, int row0, int limit, long ld) const {
+        const int base = (int)((long)row0 * ld * 4);
+        const bool full = row0 + FlCfg<DT>::TK <= limit;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            if (NI % 4 != 0 && j == NW - 1 && wave + 4 * j >= NI) break;                      // wave-uniform
+            // (range checking looks at the vector offset alone: the FL_OOB sentinel stays out of range whatever the scalar base is)
+            const int o = (full || row0 + row[j] < limit) ? off[j] : FL_OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(srd, (lds_ptr_t)(tile + (wave + 4 * j) * 1024), 16, o, base, 0, 0);
+        }
+    }
+};
+#define FL_DMA_SYNC() do { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __syncthreads(); } while (0)
 
 // per-lane register copy of row `row` (B operand of a transposed MFMA): reg[s] = src[row][4*s + quarter] * mul, 0 beyond d / limit
 template <int DT>
@@ -117,8 +166,8 @@ template <int DT>
 __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ks = lds;                         // [TK][S2]
-    float* Vs = lds + C::TK * C::S2;         // [TK][S2]
+    float* Ks0 = lds;                        // [TK][S2]   (register staging; the DMA form lays out two pairs of KiB-rounded images)
+    float* Vs0 = lds + C::TK * C::S2;        // [TK][S2]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = blockIdx.x * FL_ROWS;
@@ -142,72 +191,95 @@ __global__ __launch_bounds__(256) void flash_fwd_kernel(const FlashArgs a) {
         kbeg = blockIdx.z * kchunk; kend = min(a.Nk, kbeg + kchunk);
     }
     const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
-    FlStream<DT> st; st.init(a.ldk, a.d);
-    float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
-    fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
-    for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
-        __syncthreads();
-        fl_store<DT>(Ks, pk, st);
-        fl_store<DT>(Vs, pv, st);
-        __syncthreads();
-        if (k0 + C::TK < kend) {
-            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
-            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
-        }
-        f32x4 s[C::NT];
+    auto tile = [&](const float* Ks, const float* Vs, int k0) {
+            f32x4 s[C::NT];
 #pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int kt = 0; kt < C::NT; ++kt) s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int st = 0; st < C::KS; ++st)
+            for (int st = 0; st < C::KS; ++st)
 #pragma unroll
-            for (int kt = 0; kt < C::NT; ++kt) {
-                float av = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qreg[st], s[kt], 0, 0, 0);
+                for (int kt = 0; kt < C::NT; ++kt) {
+                    float av = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                    s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, qreg[st], s[kt], 0, 0, 0);
+                }
+            // mask (only on the ragged last tile / causal diagonal: wave-uniform branch) + online softmax per lane quartet
+            if (a.causal || k0 + C::TK > a.Nk) {
+#pragma unroll
+                for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int key = k0 + kt * 16 + quarter * 4 + r;
+                        bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                        s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    }
             }
-        // mask (only on the ragged last tile / causal diagonal: wave-uniform branch) + online softmax per lane quartet
-        if (a.causal || k0 + C::TK > a.Nk) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
+            mx = quad_max(mx);
+            float mnew = fmaxf(m, mx);
+            float muse = (mnew == -INFINITY) ? 0.f : mnew;
+            float alpha = __builtin_amdgcn_exp2f(m - muse);            // m = -inf -> 0
+            float ps = 0.f;
 #pragma unroll
             for (int kt = 0; kt < C::NT; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    int key = k0 + kt * 16 + quarter * 4 + r;
-                    bool ok = key < a.Nk && (!a.causal || key <= qrow);
-                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    float p = __builtin_amdgcn_exp2f(s[kt][r] - muse);
+                    s[kt][r] = p;
+                    ps += p;
                 }
+            l = l * alpha + quad_sum(ps);
+            m = mnew;
+#pragma unroll
+            for (int t = 0; t < DT; ++t) o[t] *= alpha;
+            // O^T += V^T P^T
+#pragma unroll
+            for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int t = 0; t < DT; ++t) {
+                        float av = Vs[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                        o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[kt][r], o[t], 0, 0, 0);
+                    }
+    };
+    if constexpr (FlDma<DT>::ON) {
+        constexpr int TB = FlDma<DT>::TILE_BYTES;
+        char* img = reinterpret_cast<char*>(lds);                  // [2 pairs][K tile, V tile]
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        FlDma<DT> dm; dm.init(a.ldk, a.d, wv, lane);
+        if (kbeg < kend) {                                         // (never leave a DMA in flight behind the block: its LDS is handed on)
+            dm.issue(srdK, img, wv, kbeg, a.Nk, a.ldk);
+            dm.issue(srdV, img + TB, wv, kbeg, a.Nk, a.ldk);
         }
-        float mx = -INFINITY;
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
-        mx = quad_max(mx);
-        float mnew = fmaxf(m, mx);
-        float muse = (mnew == -INFINITY) ? 0.f : mnew;
-        float alpha = __builtin_amdgcn_exp2f(m - muse);            // m = -inf -> 0
-        float ps = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kt][r] - muse);
-                s[kt][r] = p;
-                ps += p;
+        int pair = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += C::TK, pair ^= 1) {
+            FL_DMA_SYNC();
+            if (k0 + C::TK < kend) {
+                dm.issue(srdK, img + (pair ^ 1) * 2 * TB, wv, k0 + C::TK, a.Nk, a.ldk);
+                dm.issue(srdV, img + (pair ^ 1) * 2 * TB + TB, wv, k0 + C::TK, a.Nk, a.ldk);
             }
-        l = l * alpha + quad_sum(ps);
-        m = mnew;
-#pragma unroll
-        for (int t = 0; t < DT; ++t) o[t] *= alpha;
-        // O^T += V^T P^T
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    float av = Vs[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
-                    o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, s[kt][r], o[t], 0, 0, 0);
-                }
+            tile(reinterpret_cast<const float*>(img + pair * 2 * TB), reinterpret_cast<const float*>(img + pair * 2 * TB + TB), k0);
+        }
+    } else {
+        FlStream<DT> st; st.init(a.ldk, a.d);
+        float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
+        fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
+        fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
+        for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
+            __syncthreads();
+            fl_store<DT>(Ks0, pk, st);
+            fl_store<DT>(Vs0, pv, st);
+            __syncthreads();
+            if (k0 + C::TK < kend) {
+                fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+                fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
+            }
+            tile(Ks0, Vs0, k0);
+        }
     }
     if (a.ksplit > 1) {                                // partial: unnormalised O relative to the running max m, and (m, l)
         if (qrow < a.Nq) {
@@ -258,8 +330,8 @@ template <int DT>
 __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Ks = lds;
-    float* Vs = lds + C::TK * C::S2;
+    float* Ks0 = lds;
+    float* Vs0 = lds + C::TK * C::S2;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int q0 = blockIdx.x * FL_ROWS;
@@ -296,54 +368,88 @@ __global__ __launch_bounds__(256) void flash_bwd_dq_kernel(const FlashArgs a) {
         kbeg = blockIdx.z * kchunk; kend = min(a.Nk, kbeg + kchunk);
     }
     const __amdgpu_buffer_rsrc_t srdK = fl_srd(K), srdV = fl_srd(V);
-    FlStream<DT> st; st.init(a.ldk, a.d);
-    float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
-    fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
-    fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
-    for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
-        __syncthreads();
-        fl_store<DT>(Ks, pk, st);
-        fl_store<DT>(Vs, pv, st);
-        __syncthreads();
-        if (k0 + C::TK < kend) {
-            fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
-            fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
+    auto tile = [&](const float* Ks, const float* Vs, int k0) {
+            // the ragged / causal tile is its own copy of the body: left to itself the compiler if-converts the wave-uniform `need_mask` and
+            // every tile pays the per-element compares and selects (~9 VALU / SALU per score; fp32 MFMAs issue on the vector ALU's own
+            // pipe, so VALU instructions in this loop are matrix time lost one for one)
+            auto body = [&](auto masked) {
+                constexpr bool MASK = decltype(masked)::value;
+                f32x4 s[C::NT], dp[C::NT];
+#pragma unroll
+                for (int kt = 0; kt < C::NT; ++kt) { s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+                    for (int kt = 0; kt < C::NT; ++kt) {
+                        float ak = (FL_ABL & 4) ? dreg[st] : Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                        float av = (FL_ABL & 4) ? qreg[st] : Vs[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
+                        s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qreg[st], s[kt], 0, 0, 0);      // S^T  = K Q^T
+                        dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dreg[st], dp[kt], 0, 0, 0);    // dP^T = V dO^T
+                    }
+#pragma unroll
+                for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        if (FL_ABL & 1) { s[kt][r] += dp[kt][r]; continue; }
+                        float p = __builtin_amdgcn_exp2f(s[kt][r] - lse);
+                        if constexpr (MASK) {
+                            int key = k0 + kt * 16 + quarter * 4 + r;
+                            bool ok = key < a.Nk && (!a.causal || key <= qrow);
+                            p = ok ? p : 0.f;
+                        }
+                        s[kt][r] = p * (dp[kt][r] - Dq) * a.scale;                                        // d(q.k)
+                    }
+                // dQ^T += K^T dS^T
+#pragma unroll
+                for (int kt = 0; kt < C::NT; ++kt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) {
+                            float ak = (FL_ABL & 4) ? qreg[t] : Ks[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                            g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, s[kt][r], g[t], 0, 0, 0);
+                        }
+            };
+            if (a.causal || k0 + C::TK > a.Nk) body(std::true_type{}); else body(std::false_type{});     // wave-uniform
+    };
+    if constexpr (FlDma<DT>::ON) {
+        constexpr int TB = FlDma<DT>::TILE_BYTES;
+        char* img = reinterpret_cast<char*>(lds);                  // [2 pairs][K tile, V tile]
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        FlDma<DT> dm; dm.init(a.ldk, a.d, wv, lane);
+        if (kbeg < kend) {                                         // (never leave a DMA in flight behind the block: its LDS is handed on)
+            dm.issue(srdK, img, wv, kbeg, a.Nk, a.ldk);
+            dm.issue(srdV, img + TB, wv, kbeg, a.Nk, a.ldk);
         }
-        f32x4 s[C::NT], dp[C::NT];
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt) { s[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[kt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int st = 0; st < C::KS; ++st)
-#pragma unroll
-            for (int kt = 0; kt < C::NT; ++kt) {
-                float ak = Ks[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
-                float av = Vs[(kt * 16 + l15) * C::S2 + 4 * st + quarter];
-                s[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, qreg[st], s[kt], 0, 0, 0);      // S^T  = K Q^T
-                dp[kt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, dreg[st], dp[kt], 0, 0, 0);    // dP^T = V dO^T
+        int pair = 0;
+        for (int k0 = kbeg; k0 < kend; k0 += C::TK, pair ^= 1) {
+            if (!(FL_ABL & 2) || k0 == kbeg) {
+            FL_DMA_SYNC();
+            if (k0 + C::TK < kend) {
+                dm.issue(srdK, img + (pair ^ 1) * 2 * TB, wv, k0 + C::TK, a.Nk, a.ldk);
+                dm.issue(srdV, img + (pair ^ 1) * 2 * TB + TB, wv, k0 + C::TK, a.Nk, a.ldk);
             }
-        const bool need_mask = a.causal || k0 + C::TK > a.Nk;          // wave-uniform
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float p = __builtin_amdgcn_exp2f(s[kt][r] - lse);
-                if (need_mask) {
-                    int key = k0 + kt * 16 + quarter * 4 + r;
-                    bool ok = key < a.Nk && (!a.causal || key <= qrow);
-                    p = ok ? p : 0.f;
-                }
-                s[kt][r] = p * (dp[kt][r] - Dq) * a.scale;                                        // d(q.k)
             }
-        // dQ^T += K^T dS^T
-#pragma unroll
-        for (int kt = 0; kt < C::NT; ++kt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    float ak = Ks[(kt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
-                    g[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ak, s[kt][r], g[t], 0, 0, 0);
-                }
+            tile(reinterpret_cast<const float*>(img + pair * 2 * TB), reinterpret_cast<const float*>(img + pair * 2 * TB + TB), k0);
+        }
+    } else {
+        FlStream<DT> st; st.init(a.ldk, a.d);
+        float4 pk[FlTile<DT>::N], pv[FlTile<DT>::N];
+        fl_prefetch<DT>(pk, srdK, st, kbeg, a.Nk, a.ldk);
+        fl_prefetch<DT>(pv, srdV, st, kbeg, a.Nk, a.ldk);
+        for (int k0 = kbeg; k0 < kend; k0 += C::TK) {
+            if (!(FL_ABL & 2) || k0 == kbeg) {
+            __syncthreads();
+            fl_store<DT>(Ks0, pk, st);
+            fl_store<DT>(Vs0, pv, st);
+            __syncthreads();
+            if (k0 + C::TK < kend) {
+                fl_prefetch<DT>(pk, srdK, st, k0 + C::TK, a.Nk, a.ldk);
+                fl_prefetch<DT>(pv, srdV, st, k0 + C::TK, a.Nk, a.ldk);
+            }
+            }
+            tile(Ks0, Vs0, k0);
+        }
     }
     if (a.ksplit > 1) {
         if (qrow < a.Nq) {
@@ -380,9 +486,9 @@ template <int DT>
 __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     using C = FlCfg<DT>;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* Qs = lds;                              // [TK][S2]
-    float* Ds = lds + C::TK * C::S2;              // dO tile [TK][S2]
-    float* Ls = lds + 2 * C::TK * C::S2;          // lse[TK], D[TK]
+    float* Qs0 = lds;                             // [TK][S2]   (register staging)
+    float* Ds0 = lds + C::TK * C::S2;             // dO tile [TK][S2]
+    float* Ls0 = lds + 2 * C::TK * C::S2;         // lse[TK], D[TK]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, l15 = lane & 15, quarter = lane >> 4;
     const int bh = blockIdx.y, b = bh / a.H, h = bh - b * a.H;
     const int k0 = blockIdx.x * FL_ROWS;
@@ -405,64 +511,105 @@ __global__ __launch_bounds__(256) void flash_bwd_dkv_kernel(const FlashArgs a) {
     const int qlim = min(a.Nq, qbeg + qchunk);
     if (a.causal) qbeg = max(qbeg, (k0 / C::TK) * C::TK);   // queries before the first key of the block see none of its keys
     const __amdgpu_buffer_rsrc_t srdQ = fl_srd(Q), srdD = fl_srd(dO);
-    FlStream<DT> stq, sto; stq.init(a.ldq, a.d); sto.init(a.ldo, a.d);
     const float scale2 = a.scale * 1.4426950408889634f;
-    float4 pq[FlTile<DT>::N], pd[FlTile<DT>::N];
-    fl_prefetch<DT>(pq, srdQ, stq, qbeg, a.Nq, a.ldq);
-    fl_prefetch<DT>(pd, srdD, sto, qbeg, a.Nq, a.ldo);
-    for (int q0 = qbeg; q0 < qlim; q0 += C::TK) {
-        __syncthreads();
-        fl_store<DT>(Qs, pq, stq);
-        fl_store<DT>(Ds, pd, sto);
-        if (threadIdx.x < C::TK) {
-            int qi = q0 + threadIdx.x;
-            Ls[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
-            Ls[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
+    auto tile = [&](const float* Qs, const float* Ds, const float* Ls, int q0) {
+            // rows of the C layout are queries 4*quarter + r of sub-tile qt, the column is this lane's key; masked tiles are a separate copy of the
+            // body (see the dQ kernel)
+            auto body = [&](auto masked) {
+                constexpr bool MASK = decltype(masked)::value;
+                f32x4 s[C::NT], dp[C::NT];
+#pragma unroll
+                for (int qt = 0; qt < C::NT; ++qt) { s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+                for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+                    for (int qt = 0; qt < C::NT; ++qt) {
+                        float aq = (FL_ABL & 4) ? vreg[st] : Qs[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
+                        float ad = (FL_ABL & 4) ? kreg[st] : Ds[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
+                        s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, kreg[st], s[qt], 0, 0, 0);
+                        dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, vreg[st], dp[qt], 0, 0, 0);
+                    }
+#pragma unroll
+                for (int qt = 0; qt < C::NT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        int ql = qt * 16 + quarter * 4 + r, qi = q0 + ql;
+                        if (FL_ABL & 1) continue;
+                        float p = __builtin_amdgcn_exp2f(s[qt][r] * scale2 - Ls[ql]);
+                        if constexpr (MASK) {
+                            bool ok = qi < a.Nq && krow < a.Nk && (!a.causal || krow <= qi);
+                            p = ok ? p : 0.f;
+                        }
+                        float ds = p * (dp[qt][r] - Ls[C::TK + ql]) * a.scale;
+                        s[qt][r] = p;
+                        dp[qt][r] = ds;
+                    }
+#pragma unroll
+                for (int qt = 0; qt < C::NT; ++qt)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+#pragma unroll
+                        for (int t = 0; t < DT; ++t) {
+                            float ad = (FL_ABL & 4) ? kreg[t] : Ds[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                            float aq = (FL_ABL & 4) ? vreg[t] : Qs[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
+                            gv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s[qt][r], gv[t], 0, 0, 0);
+                            gk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dp[qt][r], gk[t], 0, 0, 0);
+                        }
+            };
+            if (a.causal || q0 + C::TK > a.Nq || k0 + FL_ROWS > a.Nk) body(std::true_type{}); else body(std::false_type{});   // wave-uniform
+    };
+    if constexpr (FlDma<DT>::ON) {
+        constexpr int TB = FlDma<DT>::TILE_BYTES;
+        char* img = reinterpret_cast<char*>(lds);                  // [2 pairs][Q tile, dO tile], then [2][lse[TK], D[TK]]
+        float* Lsb = reinterpret_cast<float*>(img + 4 * TB);
+        const int wv = __builtin_amdgcn_readfirstlane(wave);
+        FlDma<DT> dq_, do_; dq_.init(a.ldq, a.d, wv, lane); do_.init(a.ldo, a.d, wv, lane);
+        // the per-query scalars of a tile: one 256-byte DMA each (wave 0: log-sum-exp, wave 1: D); rows beyond Nq read as zero (num_records)
+        const __amdgpu_buffer_rsrc_t srdL = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((wv == 0 ? a.lse : a.dvec) + (long)bh * a.Nq), 0, a.Nq * 4, 0x00020000);
+        auto scalars = [&](int pair, int q0) {
+            if (wv < 2) __builtin_amdgcn_raw_ptr_buffer_load_lds(srdL, (lds_ptr_t)(Lsb + pair * 2 * C::TK + wv * C::TK), 4, (q0 + lane) * 4, 0, 0, 0);
+        };
+        static_assert(C::TK == 64, "one DMA instruction per scalar row");
+        if (qbeg < qlim) {                                         // (never leave a DMA in flight behind the block: its LDS is handed on)
+            dq_.issue(srdQ, img, wv, qbeg, a.Nq, a.ldq);
+            do_.issue(srdD, img + TB, wv, qbeg, a.Nq, a.ldo);
+            scalars(0, qbeg);
         }
-        __syncthreads();
-        if (q0 + C::TK < qlim) {
-            fl_prefetch<DT>(pq, srdQ, stq, q0 + C::TK, a.Nq, a.ldq);
-            fl_prefetch<DT>(pd, srdD, sto, q0 + C::TK, a.Nq, a.ldo);
+        int pair = 0;
+        for (int q0 = qbeg; q0 < qlim; q0 += C::TK, pair ^= 1) {
+            if (!(FL_ABL & 2) || q0 == qbeg) {
+            FL_DMA_SYNC();
+            if (q0 + C::TK < qlim) {
+                dq_.issue(srdQ, img + (pair ^ 1) * 2 * TB, wv, q0 + C::TK, a.Nq, a.ldq);
+                do_.issue(srdD, img + (pair ^ 1) * 2 * TB + TB, wv, q0 + C::TK, a.Nq, a.ldo);
+                scalars(pair ^ 1, q0 + C::TK);
+            }
+            }
+            tile(reinterpret_cast<const float*>(img + pair * 2 * TB), reinterpret_cast<const float*>(img + pair * 2 * TB + TB), Lsb + pair * 2 * C::TK, q0);
         }
-        f32x4 s[C::NT], dp[C::NT];
-#pragma unroll
-        for (int qt = 0; qt < C::NT; ++qt) { s[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; dp[qt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
-#pragma unroll
-        for (int st = 0; st < C::KS; ++st)
-#pragma unroll
-            for (int qt = 0; qt < C::NT; ++qt) {
-                float aq = Qs[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
-                float ad = Ds[(qt * 16 + l15) * C::S2 + 4 * st + quarter];
-                s[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, kreg[st], s[qt], 0, 0, 0);
-                dp[qt] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, vreg[st], dp[qt], 0, 0, 0);
+    } else {
+        FlStream<DT> stq, sto; stq.init(a.ldq, a.d); sto.init(a.ldo, a.d);
+        float4 pq[FlTile<DT>::N], pd[FlTile<DT>::N];
+        fl_prefetch<DT>(pq, srdQ, stq, qbeg, a.Nq, a.ldq);
+        fl_prefetch<DT>(pd, srdD, sto, qbeg, a.Nq, a.ldo);
+        for (int q0 = qbeg; q0 < qlim; q0 += C::TK) {
+            if (!(FL_ABL & 2) || q0 == qbeg) {
+            __syncthreads();
+            fl_store<DT>(Qs0, pq, stq);
+            fl_store<DT>(Ds0, pd, sto);
+            if (threadIdx.x < C::TK) {
+                int qi = q0 + threadIdx.x;
+                Ls0[threadIdx.x] = qi < a.Nq ? a.lse[(long)bh * a.Nq + qi] : 0.f;
+                Ls0[C::TK + threadIdx.x] = qi < a.Nq ? a.dvec[(long)bh * a.Nq + qi] : 0.f;
             }
-        // rows of the C layout are queries 4*quarter + r of sub-tile qt, the column is this lane's key
-        const bool need_mask = a.causal || q0 + C::TK > a.Nq || k0 + FL_ROWS > a.Nk;   // wave-uniform
-#pragma unroll
-        for (int qt = 0; qt < C::NT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                int ql = qt * 16 + quarter * 4 + r, qi = q0 + ql;
-                float p = __builtin_amdgcn_exp2f(s[qt][r] * scale2 - Ls[ql]);
-                if (need_mask) {
-                    bool ok = qi < a.Nq && krow < a.Nk && (!a.causal || krow <= qi);
-                    p = ok ? p : 0.f;
-                }
-                float ds = p * (dp[qt][r] - Ls[C::TK + ql]) * a.scale;
-                s[qt][r] = p;
-                dp[qt][r] = ds;
+            __syncthreads();
+            if (q0 + C::TK < qlim) {
+                fl_prefetch<DT>(pq, srdQ, stq, q0 + C::TK, a.Nq, a.ldq);
+                fl_prefetch<DT>(pd, srdD, sto, q0 + C::TK, a.Nq, a.ldo);
             }
-#pragma unroll
-        for (int qt = 0; qt < C::NT; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-#pragma unroll
-                for (int t = 0; t < DT; ++t) {
-                    float ad = Ds[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
-                    float aq = Qs[(qt * 16 + quarter * 4 + r) * C::S2 + t * 16 + l15];
-                    gv[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(ad, s[qt][r], gv[t], 0, 0, 0);
-                    gk[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(aq, dp[qt][r], gk[t], 0, 0, 0);
-                }
+            }
+            tile(Qs0, Ds0, Ls0, q0);
+        }
     }
     if (a.nsplit > 1) {
         if (krow < a.Nk) {
@@ -621,6 +768,7 @@ bool flash_supported(int d, const FlashArgs& a) {
 
 template <int DT> static size_t fl_lds_bytes(bool dkv) {
     using C = FlCfg<DT>;
+    if (FlDma<DT>::ON) return (size_t)4 * FlDma<DT>::TILE_BYTES + (dkv ? 4 * C::TK * sizeof(float) : 0);       // two pairs of KiB-rounded images (+ two scalar rows pairs)
     return (size_t)(2 * C::TK * C::S2 + (dkv ? 2 * C::TK : 0)) * sizeof(float);
 }
 

@@ -55,6 +55,8 @@ case "$what" in
     cd $REPO
     db=$(find gpurun_out/trace3_$tag -name "*.db" | head -1)
     python tools/prof_stats.py "$db" gpurun_out/${tag}_config3_kernel_stats.csv $((STEPS + 3)) | head -40
+    python tools/trace_overlap.py "$db" > gpurun_out/${tag}_config3_stream_overlap.txt 2>&1; cat gpurun_out/${tag}_config3_stream_overlap.txt
+    python tools/trace_timeline.py "$db" > gpurun_out/${tag}_config3_timeline.txt 2>&1; tail -15 gpurun_out/${tag}_config3_timeline.txt
     find gpurun_out/trace3_$tag -size +8M -delete ;;
   pmc|pmc3)  # pmc = the fp32 (config-2) leg alone, pmc3 = the config-3 (bf16, bs=4) leg alone: per-symbol averages are not mixed
     tag=$1; shift
