@@ -158,10 +158,15 @@ struct Trainer {
         bool broken = false;                      // a capture / instantiate failed once: the trainer stays on eager launches
         std::vector<Entry> cache;                 // at most kMaxGraphs, least recently used evicted
         float* image = nullptr; float* faces = nullptr; int64_t* ids = nullptr; int64_t* tokens = nullptr; int64_t* t = nullptr;
-        float* noise = nullptr; float* post_noise = nullptr;       // staging, sized for kMaxBatch
+        float* noise = nullptr; float* post_noise = nullptr;       // staging, sized for kMaxBatch: carved out of ONE allocation the trainer owns
+        void* stage_base = nullptr;                                // (not the context's bump pool: a graph-enabled trainer gives its ~150 MB back when it is destroyed)
         long captures = 0, replays = 0, tick = 0;
         hipStream_t cap = nullptr;                // capture stream (the caller's may be the uncapturable legacy default stream)
-        ~StepGraph() { for (auto& e : cache) if (e.exec) (void)hipGraphExecDestroy(e.exec); if (cap) (void)hipStreamDestroy(cap); }
+        ~StepGraph() {
+            for (auto& e : cache) if (e.exec) (void)hipGraphExecDestroy(e.exec);
+            if (cap) (void)hipStreamDestroy(cap);
+            if (stage_base) (void)hipFree(stage_base);
+        }
     } graph;
 };
 void trainer_load(Ctx* ctx, const WTab& wt, const TrainerCfg& cfg, Trainer* T);

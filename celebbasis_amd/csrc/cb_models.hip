@@ -773,13 +773,16 @@ static void step_graph(Trainer* T, const Batch& bt, float lr) {
     constexpr int kMaxGraphs = 8;
     const int B = bt.B, S_ = c.image_size, lat = S_ >> (c.vae.n_mult - 1), zc = c.vae.z_channels, T77 = c.clip.ctx_len;
     if (!g.image) {
-        g.image = ctx->pool.allocf((size_t)kMaxBatch * S_ * S_ * 3);
-        g.faces = ctx->pool.allocf((size_t)kMaxBatch * S_ * S_ * 6);
-        g.noise = ctx->pool.allocf((size_t)kMaxBatch * zc * lat * lat);
-        g.post_noise = ctx->pool.allocf((size_t)kMaxBatch * zc * lat * lat);
-        g.ids = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * 2 * sizeof(int64_t)));
-        g.tokens = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * T77 * sizeof(int64_t)));
-        g.t = static_cast<int64_t*>(ctx->pool.alloc((size_t)kMaxBatch * sizeof(int64_t)));
+        const size_t n_img = (size_t)kMaxBatch * S_ * S_ * 3, n_faces = (size_t)kMaxBatch * S_ * S_ * 6, n_lat = (size_t)kMaxBatch * zc * lat * lat;
+        const size_t n_ids = (size_t)kMaxBatch * 2, n_tok = (size_t)kMaxBatch * T77, n_t = kMaxBatch;
+        auto up = [](size_t b) { return (b + 255) / 256 * 256; };
+        const size_t bytes = up(n_img * 4) + up(n_faces * 4) + 2 * up(n_lat * 4) + up(n_ids * 8) + up(n_tok * 8) + up(n_t * 8);
+        CB_HIP(hipMalloc(&g.stage_base, bytes));
+        char* p = static_cast<char*>(g.stage_base);
+        auto take = [&](size_t b) { char* r = p; p += up(b); return r; };
+        g.image = reinterpret_cast<float*>(take(n_img * 4)); g.faces = reinterpret_cast<float*>(take(n_faces * 4));
+        g.noise = reinterpret_cast<float*>(take(n_lat * 4)); g.post_noise = reinterpret_cast<float*>(take(n_lat * 4));
+        g.ids = reinterpret_cast<int64_t*>(take(n_ids * 8)); g.tokens = reinterpret_cast<int64_t*>(take(n_tok * 8)); g.t = reinterpret_cast<int64_t*>(take(n_t * 8));
     }
     hipStream_t s = ctx->stream;
     ctx->join_tail();                 // an eager step may have left its tail on the side stream
