@@ -14,7 +14,7 @@ instead of on the CPU oracle:
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first steps of the fp32 run are the ones
-tests/test_gpu_models.py::test_train_4_steps_sd14_live_oracle recomputes live, which ties the fixture to the live oracle.
+tests/test_gpu_models.py::test_train_2_steps_sd14_live_oracle recomputes live, which ties the fixture to the live oracle.
 Per step the file holds the loss, the coefficients of every face in the batch (meta_net.py:289, [2B, es, inner]) and the EMA
 dictionary rows of the identities in the batch (embedding_manager.py:484-489); the MLP gradient is kept for a few steps on every
 16th row (a 32 768-element sample: the full 2 MB per step would not be a small fixture)."""
