@@ -35,7 +35,10 @@ struct UNet {
 void unet_load(Ctx* ctx, const WTab& wt, const std::string& prefix, const UNetCfg& cfg, UNet* U);
 // x: [B,H,W,Cin] NHWC, t: device int64[B], context: [B,L,ctx_dim]; returns eps_hat [B,H,W,Cout]
 // context_f32 (optional): the conditioning BEFORE its cast to the UNet's element type; used by the fp32 K/V-projection lever
-Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32 = nullptr);
+// `before_context` (optional) is called once, on the graph's stream, right before the first kernel that READS the conditioning (the stacked
+// K/V projection, issued at the first cross-attention): the trainer joins its side branch there instead of ahead of the whole UNet
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32 = nullptr,
+                  const std::function<void()>* before_context = nullptr);
 
 // ---------------------------------------------------------------- VAE encoder (model.py:368-459, autoencoder.py:324-328)
 struct VaeCfg { int ch = 128; int ch_mult[8] = {1, 2, 4, 4, 0, 0, 0, 0}; int n_mult = 4; int num_res_blocks = 2; int in_channels = 3;

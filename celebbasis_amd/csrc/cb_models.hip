@@ -126,8 +126,28 @@ static Ten* resblock(Graph& G, const ResBlockW& r, Ten* x, Ten* emb_all) {
     Ten* skip = r.has_skip ? G.linear(x, r.skip) : x;
     return G.conv(h, r.c2, CONV_SAME, nullptr, skip);  // skip_connection(x) + h fused as a residual epilogue
 }
+// All cross-attention keys / values of a UNet pass come from ONE GEMM on the conditioning (U.kv_all: the 32 projections stacked at load time);
+// the layers read column views of it. It is issued at the first cross-attention, not at the top of the UNet: everything before it — time
+// embedding, conv_in, the first ResBlock, the first block's self-attention — does not read the conditioning, and in the training step the
+// conditioning comes from the side stream (FR backbone -> head -> CLIP), which is the LONGER branch of the step's first phase at bs = 1
+// (CB_JOIN_PROBE: the context stream sat 0.54 - 0.68 ms in the join when it came ahead of the UNet). Same kernels, same operands: bitwise.
+// The backward order does not move either: nothing recorded before the first cross-attention carries a gradient.
+struct LazyKV {
+    Graph& G; const UNet& U; Ten* context; Ten* context_f32; const std::function<void()>* before;
+    Ten* kv = nullptr;
+    Ten* get() {
+        if (kv) return kv;
+        if (before && *before) (*before)();
+        kv = (context_f32 && U.kv_all32.w) ? G.cast(G.linear(context_f32, U.kv_all32), U.dt) : G.linear(context, U.kv_all);
+        if (kv->rg) {      // zero-filled up front: the 16 layers each accumulate into their own disjoint column block of its gradient
+            float beta; void* g = G.grad(kv, &beta);
+            k_fill(G.L, kv->dt, g, kv->numel(), 0.f);
+        }
+        return kv;
+    }
+};
 // attention.py:250-261 SpatialTransformer + 211-215 BasicTransformerBlock
-static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* kv_all) {
+static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, LazyKV& kv_all) {
     const int ch = w.ch, d = ch / w.heads;
     const float scale = 1.f / sqrtf((float)d);
     Ten* h = G.groupnorm(x, w.norm, false);
@@ -138,7 +158,7 @@ static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* kv_all) {
     h = G.linear(a, w.out1, h);
     Ten* n2 = G.layernorm(h, w.ln2);
     Ten* q = G.linear(n2, w.q2);
-    a = G.attention(q, 0, kv_all, w.kv_col, w.kv_col + ch, ch, w.heads, scale, false);
+    a = G.attention(q, 0, kv_all.get(), w.kv_col, w.kv_col + ch, ch, w.heads, scale, false);
     h = G.linear(a, w.out2, h);
     Ten* n3 = G.layernorm(h, w.ln3);
     Ten* f = G.linear(n3, w.ff1);
@@ -147,7 +167,7 @@ static Ten* xfmr(Graph& G, const XfmrW& w, Ten* x, Ten* kv_all) {
     return G.linear(h, w.proj_out, x);
 }
 
-Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32) {
+Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* context, Ten* context_f32, const std::function<void()>* before_context) {
     const int B = x->n, mc = U.cfg.model_channels;
     CB_CHECK(x->c == U.cfg.in_channels, CB_ERR_SHAPE, "unet: input channels %d vs %d", x->c, U.cfg.in_channels);
     CB_CHECK(context->c == U.cfg.context_dim && context->n == B, CB_ERR_SHAPE, "unet: context shape");
@@ -158,13 +178,7 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     e = G.silu(e);
     Ten* emb = G.linear(e, U.te2);
     Ten* semb = G.linear(G.silu(emb), U.emb_all);      // emb_layers of all ResBlocks: SiLU(emb) is shared, one stacked Linear
-    // all cross-attention keys/values of the step in one GEMM; the layers read column views of it. Its gradient buffer is
-    // zero-filled up front because the 16 layers each accumulate into their own disjoint column block.
-    Ten* kv_all = (context_f32 && U.kv_all32.w) ? G.cast(G.linear(context_f32, U.kv_all32), U.dt) : G.linear(context, U.kv_all);
-    if (kv_all->rg) {
-        float beta; void* g = G.grad(kv_all, &beta);
-        k_fill(G.L, kv_all->dt, g, kv_all->numel(), 0.f);
-    }
+    LazyKV kv_all{G, U, context, context_f32, before_context};
     std::vector<Ten*> hs;
     Ten* h = G.conv(x, U.conv_in, CONV_SAME);
     hs.push_back(h);
@@ -192,6 +206,7 @@ Ten* unet_forward(Graph& G, const UNet& U, Ten* x, const int64_t* t_dev, Ten* co
     h = G.groupnorm(h, U.out_norm, true);
     h = G.conv(h, U.out_conv, CONV_SAME);
     G.tap("unet.out", h);
+    kv_all.get();          // a UNet without cross-attention still owes its caller the `before_context` call
     return h;
 }
 
@@ -692,15 +707,41 @@ static void step_impl(Trainer* T, const Batch& bt, float lr) {
     }
 
     const size_t vae_region_end = ctx->arena.off;    // arena [id_region_end, vae_region_end): the first stage (context stream, before the join)
-    // join: the UNet needs the conditioning. ev_join was recorded on the side stream AFTER its wait for the previous step's deferred
-    // tail, so this wait also orders that tail before everything below
-    if (fork) { CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0)); ctx->tail_pending = false; }
+    // join: the UNet needs the conditioning — from its first cross-attention on (unet_forward calls `join` there; what runs before it reads
+    // frozen weights, z0 and the caller's noise / t, and writes the arena cells right above the first stage's: nothing the previous step's
+    // deferred tail touches). ev_join was recorded on the side stream AFTER its wait for that tail, so this wait also orders the tail before
+    // everything enqueued behind it.
+    // CB_JOIN_PROBE=1 (diagnostics; blocks the host once per step) prints how long the context stream sits in the wait.
+    static const bool join_probe = getenv("CB_JOIN_PROBE") != nullptr;
+    static hipEvent_t jp0 = nullptr, jp1 = nullptr;
+    bool joined = false;
+    const std::function<void()> join = [&]() {
+        if (!fork || joined) return;
+        joined = true;
+        const bool probe = join_probe && !T->capturing;
+        if (probe) {
+            if (!jp0) { CB_HIP(hipEventCreate(&jp0)); CB_HIP(hipEventCreate(&jp1)); }
+            CB_HIP(hipEventRecord(jp0, main_stream));
+        }
+        CB_HIP(hipStreamWaitEvent(main_stream, ctx->ev_join, 0));
+        ctx->tail_pending = false;
+        if (probe) {
+            CB_HIP(hipEventRecord(jp1, main_stream));
+            CB_HIP(hipEventSynchronize(jp1));
+            float ms = 0.f;
+            CB_HIP(hipEventElapsedTime(&ms, jp0, jp1));
+            fprintf(stderr, "[cb join probe] context stream waited %.3f ms for the side branch\n", ms);
+        }
+    };
+    static const bool join_early = [] { const char* e = getenv("CB_JOIN_EARLY"); return e && e[0] == '1'; }();      // A/B: the round-5 position
+    if (join_early) join();
 
     // (4-6) q_sample, UNet, loss   (ddpm.py:926-936, 1069-1116)
     std::unique_ptr<Phase> ph_uf(new Phase(L, "phase:unet_fwd"));
     Ten* xt = G.make(B, z0->h, z0->w, zc, false, z0->dt);
     k_qsample(L, z0->dt, xt->p, z0->p, bt.noise, bt.t, T->sqrt_ac, T->sqrt_1mac, B, zc, z0->h * z0->w);
-    Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond, cond32->dt == DT_F32 && cond32 != cond ? cond32 : nullptr);
+    Ten* eps_hat = unet_forward(G, T->unet, xt, bt.t, cond, cond32->dt == DT_F32 && cond32 != cond ? cond32 : nullptr, &join);
+    join();
     float beta;
     void* deps = G.grad(eps_hat, &beta);
     k_mse_loss(L, eps_hat->dt, T->loss, deps, eps_hat->p, bt.noise, B, zc, z0->h * z0->w);
