@@ -67,7 +67,14 @@ int cb_ctx_create_dtype(int device, void* hip_stream, int dtype, cb_ctx** out) {
         c.stream = static_cast<hipStream_t>(hip_stream);
         // (a high-priority side stream was measured: 39.23 / 39.09 ms against 39.24 / 39.26 ms per fp32 step, 34.64 / 34.41 against 34.55 / 34.56 ms
         //  per bf16 step — no effect, plain stream kept; profiles/README.md round 3)
-        CB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+        {
+            const char* e = getenv("CB_AUX_PRIORITY");          // experiment switch: 1 = side stream at the highest priority, -1 = lowest
+            int least = 0, greatest = 0;
+            CB_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+            if (e && e[0] == '1') CB_HIP(hipStreamCreateWithPriority(&c.aux, hipStreamNonBlocking, greatest));
+            else if (e && e[0] == '-') CB_HIP(hipStreamCreateWithPriority(&c.aux, hipStreamNonBlocking, least));
+            else CB_HIP(hipStreamCreateWithFlags(&c.aux, hipStreamNonBlocking));
+        }
         CB_HIP(hipStreamCreateWithFlags(&c.aux2, hipStreamNonBlocking));
         CB_HIP(hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming));
         CB_HIP(hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming));
