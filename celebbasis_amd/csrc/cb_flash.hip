@@ -14,9 +14,12 @@
 //   max/sum/rescale factors of query j are already in the lanes that hold O^T[:, j].
 // Backward = two kernels with the same trick (no atomics, deterministic): dQ (block owns 64 queries, loops over K/V tiles)
 // and dK/dV (block owns 64 keys, loops over Q/dO tiles); both recompute P from the saved log-sum-exp.
-// LDS tiles are row-major [row][S2] with S2 = DP + 4 = 4 (mod 16): both the K-style fragment read (16 rows x one column per
-// quarter) and the V-style read (one row x 16 columns per quarter) are conflict-free (FlCfg::S2; rounds 1 - 5 used 2 (mod 32), whose
-// V-style read was 2-way on half of its lanes: 34 % of the LDS-active cycles in profiles/r05_pmc_flash_f32.txt).
+// LDS tiles are row-major [row][S2] with S2 = DP + 4 (a multiple of 4: 16-byte chunks for the LDS-DMA and the float4 stores). ds_read_b32 is
+// served in two 32-lane halves over 32 banks: the V-style fragment read (row 4*quarter + r, 16 columns per quarter) is conflict-free
+// (4*S2 = 16 mod 32 puts the two quarters of a half 16 banks apart), the K-style read (16 rows x one column per quarter) is 2-way (S2*l15
+// mod 32 takes 8 values). Rounds 1 - 5 used S2 = 2 (mod 32), which has it the other way round. Measured neutral (707 vs 704 us on the 64x64-level
+// backward); bank-conflict cycles 34 -> 29 % of the LDS-active ones in dK/dV and the forward, 30 -> 38 % in dQ (profiles/r05_ / r06_pmc_flash_f32.txt):
+// the loop does not wait for LDS either way (SQ_WAIT_INST_LDS = 2.9 M of 416 M wave cycles).
 #include "cb_common.h"
 #include <type_traits>
 
@@ -38,9 +41,7 @@ template <int DT> struct FlCfg {
     static constexpr int DP = DT * 16;                          // padded head dim
     static constexpr int KS = (DT == 3) ? 10 : DT * 4;          // MFMA k-steps (4 wide) over the head dim; DT = 3 serves d <= 40
                                                                 // (SD's 64x64 attention): 10 steps, not 12 (the dispatcher sends 40 < d <= 48 to DT = 4)
-    static constexpr int S2 = DP + 4;                           // LDS row stride = 4 (mod 16): both fragment reads are conflict-free over the whole wave —
-                                                                // K-style (16 rows x one column per quarter): bank = S2*l15 + quarter, S2 mod 64 in {20, 36, 52, 4} walks the 16
-                                                                // multiples of 4; V-style (row 4*quarter + r, 16 columns): 4*S2 = 16 (mod 64) puts the quarters 16 banks apart
+    static constexpr int S2 = DP + 4;                           // LDS row stride (file header: V-style reads conflict-free, K-style 2-way; 16-byte aligned rows)
     static constexpr int TK = (DT >= 8) ? 32 : 64;              // rows of the streamed tile
     static constexpr int NT = TK / 16;                          // 16-row sub-tiles of the streamed tile
 };
