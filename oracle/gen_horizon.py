@@ -11,6 +11,8 @@ instead of on the CPU oracle:
     python oracle/gen_horizon.py fp32photo -> horizon_sd14_b1_photo.pt 800 steps of the same stream with low-pass ("photo-like") face crops (2.5 h)
     python oracle/gen_horizon.py fp32photo2 / fp32photo3 -> horizon_sd14_b1_photo{2,3}.pt  the same with other frozen weights and another batch stream
     python oracle/gen_horizon.py fp32noise2 -> horizon_sd14_b1_noise2.pt  the default (white-noise) stream with other frozen weights and another batch stream
+    python oracle/gen_horizon.py fp32photo2head / fp32photo3head / fp32noise2head -> horizon_sd14_b1_{photo2,photo3,noise2}_head.pt  their first 120 steps
+                                            with the per-step coefficients kept (30 min each)
 
 The trajectory is `oracle.cb_oracle.train_step` (pinned against the reference by oracle/gen_golden.py::gen_step) driven over
 `oracle.replay.make_batch(seed = 100 + step)` with `init_weights(seed)`; the first steps of the fp32 run are the ones
@@ -58,6 +60,16 @@ RUNS = dict(fp32=dict(B=1, steps=100, lr=5e-3, seed=8, out="horizon_sd14_b1.pt",
             # table with the host's own F.affine_grid) uses on that box: tests/test_gpu_models.py::test_train_120_steps_sd14_default_table
             fp32boxgrid=dict(B=1, steps=120, lr=5e-3, seed=8, out="horizon_sd14_b1_boxgrid.pt", grad_steps=(), slim=True, coef_steps=120,
                              grid_npz="warp_grid_gpubox_512.npz"),
+            # round 6: the first 120 steps of the three slim draws AGAIN, this time keeping the per-step coefficients of every face (the slim
+            # 800-step files hold none): the implementation's own invariant — per-step agreement, asserted at 2e-5 — on all five draws
+            # (tests/test_gpu_models.py::test_train_800_steps_sd14_more_draws; the losses / learned rows of these files must equal the slim ones')
+            # (`threads` = what the slim run had — three generators shared the host then: torch-CPU's GEMM partitioning, hence the round-off, follows it)
+            fp32photo2head=dict(B=1, steps=120, lr=5e-3, seed=9, batch_seed0=3000, out="horizon_sd14_b1_photo2_head.pt", grad_steps=(), slim=True, photo=True,
+                                coef_steps=120, id_coef_stride=4, threads=5),
+            fp32photo3head=dict(B=1, steps=120, lr=5e-3, seed=10, batch_seed0=5000, out="horizon_sd14_b1_photo3_head.pt", grad_steps=(), slim=True, photo=True,
+                                coef_steps=120, id_coef_stride=4, threads=5),
+            fp32noise2head=dict(B=1, steps=120, lr=5e-3, seed=11, batch_seed0=7000, out="horizon_sd14_b1_noise2_head.pt", grad_steps=(), slim=True,
+                                coef_steps=120, id_coef_stride=4, threads=3),
             bf16=dict(B=4, steps=20, lr=2e-2, seed=5, out="horizon_sd14_b4.pt", grad_steps=(1, 2, 5, 10, 20)),
             # round 6: config 3's stream continued to 100 steps (its first 20 are the `bf16` fixture's): a horizon beyond 20 for the bf16 path
             bf16long=dict(B=4, steps=100, lr=2e-2, seed=5, out="horizon_sd14_b4_100.pt", grad_steps=(), slim=True, coef_steps=100))

@@ -865,7 +865,22 @@ def test_train_800_steps_sd14_more_draws(cb, golden_dir, name):
     if n < 100:
         pytest.skip(f"{name}.pt holds {n} steps so far (the generator writes it every 10 steps; at least 100 are needed for a horizon claim)")
     fx["cfg"] = dict(fx["cfg"], next_weight_seed={"horizon_sd14_b1_photo2": 10, "horizon_sd14_b1_photo3": 11}.get(name))
+    # the slim files hold no per-step coefficients; <name>_head.pt (oracle/gen_horizon.py fp32*head, round 6) is the SAME oracle trajectory's
+    # first 120 steps with them — its losses and learned rows must be the slim file's, bit for bit — so that the implementation's own
+    # invariant, per-step coefficient agreement (asserted at 2e-5), is held on this draw too and not only on the default / photo streams
+    head_steps = 0
+    if os.path.exists(os.path.join(golden_dir, name + "_head.pt")):
+        hd = load(golden_dir, name + "_head.pt")
+        k = min(int(hd["steps"]), n)
+        stride = int(fx["cfg"].get("id_coef_stride", 1))
+        assert torch.equal(hd["loss"][:k], fx["loss"][:k]) and torch.equal(hd["id_coef"][:k // stride], fx["id_coef"][:k // stride]), \
+            f"{name}_head.pt is not the first {k} steps of {name}.pt"
+        fx["coef"] = hd["coef"][:k]
+        head_steps = k
     s = run_horizon(lib, ctx, fx, n, name, REPORT, dict(loss_rel_max=2e-4))
+    if head_steps:
+        REPORT[name + ".per_step_coefficient_l2_max"] = dict(steps=head_steps, value=s["coef_l2_max"])
+        assert s["coef_l2_steps"] == head_steps and s["coef_l2_max"] <= 2e-5, (name, s)
     tab = [r for r in REPORT[name + ".table"] if "id_coef_l2" in r]
     with open(f"gpurun_out/{name}.json") as f:
         rec = json.load(f)
